@@ -1,0 +1,117 @@
+// fbx_common.hpp -- shared host/device helpers of libfbx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/fbx.h"
+
+namespace fbx {
+
+// ------------------------------------------------------------------ host: errors / stream
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+hipStream_t stream();
+int ensure_device();   // FBX_OK or FBX_ERR_NO_DEVICE (message set)
+
+#define FBX_HIP(call)                                                          \
+    do {                                                                       \
+        hipError_t _e = (call);                                                \
+        if (_e != hipSuccess) return fbx::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define FBX_REQUIRE(cond, msg)                                                 \
+    do {                                                                       \
+        if (!(cond)) { fbx::set_error(msg); return FBX_ERR_BAD_ARG; }          \
+    } while (0)
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+        return FBX_OK;
+    }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------ device-side design
+struct DesignDev {
+    int n, kind, m, S, d, D;
+    int unit_coefs;          // 1 when every observable coefficient is exactly 1
+    const int* order;        // [m] grouped position -> caller's setting index
+    const uint32_t* sp;      // [m] (grouped) packed (state index << 16 | pauli index)
+    const double* coef;      // [m] (grouped)
+    const int* sptr;         // [S+1] grouped ranges per distinct input state
+    const double* C;         // [D][S] Bloch coefficients c_j(s) = tr(P_j rho_s)
+};
+
+}  // namespace fbx
+
+struct fbx_design {
+    fbx::DesignDev dev;
+    void* slab = nullptr;    // one device allocation backing every pointer in dev
+    std::vector<double> C_host;
+    std::vector<int> order_host;
+    std::vector<uint32_t> sp_host;
+    std::vector<double> coef_host;
+};
+
+namespace fbx {
+
+// ------------------------------------------------------------------ device helpers
+#if defined(__HIPCC__)
+
+struct cplx { double re, im; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// make a wave-uniform copy (lane 0's value) so branches on it are scalar
+__device__ __forceinline__ double uniform(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Pauli index (base-4 digits, qubit 0 most significant) -> x / z bit masks over the
+// computational index (qubit 0 = most significant bit) and number of Y factors.
+template <int NQ>
+__device__ __forceinline__ void pauli_masks(int idx, int& x, int& z, int& ny) {
+    x = 0; z = 0; ny = 0;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        int code = (idx >> (2 * t)) & 3;
+        int xb = (code == 1) | (code == 2);
+        int zb = (code == 2) | (code == 3);
+        x |= xb << t; z |= zb << t; ny += (code == 2);
+    }
+}
+// inverse: masks -> Pauli index
+template <int NQ>
+__device__ __forceinline__ int pauli_index(int x, int z) {
+    int idx = 0;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        int xb = (x >> t) & 1, zb = (z >> t) & 1;
+        int code = xb ? (zb ? 2 : 1) : (zb ? 3 : 0);
+        idx |= code << (2 * t);
+    }
+    return idx;
+}
+#endif
+
+}  // namespace fbx

@@ -1,0 +1,351 @@
+// fbx_pgdb.hip -- batched projected-gradient-descent-with-backtracking process tomography.
+//
+// One 64-lane wavefront owns one reconstruction for its whole life: the Choi estimate and
+// the Dykstra state live in registers (one 2x2 block per lane), work matrices and the
+// predicted-expectation tables in LDS; HBM is read once (expectations + counts) and written
+// once (Choi + counters).
+//
+// Replaces, for a batch that shares one design (file:line under forest/benchmarking/):
+//   pgdb_process_estimate   tomography.py:542-594
+//   _extract_from_results   tomography.py:494-539  (A never materialised: the Kronecker
+//                           structure A_row = vec(rho_in (x) Pi^T)/d^2 is applied as
+//                           T[s][i] = sum_j R_ij c_j(s), R = Pauli-Liouville form of E)
+//   _cost / _grad_cost      tomography.py:597-633
+//   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
+#include "fbx_choi.hpp"
+
+namespace fbx {
+
+constexpr double PGDB_EPS = 1e-6;     // probability clip, tomography.py:597,613,631
+constexpr double PGDB_GAMMA = 0.3;    // tomography.py:567
+constexpr double PGDB_STOP = 1e-10;   // tomography.py:589
+constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
+
+template <int NQ>
+struct PgdbLds {
+    ChoiLds<NQ> choi;
+    double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time)
+    double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
+    double* Tupd;   // [S*D]  same for the update direction; aliased as W[D][S] in the gradient
+    double* Cl;     // [D*S]  Bloch coefficients of the input states
+    double* hs;     // [m] (eta+ + eta-)/2 ; aliases the Jacobi work matrices
+    double* hd;     // [m] coef * (eta+ - eta-)/2
+    static size_t bytes(int S, int m) {
+        constexpr int D = ChoiLds<NQ>::D;
+        size_t choi = ChoiLds<NQ>::bytes();
+        size_t h = sizeof(double) * 2 * (size_t)m;
+        size_t jac = sizeof(cplx) * 2 * D * ChoiLds<NQ>::LD;
+        size_t extra = h > jac ? h - jac : 0;     // h aliases Mw..Vw, spill past them if longer
+        return choi + extra + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + 64;
+    }
+    __device__ void carve(char* p, int S, int m) {
+        constexpr int D = ChoiLds<NQ>::D;
+        char* base = p;
+        size_t h = sizeof(double) * 2 * (size_t)m;
+        size_t jac = sizeof(cplx) * 2 * D * ChoiLds<NQ>::LD;
+        if (h > jac) {            // put the h arrays first, Jacobi matrices inside them
+            hs = (double*)p; hd = hs + m;
+            choi.carve(p);
+            p = base + (h > ChoiLds<NQ>::bytes() ? h : ChoiLds<NQ>::bytes());
+        } else {
+            choi.carve(p);
+            hs = (double*)choi.Mw; hd = hs + m;
+        }
+        p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        Rb = (double*)p; p += sizeof(double) * D * D;
+        Test = (double*)p; p += sizeof(double) * S * D;
+        Tupd = (double*)p; p += sizeof(double) * S * D;
+        Cl = (double*)p;
+    }
+};
+
+// T[s][i] = sum_j R[i][j] * C[j][s]
+template <int NQ>
+__device__ void predict_table(const double* Rb, const double* Cl, double* T, int S, int lane) {
+    constexpr int D = ChoiLds<NQ>::D;
+    for (int idx = lane; idx < S * D; idx += 64) {
+        const int s = idx / D, i = idx % D;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < D; ++j) acc += Rb[i * D + j] * Cl[j * S + s];
+        T[idx] = acc;
+    }
+}
+
+template <int NQ, int MAXJ>
+__global__ void __launch_bounds__(64)
+pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
+            const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
+            double* __restrict__ choi_out, int* __restrict__ iters_out,
+            int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
+            double* __restrict__ cost_out, int* __restrict__ sweeps_out) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    const int m = des.m, S = des.S;
+    PgdbLds<NQ> L;
+    L.carve(smem, S, m);
+
+    for (int idx = lane; idx < D * S; idx += 64) L.Cl[idx] = des.C[idx];
+
+    // ---- data: n+-[k] = counts * (1 +- e)/2 / grand_total   (tomography.py:528-538)
+    double npl[MAXJ], nmi[MAXJ];
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int g = lane + 64 * j;
+        npl[j] = 0.0; nmi[j] = 0.0;
+        if (g < m) {
+            const int k = des.order[g];
+            const double e = expect[item * m + k], c = counts[item * m + k];
+            const double plus = (1.0 + e) / 2.0;
+            npl[j] = c * plus; nmi[j] = c * (1.0 - plus);
+            tot += c;
+        }
+    }
+    tot = uniform(wave_sum(tot));
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { npl[j] /= tot; nmi[j] /= tot; }
+
+    const double half_dd = 0.5 / (double)(d * d);      // 1 / (2 d^2)
+    const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
+
+    // negative log-likelihood at est + alpha * update from the two prediction tables
+    auto cost_at = [&](double alpha) -> double {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = lane + 64 * j;
+            if (g < m) {
+                const uint32_t sp = des.sp[g];
+                const int s = sp >> 16, p = sp & 0xffff;
+                const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+                const double tr = L.Test[s * D] + alpha * L.Tupd[s * D];
+                const double ex = cf * (L.Test[s * D + p] + alpha * L.Tupd[s * D + p]);
+                double pp = (tr + ex) * half_dd, pm = (tr - ex) * half_dd;
+                pp = pp < PGDB_EPS ? PGDB_EPS : pp;
+                pm = pm < PGDB_EPS ? PGDB_EPS : pm;
+                acc -= npl[j] * log(pp) + nmi[j] * log(pm);
+            }
+        }
+        return uniform(wave_sum(acc));
+    };
+
+    // ---- initial estimate I_D / d (tomography.py:564) in block layout
+    Blk est = blk_zero();
+    if (lane < NACT) {
+        const int I = lane / NB, J = lane % NB;
+        if (I == J) { est.re[0] = 1.0 / d; est.re[3] = 1.0 / d; }
+    }
+    __syncthreads();
+    // zero update table so cost_at(0) sees only Test
+    for (int idx = lane; idx < S * D; idx += 64) L.Tupd[idx] = 0.0;
+
+    int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
+    double old_cost = 0.0, new_cost = 0.0;
+    bool have_cost = false;
+
+    while (true) {
+        if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
+        // ---- prediction table of the current estimate
+        __syncthreads();
+        blk_store<D, LD>(L.choi.Mw, lane, est);
+        __syncthreads();
+        choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
+        __syncthreads();
+        predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
+        __syncthreads();
+        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }   // tomography.py:565
+
+        // ---- gradient (tomography.py:617-633): eta = n / clip(p); W_s = sum eta Pi
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = lane + 64 * j;
+            if (g < m) {
+                const uint32_t sp = des.sp[g];
+                const int s = sp >> 16, p = sp & 0xffff;
+                const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+                const double tr = L.Test[s * D], ex = cf * L.Test[s * D + p];
+                double pp = (tr + ex) * half_dd, pm = (tr - ex) * half_dd;
+                pp = pp < PGDB_EPS ? PGDB_EPS : pp;
+                pm = pm < PGDB_EPS ? PGDB_EPS : pm;
+                const double ep = npl[j] / pp, em = nmi[j] / pm;
+                L.hs[g] = 0.5 * (ep + em);
+                L.hd[g] = cf * 0.5 * (ep - em);
+            }
+        }
+        double* W = L.Tupd;                         // [D][S]
+        for (int idx = lane; idx < D * S; idx += 64) W[idx] = 0.0;
+        __syncthreads();
+        for (int s = lane; s < S; s += 64) {        // one lane owns one input state: no atomics
+            double w0 = 0.0;
+            for (int g = des.sptr[s]; g < des.sptr[s + 1]; ++g) {
+                const int p = des.sp[g] & 0xffff;
+                w0 += L.hs[g];
+                W[p * S + s] += L.hd[g];
+            }
+            W[s] += w0;                              // row i = 0 (identity component)
+        }
+        __syncthreads();
+        // R-coefficients of the gradient: Rg_ij = -(1/d^2) sum_s W[i][s] C[j][s]
+        for (int idx = lane; idx < D * D; idx += 64) {
+            const int i = idx / D, j = idx % D;
+            double acc = 0.0;
+            for (int s = 0; s < S; ++s) acc += W[i * S + s] * L.Cl[j * S + s];
+            L.Rb[idx] = -acc / (double)(d * d);
+        }
+        __syncthreads();
+        const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, lane);
+
+        // ---- projected step (tomography.py:572)
+        const Blk x = blk_axpy(est, -inv_mu, grad);
+        const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps);
+        const Blk upd = blk_sub(proj, est);
+
+        // ---- prediction table of the update direction
+        __syncthreads();
+        blk_store<D, LD>(L.choi.Mw, lane, upd);
+        __syncthreads();
+        choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
+        __syncthreads();
+        predict_table<NQ>(L.Rb, L.Cl, L.Tupd, S, lane);
+        __syncthreads();
+
+        // ---- backtracking line search (tomography.py:575-585)
+        double ipr, ipi;
+        blk_dotc(upd, grad, ipr, ipi);
+        ipr = uniform(wave_sum(ipr));
+        double alpha = 1.0;
+        new_cost = cost_at(alpha);
+        double change = PGDB_GAMMA * alpha * ipr;
+        while (new_cost > old_cost + change) {
+            alpha *= 0.5;
+            change *= 0.5;
+            new_cost = cost_at(alpha);
+            ++backtracks;
+            if (alpha < PGDB_ALPHA_MIN) break;
+        }
+        est = blk_axpy(est, alpha, upd);            // tomography.py:588
+        ++iters;
+        if (mode == FBX_MODE_CONVERGE) {
+            if (old_cost - new_cost < PGDB_STOP) break;          // tomography.py:589
+            if (max_iters > 0 && iters >= max_iters) break;
+        }
+        old_cost = new_cost;
+    }
+
+    // ---- write back
+    if (lane < NACT) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+            double* o = choi_out + ((item * D + row) * D + col) * 2;
+            o[0] = est.re[e]; o[1] = est.im[e];
+        }
+    }
+    if (lane == 0) {
+        if (iters_out) iters_out[item] = iters;
+        if (dykstra_out) dykstra_out[item] = dyk;
+        if (backtracks_out) backtracks_out[item] = backtracks;
+        if (cost_out) cost_out[item] = have_cost ? new_cost : 0.0;
+        if (sweeps_out) sweeps_out[item] = sweeps;
+    }
+}
+
+template <int NQ, int MAXJ>
+static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
+                       int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
+                       double* cost) {
+    const size_t lds = PgdbLds<NQ>::bytes(des->dev.S, des->dev.m);
+    if (lds > 160 * 1024) {
+        set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
+        return FBX_ERR_UNSUPPORTED;
+    }
+    auto kern = pgdb_kernel<NQ, MAXJ>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream(), des->dev, (long long)B, e, c, tp,
+                       mode, max_iters, choi, it, dy, bt, cost, (int*)nullptr);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
+                         int mode, int max_iters, double* choi, int32_t* it, int32_t* dy,
+                         int32_t* bt, double* cost) {
+    const int n = des->dev.n, m = des->dev.m;
+    if (n == 1) {
+        if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+        if (m <= 256) return launch_pgdb<1, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+    } else if (n == 2) {
+        if (m <= 256) return launch_pgdb<2, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+        if (m <= 576) return launch_pgdb<2, 9>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+        if (m <= 1024) return launch_pgdb<2, 16>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+    }
+    set_error("fbx_pgdb_process: this build handles 1- and 2-qubit designs (m <= 256 / 1024)");
+    return FBX_ERR_UNSUPPORTED;
+}
+
+static int pgdb_check(const fbx_design* des, int64_t B, const void* e, const void* c, int mode,
+                      int max_iters, const void* choi) {
+    FBX_REQUIRE(des != nullptr, "fbx_pgdb_process: NULL design");
+    FBX_REQUIRE(des->dev.kind == FBX_KIND_PROCESS, "fbx_pgdb_process: needs a process design");
+    FBX_REQUIRE(B >= 0, "fbx_pgdb_process: negative batch");
+    FBX_REQUIRE(B == 0 || (e && c && choi), "fbx_pgdb_process: NULL buffer");
+    FBX_REQUIRE(mode == FBX_MODE_CONVERGE || mode == FBX_MODE_FIXED, "fbx_pgdb_process: bad mode");
+    FBX_REQUIRE(max_iters >= 0, "fbx_pgdb_process: negative max_iters");
+    return FBX_OK;
+}
+
+}  // namespace fbx
+
+using namespace fbx;
+
+extern "C" {
+
+int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                         const double* d_counts, int trace_preserving, int mode, int max_iters,
+                         double* d_choi_out, int32_t* d_iters_out, int32_t* d_dykstra_out,
+                         int32_t* d_backtracks_out, double* d_cost_out) {
+    int rc = pgdb_check(design, B, d_expect, d_counts, mode, max_iters, d_choi_out);
+    if (rc) return rc;
+    rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return FBX_OK;
+    return pgdb_dispatch(design, B, d_expect, d_counts, trace_preserving, mode, max_iters,
+                         d_choi_out, d_iters_out, d_dykstra_out, d_backtracks_out, d_cost_out);
+}
+
+int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
+                     const double* counts, int trace_preserving, int mode, int max_iters,
+                     double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
+                     int32_t* backtracks_out, double* cost_out) {
+    int rc = pgdb_check(design, B, expect, counts, mode, max_iters, choi_out);
+    if (rc) return rc;
+    rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return FBX_OK;
+    const size_t m = design->dev.m, D = design->dev.D;
+    DevBuf de, dc, dchoi, dit, ddy, dbt, dcost;
+    if ((rc = de.alloc(sizeof(double) * B * m)) || (rc = dc.alloc(sizeof(double) * B * m)) ||
+        (rc = dchoi.alloc(sizeof(double) * 2 * B * D * D)) || (rc = dit.alloc(sizeof(int32_t) * B)) ||
+        (rc = ddy.alloc(sizeof(int32_t) * B)) || (rc = dbt.alloc(sizeof(int32_t) * B)) ||
+        (rc = dcost.alloc(sizeof(double) * B)))
+        return rc;
+    FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(dc.p, counts, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
+    rc = pgdb_dispatch(design, B, de.as<double>(), dc.as<double>(), trace_preserving, mode, max_iters,
+                       dchoi.as<double>(), dit.as<int32_t>(), ddy.as<int32_t>(), dbt.as<int32_t>(),
+                       dcost.as<double>());
+    if (rc) return rc;
+    FBX_HIP(hipMemcpyAsync(choi_out, dchoi.p, sizeof(double) * 2 * B * D * D, hipMemcpyDeviceToHost, stream()));
+    if (iters_out) FBX_HIP(hipMemcpyAsync(iters_out, dit.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+    if (dykstra_out) FBX_HIP(hipMemcpyAsync(dykstra_out, ddy.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+    if (backtracks_out) FBX_HIP(hipMemcpyAsync(backtracks_out, dbt.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+    if (cost_out) FBX_HIP(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+// fbx_runtime.hip -- library lifecycle, device memory helpers, HIP-event timing, designs.
+#include "fbx_common.hpp"
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <map>
+
+namespace fbx {
+
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static int g_device = -1;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e),
+             what, file, line);
+    g_err = buf;
+    return e == hipErrorOutOfMemory ? FBX_ERR_NOMEM : FBX_ERR_HIP;
+}
+
+int ensure_device() {
+    if (g_device >= 0) return FBX_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("libfbx: no HIP device visible -- the MI355X path has no CPU fallback");
+        return FBX_ERR_NO_DEVICE;
+    }
+    return fbx_set_device(0);
+}
+
+hipStream_t stream() { return g_stream; }
+
+}  // namespace fbx
+
+using namespace fbx;
+
+extern "C" {
+
+int fbx_version(void) { return 100; }
+
+const char* fbx_last_error(void) { return g_err.c_str(); }
+
+int fbx_device_count(int* count) {
+    FBX_REQUIRE(count != nullptr, "fbx_device_count: NULL argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return FBX_OK;
+}
+
+int fbx_set_device(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("libfbx: no HIP device visible -- the MI355X path has no CPU fallback");
+        return FBX_ERR_NO_DEVICE;
+    }
+    FBX_REQUIRE(device_id >= 0 && device_id < n, "fbx_set_device: device id out of range");
+    FBX_HIP(hipSetDevice(device_id));
+    if (g_stream && g_device != device_id) {
+        (void)hipStreamDestroy(g_stream); g_stream = nullptr;
+        if (g_ev0) { (void)hipEventDestroy(g_ev0); g_ev0 = nullptr; }
+        if (g_ev1) { (void)hipEventDestroy(g_ev1); g_ev1 = nullptr; }
+    }
+    if (!g_stream) FBX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device_id;
+    return FBX_OK;
+}
+
+int fbx_device_name(char* buf, size_t len, int* compute_units) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    FBX_HIP(hipGetDeviceProperties(&prop, g_device));
+    if (buf && len) snprintf(buf, len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    return FBX_OK;
+}
+
+int fbx_synchronize(void) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    FBX_HIP(hipStreamSynchronize(g_stream));
+    return FBX_OK;
+}
+
+int fbx_malloc(void** dev_ptr, size_t bytes) {
+    FBX_REQUIRE(dev_ptr != nullptr, "fbx_malloc: NULL argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    FBX_HIP(hipMalloc(dev_ptr, bytes ? bytes : 16));
+    return FBX_OK;
+}
+
+int fbx_free(void* dev_ptr) {
+    if (!dev_ptr) return FBX_OK;
+    FBX_HIP(hipFree(dev_ptr));
+    return FBX_OK;
+}
+
+int fbx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    FBX_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, g_stream));
+    FBX_HIP(hipStreamSynchronize(g_stream));
+    return FBX_OK;
+}
+
+int fbx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    FBX_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, g_stream));
+    FBX_HIP(hipStreamSynchronize(g_stream));
+    return FBX_OK;
+}
+
+int fbx_timer_begin(void) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!g_ev0) { FBX_HIP(hipEventCreate(&g_ev0)); FBX_HIP(hipEventCreate(&g_ev1)); }
+    FBX_HIP(hipEventRecord(g_ev0, g_stream));
+    return FBX_OK;
+}
+
+int fbx_timer_end(double* elapsed_ms) {
+    FBX_REQUIRE(elapsed_ms != nullptr && g_ev0 != nullptr, "fbx_timer_end without fbx_timer_begin");
+    FBX_HIP(hipEventRecord(g_ev1, g_stream));
+    FBX_HIP(hipEventSynchronize(g_ev1));
+    float ms = 0.f;
+    FBX_HIP(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+    *elapsed_ms = ms;
+    return FBX_OK;
+}
+
+// ---------------------------------------------------------------------------- designs
+// One-qubit state vectors of pyquil.simulation.matrices.STATES (pyquil==4.5.0), restated
+// (SURVEY.md 8a-a3); Bloch components r = (1, tr(X rho), tr(Y rho), tr(Z rho)).
+static void bloch_of_state(int code, double r[4]) {
+    using cd = std::complex<double>;
+    const double s2 = std::sqrt(2.0), s3 = std::sqrt(3.0);
+    const double pi = 3.14159265358979323846;
+    cd v0, v1;
+    switch (code) {
+        case 0: v0 = 1 / s2; v1 = 1 / s2; break;
+        case 1: v0 = 1 / s2; v1 = -1 / s2; break;
+        case 2: v0 = 1 / s2; v1 = cd(0, 1 / s2); break;
+        case 3: v0 = 1 / s2; v1 = cd(0, -1 / s2); break;
+        case 4: v0 = 1; v1 = 0; break;
+        case 5: v0 = 0; v1 = 1; break;
+        case 6: v0 = 1; v1 = 0; break;
+        case 7: v0 = 1 / s3; v1 = s2 / s3; break;
+        case 8: v0 = 1 / s3; v1 = std::exp(cd(0, -2 * pi / 3)) * s2 / s3; break;
+        default: v0 = 1 / s3; v1 = std::exp(cd(0, 2 * pi / 3)) * s2 / s3; break;
+    }
+    cd r00 = v0 * std::conj(v0), r01 = v0 * std::conj(v1), r11 = v1 * std::conj(v1);
+    r[0] = (r00 + r11).real();
+    r[1] = 2 * r01.real();
+    r[2] = -2 * r01.imag();
+    r[3] = (r00 - r11).real();
+}
+
+int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
+                      const uint8_t* paulis, const double* coefs, fbx_design** out) {
+    FBX_REQUIRE(out != nullptr, "fbx_design_create: NULL out");
+    *out = nullptr;
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_design_create: n_qubits must be 1..3");
+    FBX_REQUIRE(kind == FBX_KIND_STATE || kind == FBX_KIND_PROCESS, "fbx_design_create: bad kind");
+    FBX_REQUIRE(m >= 1 && m < 65536, "fbx_design_create: m must be in [1, 65535]");
+    FBX_REQUIRE(paulis != nullptr, "fbx_design_create: NULL paulis");
+    FBX_REQUIRE(kind == FBX_KIND_STATE || in_labels != nullptr,
+                "fbx_design_create: process designs need in_labels");
+    const int n = n_qubits, d = 1 << n, D = d * d;
+    for (int k = 0; k < m * n; ++k) {
+        FBX_REQUIRE(paulis[k] < 4, "fbx_design_create: Pauli code out of range");
+        if (kind == FBX_KIND_PROCESS)
+            FBX_REQUIRE(in_labels[k] < 10, "fbx_design_create: input-state code out of range");
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+
+    // distinct input states in first-appearance order
+    std::vector<int> sidx(m, 0), pidx(m, 0);
+    std::vector<std::vector<int>> states;
+    std::map<int, int> key2s;
+    for (int k = 0; k < m; ++k) {
+        int pk = 0;
+        for (int q = 0; q < n; ++q) pk = pk * 4 + paulis[k * n + q];
+        pidx[k] = pk;
+        int key = 0;
+        if (kind == FBX_KIND_PROCESS)
+            for (int q = 0; q < n; ++q) key = key * 10 + in_labels[k * n + q];
+        auto it = key2s.find(key);
+        if (it == key2s.end()) {
+            int s = (int)states.size();
+            key2s[key] = s;
+            std::vector<int> codes(n, 4);
+            if (kind == FBX_KIND_PROCESS)
+                for (int q = 0; q < n; ++q) codes[q] = in_labels[k * n + q];
+            states.push_back(codes);
+            sidx[k] = s;
+        } else {
+            sidx[k] = it->second;
+        }
+    }
+    const int S = (int)states.size();
+
+    auto* des = new fbx_design();
+    // Bloch coefficient matrix C[j][s] = prod_q r^{(q)}_{digit_q(j)}(s)
+    des->C_host.assign((size_t)D * S, 0.0);
+    for (int s = 0; s < S; ++s) {
+        std::vector<double> r(4 * n);
+        for (int q = 0; q < n; ++q) bloch_of_state(states[s][q], &r[4 * q]);
+        for (int j = 0; j < D; ++j) {
+            double c = 1.0;
+            for (int q = 0; q < n; ++q) {
+                int digit = (j >> (2 * (n - 1 - q))) & 3;
+                c *= r[4 * q + digit];
+            }
+            des->C_host[(size_t)j * S + s] = c;
+        }
+    }
+    // stable grouping of settings by input state
+    std::vector<int> order(m);
+    for (int k = 0; k < m; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sidx[a] < sidx[b]; });
+    std::vector<int> sptr(S + 1, 0);
+    for (int k = 0; k < m; ++k) sptr[sidx[k] + 1]++;
+    for (int s = 0; s < S; ++s) sptr[s + 1] += sptr[s];
+    des->order_host = order;
+    des->sp_host.resize(m);
+    des->coef_host.resize(m);
+    int unit = 1;
+    for (int g = 0; g < m; ++g) {
+        int k = order[g];
+        des->sp_host[g] = ((uint32_t)sidx[k] << 16) | (uint32_t)pidx[k];
+        des->coef_host[g] = coefs ? coefs[k] : 1.0;
+        if (des->coef_host[g] != 1.0) unit = 0;
+    }
+
+    // one slab: C | coef | order | sp | sptr
+    size_t oC = 0, oCoef = oC + sizeof(double) * D * S, oOrder = oCoef + sizeof(double) * m;
+    size_t oSp = oOrder + sizeof(int) * m, oPtr = oSp + sizeof(uint32_t) * m;
+    size_t total = oPtr + sizeof(int) * (S + 1);
+    std::vector<char> host(total);
+    memcpy(&host[oC], des->C_host.data(), sizeof(double) * D * S);
+    memcpy(&host[oCoef], des->coef_host.data(), sizeof(double) * m);
+    memcpy(&host[oOrder], order.data(), sizeof(int) * m);
+    memcpy(&host[oSp], des->sp_host.data(), sizeof(uint32_t) * m);
+    memcpy(&host[oPtr], sptr.data(), sizeof(int) * (S + 1));
+    hipError_t e = hipMalloc(&des->slab, total);
+    if (e != hipSuccess) { delete des; return hip_fail(e, "hipMalloc(design)", __FILE__, __LINE__); }
+    e = hipMemcpy(des->slab, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(des->slab); delete des;
+        return hip_fail(e, "hipMemcpy(design)", __FILE__, __LINE__);
+    }
+    char* base = (char*)des->slab;
+    des->dev.n = n; des->dev.kind = kind; des->dev.m = m; des->dev.S = S; des->dev.d = d;
+    des->dev.D = D; des->dev.unit_coefs = unit;
+    des->dev.C = (const double*)(base + oC);
+    des->dev.coef = (const double*)(base + oCoef);
+    des->dev.order = (const int*)(base + oOrder);
+    des->dev.sp = (const uint32_t*)(base + oSp);
+    des->dev.sptr = (const int*)(base + oPtr);
+    *out = des;
+    return FBX_OK;
+}
+
+int fbx_design_destroy(fbx_design* design) {
+    if (!design) return FBX_OK;
+    if (design->slab) (void)hipFree(design->slab);
+    delete design;
+    return FBX_OK;
+}
+
+int fbx_design_info(const fbx_design* design, int* n_qubits, int* kind, int* m,
+                    int* n_input_states) {
+    FBX_REQUIRE(design != nullptr, "fbx_design_info: NULL design");
+    if (n_qubits) *n_qubits = design->dev.n;
+    if (kind) *kind = design->dev.kind;
+    if (m) *m = design->dev.m;
+    if (n_input_states) *n_input_states = design->dev.S;
+    return FBX_OK;
+}
+
+}  // extern "C"

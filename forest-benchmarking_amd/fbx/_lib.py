@@ -1,0 +1,176 @@
+"""ctypes binding of libfbx.so (include/fbx.h).  No compute happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libfbx.so")
+
+FBX_OK, FBX_ERR_BAD_ARG, FBX_ERR_HIP, FBX_ERR_NO_DEVICE, FBX_ERR_UNSUPPORTED, FBX_ERR_NOMEM = range(6)
+KIND_STATE, KIND_PROCESS = 0, 1
+MODE_CONVERGE, MODE_FIXED = 0, 1
+REP_KRAUS, REP_CHOI, REP_SUPEROP, REP_PAULI_LIOUVILLE, REP_CHI = range(5)
+PROJ_CP, PROJ_TP, PROJ_TNI, PROJ_PHYSICAL_TP, PROJ_PHYSICAL_TNI = range(5)
+
+
+class FbxError(RuntimeError):
+    """A non-argument failure inside libfbx (HIP error, no device, unsupported size)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libfbx error {code}: {message}")
+        self.code = code
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> argtypes; every symbol include/fbx.h declares (tests/test_abi.py checks the list)
+PROTOTYPES = {
+    "fbx_version": [],
+    "fbx_last_error": [],
+    "fbx_device_count": [C.POINTER(C.c_int)],
+    "fbx_set_device": [C.c_int],
+    "fbx_device_name": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
+    "fbx_synchronize": [],
+    "fbx_malloc": [C.POINTER(_vp), C.c_size_t],
+    "fbx_free": [_vp],
+    "fbx_memcpy_h2d": [_vp, _vp, C.c_size_t],
+    "fbx_memcpy_d2h": [_vp, _vp, C.c_size_t],
+    "fbx_timer_begin": [],
+    "fbx_timer_end": [_dp],
+    "fbx_design_create": [C.c_int, C.c_int, C.c_int, _u8p, _u8p, _dp, C.POINTER(_vp)],
+    "fbx_design_destroy": [_vp],
+    "fbx_design_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                        C.POINTER(C.c_int)],
+    "fbx_pgdb_process": [_vp, _i64, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _ip, _ip, _ip, _dp],
+    "fbx_pgdb_process_dev": [_vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
+    "fbx_linv_process": [_vp, _i64, _dp, _dp],
+    "fbx_linv_state": [_vp, _i64, _dp, _dp],
+    "fbx_mle_state": [_vp, _i64, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double,
+                      C.c_int, _dp, _ip, _ip],
+    "fbx_r_operator": [_vp, _i64, _dp, _dp, _dp],
+    "fbx_state_log_likelihood": [_vp, _i64, _dp, _dp, _dp, _dp],
+    "fbx_convert": [C.c_int, C.c_int, C.c_int, _i64, _dp, C.c_int, _dp],
+    "fbx_kraus_sweep": [C.c_int, _i64, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp],
+    "fbx_kraus_sweep_dev": [C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fbx_proj_choi": [C.c_int, C.c_int, _i64, _dp, _dp, _ip],
+    "fbx_proj_state_physical": [C.c_int, _i64, _dp, _dp],
+    "fbx_apply_choi": [C.c_int, _i64, _dp, _dp, _dp],
+    "fbx_process_fidelity": [C.c_int, _i64, _dp, _dp, _dp, _dp],
+    "fbx_state_measures": [C.c_int, _i64, _dp, _dp, _dp, _dp, _dp, _dp],
+}
+
+
+def lib():
+    """The loaded library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise FbxError(-1, f"{_LIB_PATH} is missing: build it with "
+                               f"`python -c 'import __graft_entry__ as g; g.build()'` "
+                               f"(there is no CPU fallback)")
+        handle = C.CDLL(_LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_char_p if name == "fbx_last_error" else C.c_int
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    """Map an ABI return code to the reference's exception types."""
+    if code == FBX_OK:
+        return
+    msg = lib().fbx_last_error().decode("utf-8", "replace")
+    if code == FBX_ERR_BAD_ARG:
+        raise ValueError(msg)
+    raise FbxError(code, msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().fbx_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(idx: int):
+    check(lib().fbx_set_device(int(idx)))
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    check(lib().fbx_device_name(buf, 256, C.byref(cus)))
+    return buf.value.decode(), cus.value
+
+
+def synchronize():
+    check(lib().fbx_synchronize())
+
+
+# ------------------------------------------------------------------ numpy <-> pointer helpers
+def f64(a, shape=None):
+    """C-contiguous float64 view/copy (complex128 arrays are viewed as interleaved pairs)."""
+    a = np.ascontiguousarray(a)
+    if np.iscomplexobj(a):
+        a = np.ascontiguousarray(a, dtype=np.complex128).view(np.float64)
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+    return a
+
+
+def c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+class DeviceBuffer:
+    """A caller-owned HBM allocation (for batches that stay resident between calls)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = _vp()
+        check(lib().fbx_malloc(C.byref(p), self.nbytes))
+        self.ptr = p
+
+    @classmethod
+    def from_array(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(arr.nbytes)
+        check(lib().fbx_memcpy_h2d(buf.ptr, arr.ctypes.data_as(_vp), arr.nbytes))
+        return buf
+
+    def to_array(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().fbx_memcpy_d2h(out.ctypes.data_as(_vp), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr is not None:
+            lib().fbx_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

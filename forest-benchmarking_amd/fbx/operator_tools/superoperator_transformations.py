@@ -1,0 +1,182 @@
+"""Superoperator representation changes on MI355X.
+
+Mirror of operator_tools/superoperator_transformations.py:33-438.  ``vec`` / ``unvec`` are
+host-side reshapes exactly as in the reference; every conversion runs in libfbx
+(``fbx_convert``).  ``*_batch`` helpers accept stacked inputs ``[B, ...]``.  Conversions *to*
+Kraus operators are eigenvector-valued (defined only up to phase / degeneracy,
+superoperator_transformations.py:325-336) and are not offered.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .. import _lib
+
+_REPS = {"kraus": _lib.REP_KRAUS, "choi": _lib.REP_CHOI, "superop": _lib.REP_SUPEROP,
+         "pauli_liouville": _lib.REP_PAULI_LIOUVILLE, "chi": _lib.REP_CHI}
+
+__all__ = ["vec", "unvec", "convert_batch", "kraus2chi", "kraus2superop", "kraus2pauli_liouville",
+           "kraus2choi", "chi2pauli_liouville", "chi2superop", "chi2choi", "superop2chi",
+           "superop2pauli_liouville", "superop2choi", "pauli_liouville2chi",
+           "pauli_liouville2superop", "pauli_liouville2choi", "choi2chi", "choi2superop",
+           "choi2pauli_liouville", "pauli2computational_basis_matrix",
+           "computational2pauli_basis_matrix"]
+
+
+def vec(matrix: np.ndarray) -> np.ndarray:
+    """Column-stacking vectorisation (superoperator_transformations.py:33-51)."""
+    return np.asarray(matrix).T.reshape((-1, 1))
+
+
+def unvec(vector: np.ndarray, shape: Optional[Tuple[int, int]] = None) -> np.ndarray:
+    """Inverse of vec (superoperator_transformations.py:54-79)."""
+    vector = np.asarray(vector)
+    if shape is None:
+        dim = int(np.sqrt(vector.size))
+        shape = dim, dim
+    return vector.reshape(*shape).T
+
+
+def _nq_from_D(D):
+    d = int(round(np.sqrt(D)))
+    n = int(round(np.log2(d)))
+    if 4 ** n != D:
+        raise ValueError("superoperator dimension must be a power of four")
+    return n
+
+
+def convert_batch(src: str, dst: str, x) -> np.ndarray:
+    """Stacked conversion: x is [B, K, d, d] for src == 'kraus', else [B, D, D]; returns [B, D, D]."""
+    x = _lib.c128(x)
+    if src == "kraus":
+        if x.ndim != 4 or x.shape[-1] != x.shape[-2]:
+            raise ValueError("kraus input must be [B, K, d, d] with square operators")
+        B, K, d = x.shape[0], x.shape[1], x.shape[-1]
+        n = int(round(np.log2(d)))
+        if 2 ** n != d:
+            raise ValueError("Kraus dimension must be a power of two")
+    else:
+        if x.ndim != 3 or x.shape[-1] != x.shape[-2]:
+            raise ValueError("input must be [B, D, D]")
+        B, K = x.shape[0], 0
+        n = _nq_from_D(x.shape[-1])
+    D = 4 ** n
+    out = np.empty((B, D, D), dtype=np.complex128)
+    _lib.check(_lib.lib().fbx_convert(_REPS[src], _REPS[dst], n, B, _lib.dptr(x.view(np.float64)),
+                                      K, _lib.dptr(out.view(np.float64))))
+    return out
+
+
+def _kraus_stack(kraus_ops):
+    """single-ndarray-as-one-operator convenience (superoperator_transformations.py:90-92)."""
+    if isinstance(kraus_ops, np.ndarray):
+        if len(kraus_ops[0].shape) < 2:
+            kraus_ops = [kraus_ops]
+    return np.stack([np.asarray(k, dtype=np.complex128) for k in kraus_ops])[None]
+
+
+def _one(src, dst, x):
+    return convert_batch(src, dst, np.asarray(x)[None])[0]
+
+
+def kraus2chi(kraus_ops):
+    """superoperator_transformations.py:82-97."""
+    return convert_batch("kraus", "chi", _kraus_stack(kraus_ops))[0]
+
+
+def kraus2superop(kraus_ops):
+    """superoperator_transformations.py:100-145 (square Kraus operators)."""
+    return convert_batch("kraus", "superop", _kraus_stack(kraus_ops))[0]
+
+
+def kraus2pauli_liouville(kraus_ops):
+    """superoperator_transformations.py:148-156."""
+    return convert_batch("kraus", "pauli_liouville", _kraus_stack(kraus_ops))[0]
+
+
+def kraus2choi(kraus_ops):
+    """superoperator_transformations.py:159-182."""
+    return convert_batch("kraus", "choi", _kraus_stack(kraus_ops))[0]
+
+
+def chi2pauli_liouville(chi_matrix):
+    """superoperator_transformations.py:185-192."""
+    return _one("chi", "pauli_liouville", chi_matrix)
+
+
+def chi2superop(chi_matrix):
+    """superoperator_transformations.py:207-214."""
+    return _one("chi", "superop", chi_matrix)
+
+
+def chi2choi(chi_matrix):
+    """superoperator_transformations.py:217-226."""
+    return _one("chi", "choi", chi_matrix)
+
+
+def superop2chi(superop):
+    """superoperator_transformations.py:241-250."""
+    return _one("superop", "chi", superop)
+
+
+def superop2pauli_liouville(superop):
+    """superoperator_transformations.py:253-264."""
+    return _one("superop", "pauli_liouville", superop)
+
+
+def superop2choi(superop):
+    """superoperator_transformations.py:267-277."""
+    return _one("superop", "choi", superop)
+
+
+def pauli_liouville2chi(pl_matrix):
+    """superoperator_transformations.py:291-298."""
+    return _one("pauli_liouville", "chi", pl_matrix)
+
+
+def pauli_liouville2superop(pl_matrix):
+    """superoperator_transformations.py:301-312."""
+    return _one("pauli_liouville", "superop", pl_matrix)
+
+
+def pauli_liouville2choi(pl_matrix):
+    """superoperator_transformations.py:315-322."""
+    return _one("pauli_liouville", "choi", pl_matrix)
+
+
+def choi2chi(choi):
+    """superoperator_transformations.py:339-348 (through the eigendecomposition: |C| for
+    non-CP input, eigenvalues with |lambda| <= 1e-9 dropped -- reproduced on the device)."""
+    return _one("choi", "chi", choi)
+
+
+def choi2superop(choi):
+    """superoperator_transformations.py:351-361."""
+    return _one("choi", "superop", choi)
+
+
+def choi2pauli_liouville(choi):
+    """superoperator_transformations.py:364-371."""
+    return _one("choi", "pauli_liouville", choi)
+
+
+def pauli2computational_basis_matrix(dim) -> np.ndarray:
+    """superoperator_transformations.py:374-408: p2c = chi2choi-style basis change applied to
+    the identity is not needed -- the matrix is the superop form of the identity Pauli-Liouville
+    basis; obtained from the device conversion of unit vectors."""
+    n = int(np.log2(dim))
+    D = dim ** 2
+    # columns are vec(P_k): superop of the map with Pauli-Liouville matrix e_k e_0^T ... simpler:
+    # p2c[:, k] = vec(P_k); chi2choi(E_kk) = vec(P_k) vec(P_k)^H, whose first non-zero column
+    # gives vec(P_k) up to the (known, real-positive for these matrices) normalisation.
+    eye = np.zeros((D, D, D), dtype=np.complex128)
+    for k in range(D):
+        eye[k, k, 0] = 1.0          # chi = e_k e_0^T  ->  choi = vec(P_k) vec(P_0)^H
+    choi = convert_batch("chi", "choi", eye)
+    # vec(P_0) = vec(I) has ones at the diagonal positions; row 0 / col 0 entry is 1
+    return np.ascontiguousarray(choi[:, :, 0].T)
+
+
+def computational2pauli_basis_matrix(dim) -> np.ndarray:
+    """superoperator_transformations.py:411-438."""
+    return pauli2computational_basis_matrix(dim).conj().T / dim

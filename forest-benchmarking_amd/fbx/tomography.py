@@ -1,0 +1,256 @@
+"""Tomography estimators with the reference's names and signatures, running on MI355X.
+
+Mirror of forest/benchmarking/tomography.py:130-633.  Every estimator takes the same
+``(results: List[ExperimentResult], qubits: List[int], **kwargs)`` and returns the same dense
+complex128 ``np.ndarray``; ``*_batch`` variants take SoA arrays ``expectations[B, m]``,
+``total_counts[B, m]`` plus a :class:`fbx.design.Design` and are where the throughput lives.
+"""
+import warnings
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from . import distance_measures as dm
+from .design import Design, flatten_results, process_design, state_design  # noqa: F401
+from .observable_estimation import (ExperimentResult, ExperimentSetting, PauliTerm,
+                                    TensorProductState, zeros_state, SIC0, SIC1, SIC2, SIC3,
+                                    plusX, minusX, plusY, minusY, plusZ, minusZ)
+from .design import traceless_pauli_codes, PAULI_LABELS
+
+import functools
+import itertools
+from operator import mul
+
+
+# ==================================================================================================
+# Experiment settings (tomography.py:31-123) -- pure bookkeeping, no pyquil Program needed
+# ==================================================================================================
+def _traceless_pauli_terms(qubits):
+    terms = []
+    for codes in traceless_pauli_codes(len(qubits)):
+        terms.append(PauliTerm({q: PAULI_LABELS[c] for q, c in zip(qubits, codes)}))
+    return terms
+
+
+def _state_tomo_settings(qubits: Sequence[int]):
+    for obs in _traceless_pauli_terms(qubits):
+        yield ExperimentSetting(in_state=zeros_state(qubits), observable=obs)
+
+
+def _sic_process_tomo_settings(qubits: Sequence[int]):
+    for in_sics in itertools.product([SIC0, SIC1, SIC2, SIC3], repeat=len(qubits)):
+        i_state = functools.reduce(mul, (state(q) for state, q in zip(in_sics, qubits)),
+                                   TensorProductState())
+        for obs in _traceless_pauli_terms(qubits):
+            yield ExperimentSetting(in_state=i_state, observable=obs)
+
+
+def _pauli_process_tomo_settings(qubits):
+    for states in itertools.product([plusX, minusX, plusY, minusY, plusZ, minusZ],
+                                    repeat=len(qubits)):
+        i_state = functools.reduce(mul, (state(q) for state, q in zip(states, qubits)),
+                                   TensorProductState())
+        for obs in _traceless_pauli_terms(qubits):
+            yield ExperimentSetting(in_state=i_state, observable=obs)
+
+
+def generate_state_tomography_settings(qubits: List[int]) -> List[ExperimentSetting]:
+    """The settings of generate_state_tomography_experiment (tomography.py:46-60)."""
+    return list(_state_tomo_settings(qubits))
+
+
+def generate_process_tomography_settings(qubits: List[int], in_basis='pauli') -> List[ExperimentSetting]:
+    """The settings of generate_process_tomography_experiment (tomography.py:100-123)."""
+    if in_basis.upper() == 'SIC':
+        func = _sic_process_tomo_settings
+    elif in_basis.upper() == 'PAULI':
+        func = _pauli_process_tomo_settings
+    else:
+        raise ValueError(f"Unknown basis {in_basis}")
+    return list(func(qubits))
+
+
+def _batch_arrays(design, expectations, total_counts=None):
+    e = np.ascontiguousarray(expectations, dtype=np.float64)
+    if e.ndim == 1:
+        e = e[None, :]
+    if e.ndim != 2 or e.shape[1] != design.m:
+        raise ValueError(f"expectations must have shape [B, {design.m}]")
+    if total_counts is None:
+        return e, None
+    c = np.ascontiguousarray(total_counts, dtype=np.float64)
+    if c.ndim == 1:
+        c = np.ascontiguousarray(np.broadcast_to(c[None, :], e.shape))
+    if c.shape != e.shape:
+        raise ValueError("total_counts must have the shape of expectations")
+    return e, c
+
+
+# ==================================================================================================
+# STATE tomography
+# ==================================================================================================
+def linear_inv_state_estimate_batch(design: Design, expectations) -> np.ndarray:
+    e, _ = _batch_arrays(design, expectations)
+    d = design.dim
+    out = np.empty((e.shape[0], d, d), dtype=np.complex128)
+    _lib.check(_lib.lib().fbx_linv_state(design.handle, e.shape[0], _lib.dptr(e),
+                                         _lib.dptr(out.view(np.float64))))
+    return out
+
+
+def linear_inv_state_estimate(results: List[ExperimentResult], qubits: List[int]) -> np.ndarray:
+    """tomography.py:130-165."""
+    design, e, _ = flatten_results(results, qubits, "state")
+    return linear_inv_state_estimate_batch(design, e)[0]
+
+
+def iterative_mle_state_estimate_batch(design: Design, expectations, total_counts, epsilon=.1,
+                                       entropy_penalty=0.0, beta=0.0, tol=1e-9, maxiter=10_000,
+                                       return_stats=False):
+    if (entropy_penalty != 0.0) and (beta != 0.0):
+        raise ValueError("One can't sensibly do entropy penalty and hedging. Do one or the other"
+                         " but not both.")
+    e, c = _batch_arrays(design, expectations, total_counts)
+    B, d = e.shape[0], design.dim
+    rho = np.empty((B, d, d), dtype=np.complex128)
+    iters = np.zeros(B, dtype=np.int32)
+    hit = np.zeros(B, dtype=np.int32)
+    _lib.check(_lib.lib().fbx_mle_state(design.handle, B, _lib.dptr(e), _lib.dptr(c),
+                                        float(epsilon), float(entropy_penalty), float(beta),
+                                        float(tol), int(maxiter), _lib.dptr(rho.view(np.float64)),
+                                        _lib.iptr(iters), _lib.iptr(hit)))
+    if hit.any():
+        warnings.warn('Maximum number of iterations reached before convergence.')
+    if return_stats:
+        return rho, {"iterations": iters, "hit_max": hit.astype(bool)}
+    return rho
+
+
+def iterative_mle_state_estimate(results: List[ExperimentResult], qubits: List[int], epsilon=.1,
+                                 entropy_penalty=0.0, beta=0.0, tol=1e-9, maxiter=10_000) \
+        -> np.ndarray:
+    """tomography.py:168-270 (diluted iterative MLE; max-entropy or hedged variants)."""
+    if (entropy_penalty != 0.0) and (beta != 0.0):
+        raise ValueError("One can't sensibly do entropy penalty and hedging. Do one or the other"
+                         " but not both.")
+    design, e, c = flatten_results(results, qubits, "state")
+    return iterative_mle_state_estimate_batch(design, e, c, epsilon, entropy_penalty, beta, tol,
+                                              maxiter)[0]
+
+
+def _R_batch(states, design: Design, expectations) -> np.ndarray:
+    e, _ = _batch_arrays(design, expectations)
+    d = design.dim
+    rho = _lib.c128(states).reshape(-1, d, d)
+    out = np.empty_like(rho)
+    _lib.check(_lib.lib().fbx_r_operator(design.handle, rho.shape[0], _lib.dptr(rho.view(np.float64)),
+                                         _lib.dptr(e), _lib.dptr(out.view(np.float64))))
+    return out
+
+
+def _R(state, results, qubits):
+    """tomography.py:273-338.  NOTE: like the reference's private helper, ``qubits`` here is
+    the *reversed* list the public estimators pass down (tomography.py:233,248)."""
+    design, e, _ = flatten_results(results, list(qubits)[::-1], "state")
+    return _R_batch(np.asarray(state)[None], design, e)[0]
+
+
+def state_log_likelihood_batch(states, design: Design, expectations, total_counts) -> np.ndarray:
+    e, c = _batch_arrays(design, expectations, total_counts)
+    d = design.dim
+    rho = _lib.c128(states).reshape(-1, d, d)
+    out = np.empty(rho.shape[0])
+    _lib.check(_lib.lib().fbx_state_log_likelihood(design.handle, rho.shape[0],
+                                                   _lib.dptr(rho.view(np.float64)), _lib.dptr(e),
+                                                   _lib.dptr(c), _lib.dptr(out)))
+    return out
+
+
+def state_log_likelihood(state: np.ndarray, results, qubits: Sequence[int]) -> float:
+    """tomography.py:341-375 (log10 likelihood)."""
+    design, e, c = flatten_results(list(results), qubits, "state")
+    return float(state_log_likelihood_batch(np.asarray(state)[None], design, e, c)[0])
+
+
+def _resample_expectations_with_beta(results, prior_counts=1):
+    """tomography.py:378-409 -- host RNG (np.random global stream, as in the reference)."""
+    resampled = []
+    for result in results:
+        num_plus = ((result.expectation + 1) / 2) * result.total_counts
+        num_minus = result.total_counts - num_plus
+        resampled_expect = 2 * np.random.beta(num_plus + prior_counts, num_minus + prior_counts) - 1
+        resampled.append(ExperimentResult(setting=result.setting, expectation=resampled_expect,
+                                          std_err=result.std_err,
+                                          total_counts=result.total_counts))
+    return resampled
+
+
+def estimate_variance(results: List[ExperimentResult], qubits: List[int], tomo_estimator: Callable,
+                      functional: Callable, target_state=None, n_resamples: int = 40,
+                      project_to_physical: bool = False) -> Tuple[float, float]:
+    """tomography.py:412-453 (bootstrap error bar of a functional of the state)."""
+    from .operator_tools.project_state_matrix import project_state_matrix_to_physical
+    if functional != dm.purity:
+        if target_state is None:
+            raise ValueError("You're not using the `purity` functional. "
+                             "Please specify a target state.")
+    sample_estimate = []
+    for _ in range(n_resamples):
+        resampled_results = _resample_expectations_with_beta(results)
+        rho = tomo_estimator(resampled_results, qubits)
+        if project_to_physical:
+            rho = project_state_matrix_to_physical(rho)
+        if functional == dm.purity:
+            sample_estimate.append(np.real(dm.purity(rho, dim_renorm=False)))
+        else:
+            sample_estimate.append(np.real(functional(target_state, rho)))
+    return np.mean(sample_estimate), np.var(sample_estimate)
+
+
+# ==================================================================================================
+# PROCESS tomography
+# ==================================================================================================
+def linear_inv_process_estimate_batch(design: Design, expectations) -> np.ndarray:
+    e, _ = _batch_arrays(design, expectations)
+    D = design.dim ** 2
+    out = np.empty((e.shape[0], D, D), dtype=np.complex128)
+    _lib.check(_lib.lib().fbx_linv_process(design.handle, e.shape[0], _lib.dptr(e),
+                                           _lib.dptr(out.view(np.float64))))
+    return out
+
+
+def linear_inv_process_estimate(results: List[ExperimentResult], qubits: List[int]) -> np.ndarray:
+    """tomography.py:459-491."""
+    design, e, _ = flatten_results(results, qubits, "process")
+    return linear_inv_process_estimate_batch(design, e)[0]
+
+
+def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trace_preserving=True,
+                                mode="converge", max_iters=0, return_stats=False):
+    """Batched pgdb_process_estimate.  ``mode='converge'`` is the reference loop (optionally
+    capped by ``max_iters``); ``mode='fixed'`` runs exactly ``max_iters`` outer iterations."""
+    if mode not in ("converge", "fixed"):
+        raise ValueError("mode must be 'converge' or 'fixed'")
+    e, c = _batch_arrays(design, expectations, total_counts)
+    B, D = e.shape[0], design.dim ** 2
+    choi = np.empty((B, D, D), dtype=np.complex128)
+    iters = np.zeros(B, dtype=np.int32)
+    dyk = np.zeros(B, dtype=np.int32)
+    bt = np.zeros(B, dtype=np.int32)
+    cost = np.zeros(B)
+    _lib.check(_lib.lib().fbx_pgdb_process(
+        design.handle, B, _lib.dptr(e), _lib.dptr(c), int(bool(trace_preserving)),
+        _lib.MODE_FIXED if mode == "fixed" else _lib.MODE_CONVERGE, int(max_iters),
+        _lib.dptr(choi.view(np.float64)), _lib.iptr(iters), _lib.iptr(dyk), _lib.iptr(bt),
+        _lib.dptr(cost)))
+    if return_stats:
+        return choi, {"iterations": iters, "dykstra": dyk, "backtracks": bt, "cost": cost}
+    return choi
+
+
+def pgdb_process_estimate(results: List[ExperimentResult], qubits: List[int],
+                          trace_preserving=True) -> np.ndarray:
+    """tomography.py:542-594 (projected gradient descent with backtracking)."""
+    design, e, c = flatten_results(results, qubits, "process")
+    return pgdb_process_estimate_batch(design, e, c, trace_preserving)[0]

@@ -1,0 +1,183 @@
+/*
+ * fbx.h -- C ABI of libfbx.so, the MI355X (gfx950) tomography-reconstruction library.
+ *
+ * This is the drop-in boundary for the hot path of rigetti/forest-benchmarking
+ * (forest/benchmarking/tomography.py:130-633, operator_tools/, distance_measures.py).
+ * The reference has no FFI of its own (it is 100 % Python); each entry point below names
+ * the reference function it replaces (file:line relative to forest/benchmarking/).
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every entry point returns int: FBX_OK or an FBX_ERR_* category; the message is
+ *    available per thread through fbx_last_error().  No exceptions / abort() cross the ABI.
+ *  - all buffers are caller-owned, C-contiguous; complex128 is interleaved (re, im) doubles
+ *    (binary compatible with `double _Complex` and numpy complex128); matrices are
+ *    row-major [B][row][col].  Plain entry points take HOST pointers and do H2D/D2H
+ *    themselves; *_dev entry points take DEVICE pointers (HBM-resident data) and are
+ *    asynchronous on the library stream until fbx_synchronize().
+ *  - column-stacking vec; un-normalised Choi on H_in (x) H_out; n-qubit Pauli order
+ *    itertools.product('IXYZ', repeat=n) with qubits[0] the left-most tensor factor.
+ *  - label codes: one-qubit input states 0:X+ 1:X- 2:Y+ 3:Y- 4:Z+ 5:Z- 6:SIC0 7:SIC1
+ *    8:SIC2 9:SIC3; one-qubit Paulis 0:I 1:X 2:Y 3:Z.
+ */
+#ifndef FBX_H
+#define FBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBX_OK               0
+#define FBX_ERR_BAD_ARG      1   /* -> ValueError in the Python shim */
+#define FBX_ERR_HIP          2   /* HIP runtime / kernel failure */
+#define FBX_ERR_NO_DEVICE    3   /* no gfx950 device visible: the product fails loudly */
+#define FBX_ERR_UNSUPPORTED  4   /* valid request outside what this build implements */
+#define FBX_ERR_NOMEM        5
+
+#define FBX_KIND_STATE    0
+#define FBX_KIND_PROCESS  1
+
+/* pgdb modes */
+#define FBX_MODE_CONVERGE 0   /* reference loop: stop when old_cost - new_cost < 1e-10
+                                 (tomography.py:589); max_iters > 0 adds a cap */
+#define FBX_MODE_FIXED    1   /* exactly max_iters outer iterations (benchmark mode) */
+
+/* superoperator representations for fbx_convert */
+#define FBX_REP_KRAUS   0
+#define FBX_REP_CHOI    1
+#define FBX_REP_SUPEROP 2
+#define FBX_REP_PAULI_LIOUVILLE 3
+#define FBX_REP_CHI     4
+
+/* Choi projections for fbx_proj_choi */
+#define FBX_PROJ_CP        0  /* project_superoperators.py:19  proj_choi_to_completely_positive */
+#define FBX_PROJ_TP        1  /* project_superoperators.py:62  proj_choi_to_trace_preserving    */
+#define FBX_PROJ_TNI       2  /* project_superoperators.py:37  proj_choi_to_trace_non_increasing */
+#define FBX_PROJ_PHYSICAL_TP  3  /* project_superoperators.py:87 proj_choi_to_physical(.., True)  */
+#define FBX_PROJ_PHYSICAL_TNI 4  /* project_superoperators.py:87 proj_choi_to_physical(.., False) */
+
+typedef struct fbx_design fbx_design;   /* opaque: owns the device copy of a design */
+
+/* ---------------------------------------------------------------- library / device */
+int         fbx_version(void);
+const char* fbx_last_error(void);
+int         fbx_device_count(int* count);
+int         fbx_set_device(int device_id);          /* one process per GPU: call once */
+int         fbx_device_name(char* buf, size_t len, int* compute_units);
+int         fbx_synchronize(void);
+
+/* device memory helpers so callers can keep batches resident in HBM */
+int fbx_malloc(void** dev_ptr, size_t bytes);
+int fbx_free(void* dev_ptr);
+int fbx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
+int fbx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+
+/* HIP-event timing of everything enqueued on the library stream between begin and end */
+int fbx_timer_begin(void);
+int fbx_timer_end(double* elapsed_ms);
+
+/* ---------------------------------------------------------------- designs
+ * A design is the data-independent half of an experiment: m settings on n qubits, shared by
+ * every item of a batch.  Replaces the per-call rebuilding of measurement operators in
+ * tomography.py:159-160 (linear inversion), :326-327 (_R), :482-486, :494-539
+ * (_extract_from_results).  in_labels / paulis are [m][n_qubits] codes (in_labels may be
+ * NULL for FBX_KIND_STATE); coefs[m] are the observables' real coefficients (NULL = 1). */
+int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
+                      const uint8_t* paulis, const double* coefs, fbx_design** out);
+int fbx_design_destroy(fbx_design* design);
+int fbx_design_info(const fbx_design* design, int* n_qubits, int* kind, int* m,
+                    int* n_input_states);
+
+/* ---------------------------------------------------------------- process estimators
+ * fbx_pgdb_process replaces pgdb_process_estimate (tomography.py:542-594) together with
+ * _extract_from_results (:494-539), _cost (:597-614), _grad_cost (:617-633) and
+ * proj_choi_to_physical (operator_tools/project_superoperators.py:87-144), for a batch of B
+ * independent experiments that share `design`.
+ *   expect[B][m], counts[B][m]  -- ExperimentResult.expectation / .total_counts
+ *   choi_out[B][D][D] complex128, D = 4^n
+ *   iters_out / dykstra_out / backtracks_out [B] (may be NULL): outer iterations, total
+ *   Dykstra (= eigendecomposition) iterations, total step halvings; cost_out[B] (may be
+ *   NULL): final negative log-likelihood. */
+int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
+                     const double* counts, int trace_preserving, int mode, int max_iters,
+                     double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
+                     int32_t* backtracks_out, double* cost_out);
+int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                         const double* d_counts, int trace_preserving, int mode,
+                         int max_iters, double* d_choi_out, int32_t* d_iters_out,
+                         int32_t* d_dykstra_out, int32_t* d_backtracks_out,
+                         double* d_cost_out);
+
+/* linear_inv_process_estimate (tomography.py:459-491): choi_out[B][D][D]. */
+int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect,
+                     double* choi_out);
+
+/* ---------------------------------------------------------------- state estimators
+ * linear_inv_state_estimate (tomography.py:130-165): rho_out[B][d][d], d = 2^n. */
+int fbx_linv_state(const fbx_design* design, int64_t B, const double* expect, double* rho_out);
+
+/* iterative_mle_state_estimate (tomography.py:168-270) incl. _R (:273-338): diluted
+ * iterative MLE with optional max-entropy (entropy_penalty > 0) or hedging (beta > 0).
+ * Performs at most maxiter-1 updates like the reference; hit_max_out[b] = 1 where the cap was
+ * reached (the shim then emits the reference's warning). */
+int fbx_mle_state(const fbx_design* design, int64_t B, const double* expect,
+                  const double* counts, double epsilon, double entropy_penalty, double beta,
+                  double tol, int maxiter, double* rho_out, int32_t* iters_out,
+                  int32_t* hit_max_out);
+
+/* _R (tomography.py:273-338): r_out[B][d][d] for given states rho[B][d][d]. */
+int fbx_r_operator(const fbx_design* design, int64_t B, const double* rho, const double* expect,
+                   double* r_out);
+
+/* state_log_likelihood (tomography.py:341-375): ll_out[B] (log10). */
+int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* rho,
+                             const double* expect, const double* counts, double* ll_out);
+
+/* ---------------------------------------------------------------- operator tools
+ * fbx_convert: the pairwise conversions of operator_tools/superoperator_transformations.py
+ * :82-371.  `in` is [B][K][d][d] for FBX_REP_KRAUS (K operators per item), else [B][D][D];
+ * `out` is [B][D][D].  Conversions *to* Kraus are not offered (eigenvector-valued outputs
+ * are only defined up to phase, superoperator_transformations.py:325-336). */
+int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K,
+                double* out);
+
+/* Fused conversion sweep of BASELINE config 3: kraus2choi -> choi2pauli_liouville ->
+ * choi2chi -> process_fidelity(ptm_ref, ptm) (superoperator_transformations.py:159,364,339;
+ * distance_measures.py:315).  Any of choi_out / ptm_out / chi_out / fid_out may be NULL. */
+int fbx_kraus_sweep(int n_qubits, int64_t B, int K, const double* kraus, const double* ptm_ref,
+                    double* choi_out, double* ptm_out, double* chi_out, double* fid_out);
+int fbx_kraus_sweep_dev(int n_qubits, int64_t B, int K, const double* d_kraus,
+                        const double* d_ptm_ref, double* d_choi_out, double* d_ptm_out,
+                        double* d_chi_out, double* d_fid_out);
+
+/* Choi projections (operator_tools/project_superoperators.py:19-144): out[B][D][D];
+ * iters_out[B] (may be NULL) = Dykstra iterations for the PHYSICAL kinds. */
+int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, double* out,
+                  int32_t* iters_out);
+
+/* project_state_matrix_to_physical (operator_tools/project_state_matrix.py:6-52). */
+int fbx_proj_state_physical(int n_qubits, int64_t B, const double* rho, double* out);
+
+/* apply_choi_matrix_2_state (operator_tools/apply_superoperator.py:60-90): out[B][d][d]. */
+int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rho, double* out);
+
+/* entanglement_fidelity / process_fidelity (distance_measures.py:271-359) on
+ * Pauli-Liouville matrices [B][D][D] (real parts of tr(A^H B) / d^2): fe_out, fp_out may be
+ * NULL. */
+int fbx_process_fidelity(int n_qubits, int64_t B, const double* ptm0, const double* ptm1,
+                         double* fe_out, double* fp_out);
+
+/* State measures (distance_measures.py:14-114, :198): purity tr(rho^2), fidelity
+ * (tr sqrt(sqrt(rho) sigma sqrt(rho)))^2, trace_distance = 0.5 * induced 1-norm,
+ * hilbert_schmidt_ip Re tr(rho^H sigma); rho, sigma are [B][d][d]; out arrays [B], NULL to skip. */
+int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double* sigma,
+                       double* purity_out, double* fidelity_out, double* trace_dist_out,
+                       double* hs_ip_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBX_H */
