@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: process-tomography MLE reconstructions/sec (2-qubit, 100 iters).
+
+Workload (BASELINE.json configs[1]): a batch of 1024 independent 2-qubit process tomographies
+per GPU (Pauli in-basis, 540 settings, 1000 shots), 100 fixed outer iterations of projected
+gradient descent with backtracking (fbx_pgdb_process_dev, FBX_MODE_FIXED), fp64.  Inputs are
+resident in HBM before the timed region; a "step" is one pass of the kernel over the batch.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; the batch axis is embarrassingly parallel, so ranks shard items with no
+data-path collective (scaling = weak: every rank owns `--batch` items).  torch.distributed is
+used only for the barrier and the max-over-ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "forest-benchmarking_amd"))
+
+# algorithmic work of one 2-qubit, 100-iteration reconstruction in the
+# reference's dense formulation (~7.7 MFLOP per outer iteration) and its HBM bytes
+# (540 expectations + 540 counts in, 16x16 complex128 Choi out).
+ALGO_FLOP_PER_RECON = 0.77e9
+ALGO_BYTES_PER_RECON = 12736
+FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector == fp64 MFMA (v_mfma_f64_16x16x4) dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="reconstructions per GPU per step")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--in-basis", default="pauli")
+    ap.add_argument("--cpu-sample", type=int, default=12,
+                    help="items timed on the host for cpu_baseline (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(design, e, c, n_items, iters):
+    """The oracle (numpy restatement of the reference) on a bounded sample of the same batch,
+    one core, design matrix hoisted out of the loop (the fair variant of BASELINE.md section 3)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from fbx_oracle import design as od, estimators as oe
+    d = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)
+    A = oe.design_matrix_A(d)
+    t0 = time.perf_counter()
+    for b in range(n_items):
+        oe.pgdb_process_estimate(d, e[b], c[b], mode="fixed", max_iters=iters, A=A)
+    dt = time.perf_counter() - t0
+    return {"value": n_items / dt, "unit": "reconstructions/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_items} items of the bench batch, fixed {iters} iterations, "
+                      f"numpy oracle with the design matrix hoisted, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    # torch first: its bundled libamdhip64.so.7 and ours share one SONAME, so loading torch
+    # before libfbx.so keeps a single HIP runtime in the process.
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from fbx import _lib, synthetic
+    _lib.set_device(local_rank)                       # fails loudly without a GPU
+    dev_name, cus = _lib.device_name()
+
+    B = args.batch
+    design, _, e, c = synthetic.process_batch(2, args.in_basis, B, first_item=rank * B)
+    d_e = _lib.DeviceBuffer.from_array(e)
+    d_c = _lib.DeviceBuffer.from_array(c)
+    D = 16
+    d_choi = _lib.DeviceBuffer(B * D * D * 16)
+    d_it = _lib.DeviceBuffer(B * 4)
+    d_dy = _lib.DeviceBuffer(B * 4)
+    d_bt = _lib.DeviceBuffer(B * 4)
+    d_cost = _lib.DeviceBuffer(B * 8)
+    lib = _lib.lib()
+
+    def step():
+        _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, _lib.MODE_FIXED,
+                                            args.iters, d_choi.ptr, d_it.ptr, d_dy.ptr, d_bt.ptr,
+                                            d_cost.ptr))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        _lib.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    import ctypes
+    ms = ctypes.c_double(0.0)
+    t0 = time.perf_counter()
+    _lib.check(lib.fbx_timer_begin())
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.fbx_timer_end(ctypes.byref(ms)))     # HIP events on the launch stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed, ms.value], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_total = t.tolist()
+    else:
+        kernel_ms_total = ms.value
+
+    iters = d_it.to_array(np.int32, (B,))
+    dyk = d_dy.to_array(np.int32, (B,))
+    bt = d_bt.to_array(np.int32, (B,))
+
+    if rank == 0:
+        total_recons = world * B * args.steps
+        value = total_recons / elapsed
+        kernel_s = kernel_ms_total / 1e3 / args.steps           # average launch duration
+        achieved_tflops = B * ALGO_FLOP_PER_RECON * (args.iters / 100.0) / kernel_s / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("pgdb_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "process-tomography MLE reconstructions/sec (2-qubit, 100 iters)",
+            "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{B} independent 2-qubit process tomographies per GPU, "
+                                   f"{args.in_basis} in-basis ({design.m} settings, 1000 shots), "
+                                   f"{args.iters} fixed PGDB iterations, inputs resident in HBM",
+                       "batch_per_gpu": B, "iters": args.iters, "parallelism": f"shard{world}",
+                       "device": dev_name.strip(), "compute_units": cus,
+                       "mean_dykstra_iters": float(dyk.mean()),
+                       "mean_backtracks": float(bt.mean()),
+                       "mean_outer_iters": float(iters.mean())},
+            "roofline": {"bound": "fp64", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS,
+                         "traffic": traffic,
+                         "kernel": "pgdb_kernel<2,9>", "kernel_ms": 1e3 * kernel_s,
+                         "note": "PGDB is fp64-compute bound (SURVEY.md 8d): achieved = "
+                                 "0.77 GFLOP algorithmic (dense-A formulation) x batch / HIP-event "
+                                 "kernel time; peak = MI355X fp64 vector = fp64 MFMA dense peak",
+                         "hbm": {"achieved": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9 / HBM_PEAK_GBS}},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(design, e, c, min(args.cpu_sample, B), args.iters)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

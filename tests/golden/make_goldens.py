@@ -1,0 +1,164 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Build-container only (needs /root/reference; see _ref_harness.py):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+Inputs come from the build's own synthetic-data generator (fbx.synthetic, SURVEY.md 8d
+recipe); every expected output below is produced by the reference's own functions
+(forest.benchmarking.tomography / operator_tools / distance_measures) called on the
+reference's own ExperimentResult objects.  Fixtures are data only (inputs + outputs).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "forest-benchmarking_amd"))
+sys.dont_write_bytecode = True
+
+import _ref_harness  # noqa: E402
+from fbx import synthetic  # noqa: E402
+
+ref = _ref_harness.load_reference()
+T, OT, DM, OE = ref.tomography, ref.operator_tools, ref.distance_measures, ref.observable_estimation
+PSM = ref.project_state_matrix
+
+
+def ref_results(settings, e, c):
+    return [OE.ExperimentResult(setting=s, expectation=float(e[k]), std_err=0.0,
+                                total_counts=int(c[k])) for k, s in enumerate(settings)]
+
+
+def process_settings(qubits, basis):
+    f = T._pauli_process_tomo_settings if basis == "pauli" else T._sic_process_tomo_settings
+    return list(f(qubits))
+
+
+def make_process(n, basis, batch, tni_items):
+    qubits = list(range(n))
+    design, us, e, c = synthetic.process_batch(n, basis, batch)
+    settings = process_settings(qubits, basis)
+    assert len(settings) == design.m
+    pgdb, linv, pgdb_tni = [], [], []
+    for b in range(batch):
+        res = ref_results(settings, e[b], c[b])
+        pgdb.append(T.pgdb_process_estimate(res, qubits))
+        linv.append(T.linear_inv_process_estimate(res, qubits))
+        if b < tni_items:
+            pgdb_tni.append(T.pgdb_process_estimate(res, qubits, trace_preserving=False))
+    np.savez_compressed(os.path.join(HERE, f"process_{n}q_{basis}.npz"),
+                        n_qubits=n, in_labels=design.in_labels, paulis=design.paulis,
+                        unitaries=us, expectations=e, counts=c, pgdb=np.array(pgdb),
+                        linv=np.array(linv), pgdb_tni=np.array(pgdb_tni))
+    print("process", n, basis, "done")
+
+
+def make_state(n, batch):
+    qubits = list(range(n))
+    design, rhos, e, c = synthetic.state_batch(n, batch, mixed=0.1)
+    settings = list(T._state_tomo_settings(qubits))
+    assert len(settings) == design.m
+    out = {k: [] for k in ("linv", "mle100", "mle_tol", "hedged", "maxent", "loglik", "r_op")}
+    for b in range(batch):
+        res = ref_results(settings, e[b], c[b])
+        out["linv"].append(T.linear_inv_state_estimate(res, qubits))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m100 = T.iterative_mle_state_estimate(res, qubits, maxiter=100)
+            out["mle100"].append(m100)
+            out["mle_tol"].append(T.iterative_mle_state_estimate(res, qubits, epsilon=0.5, tol=1e-6,
+                                                                 maxiter=2000))
+            out["hedged"].append(T.iterative_mle_state_estimate(res, qubits, beta=0.5, epsilon=1e-4,
+                                                                maxiter=60))
+            out["maxent"].append(T.iterative_mle_state_estimate(res, qubits, entropy_penalty=0.005,
+                                                                maxiter=60))
+        out["loglik"].append(T.state_log_likelihood(m100, res, qubits))
+        out["r_op"].append(T._R(m100, res, qubits[::-1]))
+    np.savez_compressed(os.path.join(HERE, f"state_{n}q.npz"), n_qubits=n, paulis=design.paulis,
+                        truth=rhos, expectations=e, counts=c,
+                        **{k: np.array(v) for k, v in out.items()})
+    print("state", n, "done")
+
+
+def rand_herm(rs, D, scale=1.0):
+    g = rs.randn(D, D) + 1j * rs.randn(D, D)
+    return scale * (g + g.conj().T) / 2
+
+
+def make_superops(n, batch):
+    d, D = 2 ** n, 4 ** n
+    rs = np.random.RandomState(100 + n)
+    out = {}
+    for K in (1, 2, 4):
+        ks = synthetic.kraus_batch(n, K, batch, seed=10 * n + K)
+        out[f"kraus{K}"] = ks
+        out[f"kraus{K}_choi"] = np.array([OT.kraus2choi(list(k)) for k in ks])
+        out[f"kraus{K}_superop"] = np.array([OT.kraus2superop(list(k)) for k in ks])
+        out[f"kraus{K}_ptm"] = np.array([OT.kraus2pauli_liouville(list(k)) for k in ks])
+        out[f"kraus{K}_chi"] = np.array([OT.kraus2chi(list(k)) for k in ks])
+    choi = out["kraus4_choi"]
+    out["choi2chi"] = np.array([OT.choi2chi(x) for x in choi])
+    out["choi2superop"] = np.array([OT.choi2superop(x) for x in choi])
+    out["choi2ptm"] = np.array([OT.choi2pauli_liouville(x) for x in choi])
+    out["chi2choi"] = np.array([OT.chi2choi(x) for x in out["kraus4_chi"]])
+    out["chi2ptm"] = np.array([OT.chi2pauli_liouville(x) for x in out["kraus4_chi"]])
+    out["chi2superop"] = np.array([OT.chi2superop(x) for x in out["kraus4_chi"]])
+    out["superop2choi"] = np.array([OT.superop2choi(x) for x in out["kraus4_superop"]])
+    out["superop2ptm"] = np.array([OT.superop2pauli_liouville(x) for x in out["kraus4_superop"]])
+    out["superop2chi"] = np.array([OT.superop2chi(x) for x in out["kraus4_superop"]])
+    out["ptm2choi"] = np.array([OT.pauli_liouville2choi(x) for x in out["kraus4_ptm"]])
+    out["ptm2superop"] = np.array([OT.pauli_liouville2superop(x) for x in out["kraus4_ptm"]])
+    out["ptm2chi"] = np.array([OT.pauli_liouville2chi(x) for x in out["kraus4_ptm"]])
+    # non-CP Hermitian input: choi2chi goes through |C|
+    herm = np.array([rand_herm(rs, D) for _ in range(batch)])
+    out["herm"] = herm
+    out["herm_choi2chi"] = np.array([OT.choi2chi(x) for x in herm])
+    # process fidelity against a fixed reference unitary channel
+    u_ref = synthetic.haar_unitary(d, np.random.RandomState(7))
+    ptm_ref = OT.kraus2pauli_liouville(u_ref)
+    out["ptm_ref"] = ptm_ref
+    out["proc_fid"] = np.array([DM.process_fidelity(ptm_ref, x) for x in out["kraus4_ptm"]])
+    out["ent_fid"] = np.array([DM.entanglement_fidelity(ptm_ref, x) for x in out["kraus4_ptm"]])
+    # projections: general complex input and Hermitian perturbations of CPTP maps
+    gen = np.array([rs.randn(D, D) + 1j * rs.randn(D, D) for _ in range(batch)]) * 0.3
+    near = choi + np.array([rand_herm(rs, D, 0.2) for _ in range(batch)])
+    for name, x in (("gen", gen), ("near", near)):
+        out[f"proj_{name}_in"] = x
+        out[f"proj_{name}_cp"] = np.array([OT.proj_choi_to_completely_positive(v) for v in x])
+        out[f"proj_{name}_tp"] = np.array([OT.proj_choi_to_trace_preserving(v) for v in x])
+        out[f"proj_{name}_tni"] = np.array([OT.proj_choi_to_trace_non_increasing(v) for v in x])
+    out["proj_near_phys_tp"] = np.array([OT.proj_choi_to_physical(v) for v in near])
+    out["proj_near_phys_tni"] = np.array([OT.proj_choi_to_physical(v, False) for v in near])
+    # states: unphysical Hermitian trace-ish-one matrices and physical pairs
+    unphys = np.array([np.eye(d) / d + rand_herm(rs, d, 0.25) for _ in range(batch)])
+    out["state_unphys"] = unphys
+    out["state_proj"] = np.array([PSM.project_state_matrix_to_physical(v) for v in unphys])
+    g1 = rs.randn(batch, d, d) + 1j * rs.randn(batch, d, d)
+    g2 = rs.randn(batch, d, d) + 1j * rs.randn(batch, d, d)
+    rho = np.array([g @ g.conj().T / np.trace(g @ g.conj().T) for g in g1])
+    sig = np.array([g @ g.conj().T / np.trace(g @ g.conj().T) for g in g2])
+    out["rho"], out["sigma"] = rho, sig
+    out["purity"] = np.array([DM.purity(r) for r in rho])
+    out["fidelity"] = np.array([DM.fidelity(r, s) for r, s in zip(rho, sig)])
+    out["trace_distance"] = np.array([DM.trace_distance(r, s) for r, s in zip(rho, sig)])
+    out["hs_ip"] = np.array([DM.hilbert_schmidt_ip(r, s) for r, s in zip(rho, sig)])
+    out["apply_choi"] = np.array([OT.apply_choi_matrix_2_state(cx, r) for cx, r in zip(choi, rho)])
+    np.savez_compressed(os.path.join(HERE, f"superops_{n}q.npz"), n_qubits=n, **out)
+    print("superops", n, "done")
+
+
+if __name__ == "__main__":
+    np.random.seed(0)
+    make_process(1, "pauli", 6, 3)
+    make_process(1, "sic", 6, 3)
+    make_process(2, "sic", 4, 2)
+    make_process(2, "pauli", 4, 1)
+    make_state(1, 6)
+    make_state(2, 4)
+    make_superops(1, 6)
+    make_superops(2, 6)
