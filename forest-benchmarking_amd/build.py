@@ -24,31 +24,41 @@ def stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, profile=False):
+    """profile=True builds libfbx_prof.so with per-phase cycle timers (diagnostics only)."""
+    global OUT
+    out = OUT
+    flags = list(FLAGS)
+    tag = ""
+    if profile:
+        out = os.path.join(HERE, "libfbx_prof.so")
+        flags.append("-DFBX_PHASE_TIMERS")
+        tag = ".prof"
+        force = True
     if not force and not stale():
-        return OUT
+        return out
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(HERE, "build", os.path.basename(src) + tag + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 [os.path.getmtime(src)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.hpp"))]
                 + [os.path.getmtime(os.path.join(HERE, "..", "include", "fbx.h"))]):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, profile="--profile" in sys.argv)

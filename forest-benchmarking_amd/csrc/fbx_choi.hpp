@@ -17,21 +17,26 @@ namespace fbx {
 template <int NQ>
 struct ChoiLds {
     static constexpr int d = 1 << NQ, D = d * d, LD = D + 1, LDs = d + 1;
-    cplx* Mw;      // [D * LD]   staging / Jacobi work matrix
-    cplx* Vw;      // [D * LD]   eigenvectors
-    double* rot;   // [4 * D/2]
+    cplx* Mw;      // [D * LD]   row-major staging matrix (partial trace, Pauli transforms)
+    cplx* Ms;      // [D * D]    Jacobi work matrix, element-major block layout
+    cplx* Vs;      // [D * D]    eigenvectors, same layout
     double* lam;   // [D]
-    cplx* pt;      // [d * LDs]  partial trace (d x d)
-    cplx* ptV;     // [d * LDs]  eigenvectors of the partial trace (TNI only)
+    JRec* rec;     // [D / 2]    published rotations of the pipelined Jacobi
+    cplx* pt;      // [d * LDs]  partial trace (d x d), row-major
+    cplx* pts;     // [d * d]    partial trace in the Jacobi layout (TNI only)
+    cplx* ptV;     // [d * d]    its eigenvectors (TNI only)
+    PhaseClock* pc = nullptr;   // diagnostics (FBX_PHASE_TIMERS builds)
     static constexpr size_t bytes() {
-        return sizeof(cplx) * (2 * D * LD + 2 * d * LDs) + sizeof(double) * (4 * (D / 2) + D);
+        return sizeof(cplx) * (D * LD + 2 * D * D + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
     }
     __device__ void carve(char*& p) {
         Mw = (cplx*)p; p += sizeof(cplx) * D * LD;
-        Vw = (cplx*)p; p += sizeof(cplx) * D * LD;
+        Ms = (cplx*)p; p += sizeof(cplx) * D * D;
+        Vs = (cplx*)p; p += sizeof(cplx) * D * D;
         pt = (cplx*)p; p += sizeof(cplx) * d * LDs;
-        ptV = (cplx*)p; p += sizeof(cplx) * d * LDs;
-        rot = (double*)p; p += sizeof(double) * 4 * (D / 2);
+        pts = (cplx*)p; p += sizeof(cplx) * d * d;
+        ptV = (cplx*)p; p += sizeof(cplx) * d * d;
+        rec = (JRec*)p; p += sizeof(JRec) * (D / 2 + 1);
         lam = (double*)p; p += sizeof(double) * D;
     }
 };
@@ -41,24 +46,28 @@ struct ChoiLds {
 // sweeps (diagnostics).
 template <int NQ>
 __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps) {
-    constexpr int D = ChoiLds<NQ>::D, LD = ChoiLds<NQ>::LD;
-    __syncthreads();                       // previous readers of Mw / Vw are done
-    blk_store<D, LD>(L.Mw, lane, x);
+    constexpr int D = ChoiLds<NQ>::D;
+    __syncthreads();                       // previous readers of Ms / Vs are done
+    sys_store<D>(L.Ms, lane, x);
     __syncthreads();
-    const Blk xa = blk_load_adjoint<D, LD>(L.Mw, lane);
+    const Blk xa = sys_load_adjoint<D>(L.Ms, lane);
     Blk h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (x.re[e] + xa.re[e]); h.im[e] = 0.5 * (x.im[e] + xa.im[e]); }
     __syncthreads();
-    blk_store<D, LD>(L.Mw, lane, h);
+    sys_store<D>(L.Ms, lane, h);
     __syncthreads();
-    sweeps += jacobi_eigh_lds<D, LD>(L.Mw, L.Vw, L.rot, lane);
+    PH_STOP(*L.pc, 2);
+    sweeps += jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane);
+    PH_STOP(*L.pc, 0);
     if (lane < D) {
-        const double l = L.Mw[lane * LD + lane].re;
+        const double l = L.Ms[sys_index<D>(lane, lane)].re;
         L.lam[lane] = l < 0.0 ? 0.0 : l;
     }
     __syncthreads();
-    return reconstruct_blk<D, LD>(L.Vw, L.lam, lane);
+    const Blk out = reconstruct_blk<D>(L.Vs, L.lam, lane);
+    PH_STOP(*L.pc, 1);
+    return out;
 }
 
 // ---- partial trace over the output space into L.pt (d x d): calculational.py:5-35 with
@@ -117,22 +126,22 @@ template <int NQ>
 __device__ Blk proj_tni_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps) {
     constexpr int d = ChoiLds<NQ>::d, LDs = ChoiLds<NQ>::LDs;
     partial_trace_out<NQ>(x, L, lane);
-    // keep pt in registers, Hermitise a copy in place for the eigensolver
+    // keep pt in registers, Hermitise a copy for the eigensolver
     const Blk ptb = blk_load<d, LDs>(L.pt, lane);
     const Blk pta = blk_load_adjoint<d, LDs>(L.pt, lane);
     Blk h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (ptb.re[e] + pta.re[e]); h.im[e] = 0.5 * (ptb.im[e] + pta.im[e]); }
     __syncthreads();
-    blk_store<d, LDs>(L.pt, lane, h);
+    sys_store<d>(L.pts, lane, h);
     __syncthreads();
-    sweeps += jacobi_eigh_lds<d, LDs>(L.pt, L.ptV, L.rot, lane);
+    sweeps += jacobi_eigh_lds<d>(L.pts, L.ptV, L.rec, lane);
     if (lane < d) {
-        const double l = L.pt[lane * LDs + lane].re;
+        const double l = L.pts[sys_index<d>(lane, lane)].re;
         L.lam[lane] = l > 1.0 ? 1.0 : l;
     }
     __syncthreads();
-    const Blk proj = reconstruct_blk<d, LDs>(L.ptV, L.lam, lane);
+    const Blk proj = reconstruct_blk<d>(L.ptV, L.lam, lane);
     __syncthreads();
     blk_store<d, LDs>(L.pt, lane, blk_sub(ptb, proj));      // pt - projection
     __syncthreads();

@@ -67,7 +67,24 @@ namespace fbx {
 // ------------------------------------------------------------------ device helpers
 #if defined(__HIPCC__)
 
-struct cplx { double re, im; };
+// Optional per-phase cycle accounting (build with -DFBX_PHASE_TIMERS; diagnostics only).
+#ifdef FBX_PHASE_TIMERS
+#define FBX_NPHASE 8
+struct PhaseClock {
+    long long acc[FBX_NPHASE]; long long t0;
+    __device__ void reset() { for (int i = 0; i < FBX_NPHASE; ++i) acc[i] = 0; }
+    __device__ __forceinline__ void start() { t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void stop(int ph) { long long t = __builtin_readcyclecounter(); acc[ph] += t - t0; t0 = t; }
+};
+#define PH_START(pc) (pc).start()
+#define PH_STOP(pc, ph) (pc).stop(ph)
+#else
+struct PhaseClock { __device__ void reset() {} };
+#define PH_START(pc)
+#define PH_STOP(pc, ph)
+#endif
+
+struct __attribute__((aligned(16))) cplx { double re, im; };
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -86,6 +103,16 @@ __device__ __forceinline__ double uniform(double v) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// 1/sqrt(x) for normal positive x to ~1 ulp: hardware estimate (v_rsq_f64, ~2^-26) refined by
+// one cubically convergent step  y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2.
+// Avoids the IEEE sqrt / divide expansions in the Jacobi rotation's dependent chain.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    return fma(y * e, p, y);
+}
 
 // Pauli index (base-4 digits, qubit 0 most significant) -> x / z bit masks over the
 // computational index (qubit 0 = most significant bit) and number of Y factors.

@@ -93,119 +93,211 @@ __device__ __forceinline__ Blk blk_load_adjoint(const cplx* M, int lane) {
     return v;
 }
 
-// round-robin (circle method) pairing of N players: round r in [0, N-1), pair k in [0, N/2)
+// ---------------------------------------------------------------------------------------
+// Systolic (Brent-Luk) Jacobi.  The matrix lives in "slot space": slot 2k / 2k+1 are the two
+// members of pair k, so the pivots of a round are always the diagonal 2x2 blocks and lane
+// (I, J) always rotates its own block with the rotations of pairs I (rows) and J (columns).
+// After each round the slots are permuted by a fixed tournament permutation pi (player 0 stays,
+// the others advance one seat), which is applied on the way through LDS: every lane writes its
+// four updated entries to the seats pi assigns them and reads its new block back.  All LDS
+// addresses are per-lane constants (no index arithmetic in the loop) and the element-major
+// layout  Ms[e * LS + lane]  (e = 2a + b the position inside the 2x2 block) makes the b128
+// accesses conflict-free.  After N-1 rounds (one sweep) pi^(N-1) = identity, so slot == index
+// again whenever the convergence test runs.
 template <int N>
-__device__ __forceinline__ void rr_pair(int r, int k, int& p, int& q) {
-    constexpr int M = N - 1;
-    if (k == 0) { p = N - 1; q = r; }
-    else {
-        p = r + k; if (p >= M) p -= M;
-        q = r - k; if (q < 0) q += M;
+__device__ __forceinline__ int jacobi_seat(int s) {       // pi: slot -> next slot
+    constexpr int NB = N / 2;
+    if (NB == 1) return s;
+    const int k = s >> 1;
+    if ((s & 1) == 0) {                                    // top row: t_k
+        if (k == 0) return 0;
+        if (k == NB - 1) return 2 * (NB - 1) + 1;          // t_last -> b_last
+        return 2 * (k + 1);                                // t_k -> t_{k+1}
     }
+    if (k == 0) return 2;                                  // b_0 -> t_1
+    return 2 * (k - 1) + 1;                                // b_k -> b_{k-1}
+}
+
+// element (r, c) of an N x N matrix in the element-major block layout
+template <int N>
+__device__ __forceinline__ int sys_index(int r, int c) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    return ((r & 1) * 2 + (c & 1)) * LS + (r >> 1) * NB + (c >> 1);
+}
+
+template <int N>
+__device__ __forceinline__ void sys_store(cplx* Ms, int lane, const Blk& v) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    if (lane < LS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cplx c; c.re = v.re[e]; c.im = v.im[e]; Ms[e * LS + lane] = c; }
+    }
+}
+template <int N>
+__device__ __forceinline__ Blk sys_load(const cplx* Ms, int lane) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    Blk v = blk_zero();
+    if (lane < LS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const cplx c = Ms[e * LS + lane]; v.re[e] = c.re; v.im[e] = c.im; }
+    }
+    return v;
+}
+// conjugate-transpose block: element (a, b) of block (I, J) <- conj of element (b, a) of block (J, I)
+template <int N>
+__device__ __forceinline__ Blk sys_load_adjoint(const cplx* Ms, int lane) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    Blk v = blk_zero();
+    if (lane < LS) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const cplx c = Ms[((e & 1) * 2 + (e >> 1)) * LS + J * NB + I];
+            v.re[e] = c.re; v.im[e] = -c.im;
+        }
+    }
+    return v;
 }
 
 constexpr int FBX_JACOBI_MAX_SWEEPS = 40;
 constexpr double FBX_JACOBI_TOL2 = 1e-26;   // stop when off(A)^2 <= TOL2 * ||A||_F^2
 
-// In-LDS Hermitian eigendecomposition.  On entry M holds the (Hermitian) matrix; on exit the
-// diagonal of M holds the eigenvalues and the columns of V the eigenvectors.  `rot` is
-// 4*(N/2) doubles of LDS scratch.  All 64 lanes of the wave must call; (N/2)^2 do the work.
-// Returns the number of sweeps performed.
-template <int N, int LD>
-__device__ int jacobi_eigh_lds(cplx* M, cplx* V, double* rot, int lane) {
-    constexpr int NB = N / 2, NACT = NB * NB;
-    static_assert(NACT <= 64, "one wavefront per matrix");
-    const bool act = lane < NACT;
+// Rotation helpers ----------------------------------------------------------------------------
+// Rotation R = [[c, s], [-conj(s), c]] that diagonalises the Hermitian pivot [[a, b], [conj(b), d]]
+// (R^H . R): with delta = (d - a)/2, h = sqrt(delta^2 + |b|^2), q = |delta|/h:
+//   c = sqrt((1 + q)/2),  s = sign(delta) * b / (2 h c) = f b.
+// Two reciprocal square roots, no divisions, no branches (selects only); c^2 + |s|^2 = 1 to
+// rounding.  Also returns the rotated diagonal  a' = a + u, d' = d - u,
+// u = |s|^2 (d - a) - 2 c f |b|^2.
+struct JRot { double c, sr, si, an, dn; };
+__device__ __forceinline__ JRot jacobi_rotation(double a, double d, double br, double bi) {
+    const double beta = fma(br, br, bi * bi);
+    const double delta = 0.5 * (d - a);
+    const double h2 = fma(delta, delta, beta);
+    const bool live = beta > 1e-290;                   // else: identity rotation
+    const double ih = fast_rsqrt(live ? h2 : 1.0);
+    const double x = fma(0.5 * fabs(delta), ih, 0.5);  // (1 + q) / 2 in [0.5, 1]
+    const double ic = fast_rsqrt(x);
+    const double f = (delta >= 0.0 ? 0.5 : -0.5) * ih * ic;
+    const double c = x * ic;
+    const double fb = f * beta;
+    const double u = fma(f * fb, 2.0 * delta, -2.0 * c * fb);
+    JRot r;
+    r.c = live ? c : 1.0;
+    r.sr = live ? f * br : 0.0;
+    r.si = live ? f * bi : 0.0;
+    r.an = live ? a + u : a;
+    r.dn = live ? d - u : d;
+    return r;
+}
+
+// 2x2 block update  m <- R_I^H m R_J  and eigenvector columns  v <- v R_J
+__device__ __forceinline__ void jacobi_apply_m(double cI, double sIr, double sIi, double cJ, double sJr,
+                                               double sJi, cplx& m00, cplx& m01, cplx& m10, cplx& m11) {
+    // columns: u' = c u - conj(s) v ; v' = s u + c v
+    cplx t00, t01, t10, t11;
+    t00.re = cJ * m00.re - (sJr * m01.re + sJi * m01.im);
+    t00.im = cJ * m00.im - (sJr * m01.im - sJi * m01.re);
+    t01.re = cJ * m01.re + (sJr * m00.re - sJi * m00.im);
+    t01.im = cJ * m01.im + (sJr * m00.im + sJi * m00.re);
+    t10.re = cJ * m10.re - (sJr * m11.re + sJi * m11.im);
+    t10.im = cJ * m10.im - (sJr * m11.im - sJi * m11.re);
+    t11.re = cJ * m11.re + (sJr * m10.re - sJi * m10.im);
+    t11.im = cJ * m11.im + (sJr * m10.im + sJi * m10.re);
+    // rows: u' = c u - s v ; v' = conj(s) u + c v
+    m00.re = cI * t00.re - (sIr * t10.re - sIi * t10.im);
+    m00.im = cI * t00.im - (sIr * t10.im + sIi * t10.re);
+    m10.re = cI * t10.re + (sIr * t00.re + sIi * t00.im);
+    m10.im = cI * t10.im + (sIr * t00.im - sIi * t00.re);
+    m01.re = cI * t01.re - (sIr * t11.re - sIi * t11.im);
+    m01.im = cI * t01.im - (sIr * t11.im + sIi * t11.re);
+    m11.re = cI * t11.re + (sIr * t01.re + sIi * t01.im);
+    m11.im = cI * t11.im + (sIr * t01.im - sIi * t01.re);
+}
+// eigenvector accumulation: rows 2I, 2I+1 of V, column pair J:  v <- v R_J
+__device__ __forceinline__ void jacobi_apply_v(double cJ, double sJr, double sJi, cplx& v0p, cplx& v0q,
+                                               cplx& v1p, cplx& v1q) {
+    cplx u0, w0, u1, w1;
+    u0.re = cJ * v0p.re - (sJr * v0q.re + sJi * v0q.im);
+    u0.im = cJ * v0p.im - (sJr * v0q.im - sJi * v0q.re);
+    w0.re = cJ * v0q.re + (sJr * v0p.re - sJi * v0p.im);
+    w0.im = cJ * v0q.im + (sJr * v0p.im + sJi * v0p.re);
+    u1.re = cJ * v1p.re - (sJr * v1q.re + sJi * v1q.im);
+    u1.im = cJ * v1p.im - (sJr * v1q.im - sJi * v1q.re);
+    w1.re = cJ * v1q.re + (sJr * v1p.re - sJi * v1p.im);
+    w1.im = cJ * v1q.im + (sJr * v1p.im + sJi * v1p.re);
+    v0p = u0; v0q = w0; v1p = u1; v1q = w1;
+}
+
+// LDS scratch of the pipelined solver: one 48-byte record per pair
+struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
+
+// In-LDS Hermitian eigendecomposition A = V diag(w) V^H.  On entry Ms holds the Hermitian matrix
+// in the element-major layout (sys_store); on exit Ms is diagonal (eigenvalue k at
+// sys_index(k, k)) and Vs holds the eigenvectors as columns in the same layout.  All 64 lanes of
+// the wave must call; (N/2)^2 of them work.  Returns the number of sweeps.
+//
+// Simple form (any even N <= 16): every lane derives its two rotations from the pivots in LDS.
+template <int N>
+__device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    static_assert(LS <= 64, "one wavefront per matrix");
+    const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
+    const int me = act ? lane : 0;
+    int wm[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
+        wm[e] = ((sa & 1) * 2 + (sb & 1)) * LS + (sa >> 1) * NB + (sb >> 1);
+        wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
+    }
+    const int dI = I * NB + I, dJ = J * NB + J;            // lanes owning the pivot blocks
     if (act) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
-            cplx v; v.re = (r == c) ? 1.0 : 0.0; v.im = 0.0;
-            V[r * LD + c] = v;
+            cplx v; v.re = (2 * I + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; v.im = 0.0;
+            Vs[e * LS + me] = v;
         }
     }
     __syncthreads();
     int sweep = 0;
     for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
-        double o2 = 0.0, n2 = 0.0;
-        if (act) {
+        {
+            double o2 = 0.0, n2 = 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
-                const cplx v = M[r * LD + c];
+                const cplx v = Ms[e * LS + me];
                 const double a2 = v.re * v.re + v.im * v.im;
                 n2 += a2;
-                if (r != c) o2 += a2;
+                if (!(I == J && (e == 0 || e == 3))) o2 += a2;
             }
+            if (!act) { o2 = 0.0; n2 = 0.0; }
+            o2 = uniform(wave_sum(o2));
+            n2 = uniform(wave_sum(n2));
+            if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
         }
-        o2 = uniform(wave_sum(o2));
-        n2 = uniform(wave_sum(n2));
-        if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
         for (int r = 0; r < N - 1; ++r) {
-            if (act && I == J) {
-                int p, q;
-                rr_pair<N>(r, I, p, q);
-                const double a = M[p * LD + p].re, dq = M[q * LD + q].re;
-                const cplx b = M[p * LD + q];
-                const double beta = b.re * b.re + b.im * b.im;
-                double c = 1.0, sr = 0.0, si = 0.0;
-                if (beta > 1e-300) {
-                    const double delta = 0.5 * (dq - a);
-                    const double w = fabs(delta) + sqrt(delta * delta + beta);
-                    const double iw = 1.0 / w;
-                    c = 1.0 / sqrt(1.0 + beta * iw * iw);
-                    const double f = (delta >= 0.0 ? iw : -iw) * c;
-                    sr = f * b.re; si = f * b.im;
-                }
-                rot[4 * I + 0] = c; rot[4 * I + 1] = sr; rot[4 * I + 2] = si;
+            const double aI = Ms[0 * LS + dI].re, dI_ = Ms[3 * LS + dI].re;
+            const cplx bI = Ms[1 * LS + dI];
+            const double aJ = Ms[0 * LS + dJ].re, dJ_ = Ms[3 * LS + dJ].re;
+            const cplx bJ = Ms[1 * LS + dJ];
+            cplx m00 = Ms[0 * LS + me], m01 = Ms[1 * LS + me];
+            cplx m10 = Ms[2 * LS + me], m11 = Ms[3 * LS + me];
+            cplx v0p = Vs[0 * LS + me], v0q = Vs[1 * LS + me];
+            cplx v1p = Vs[2 * LS + me], v1q = Vs[3 * LS + me];
+            __syncthreads();            // everything read before anyone overwrites it
+            const JRot rI = jacobi_rotation(aI, dI_, bI.re, bI.im);
+            const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
+            jacobi_apply_m(rI.c, rI.sr, rI.si, rJ.c, rJ.sr, rJ.si, m00, m01, m10, m11);
+            jacobi_apply_v(rJ.c, rJ.sr, rJ.si, v0p, v0q, v1p, v1q);
+            if (I == J) {   // the annihilated pair: exact zeros, real diagonal
+                m01.re = m01.im = 0.0; m10.re = m10.im = 0.0;
+                m00.re = rI.an; m11.re = rI.dn; m00.im = 0.0; m11.im = 0.0;
             }
-            __syncthreads();
             if (act) {
-                int pI, qI, pJ, qJ;
-                rr_pair<N>(r, I, pI, qI);
-                rr_pair<N>(r, J, pJ, qJ);
-                const double cI = rot[4 * I], sIr = rot[4 * I + 1], sIi = rot[4 * I + 2];
-                const double cJ = rot[4 * J], sJr = rot[4 * J + 1], sJi = rot[4 * J + 2];
-                cplx m00 = M[pI * LD + pJ], m01 = M[pI * LD + qJ];
-                cplx m10 = M[qI * LD + pJ], m11 = M[qI * LD + qJ];
-                // columns: u' = c u - conj(s) v ; v' = s u + c v
-                cplx t00, t01, t10, t11;
-                t00.re = cJ * m00.re - (sJr * m01.re + sJi * m01.im);
-                t00.im = cJ * m00.im - (sJr * m01.im - sJi * m01.re);
-                t01.re = cJ * m01.re + (sJr * m00.re - sJi * m00.im);
-                t01.im = cJ * m01.im + (sJr * m00.im + sJi * m00.re);
-                t10.re = cJ * m10.re - (sJr * m11.re + sJi * m11.im);
-                t10.im = cJ * m10.im - (sJr * m11.im - sJi * m11.re);
-                t11.re = cJ * m11.re + (sJr * m10.re - sJi * m10.im);
-                t11.im = cJ * m11.im + (sJr * m10.im + sJi * m10.re);
-                // rows: u' = c u - s v ; v' = conj(s) u + c v
-                m00.re = cI * t00.re - (sIr * t10.re - sIi * t10.im);
-                m00.im = cI * t00.im - (sIr * t10.im + sIi * t10.re);
-                m10.re = cI * t10.re + (sIr * t00.re + sIi * t00.im);
-                m10.im = cI * t10.im + (sIr * t00.im - sIi * t00.re);
-                m01.re = cI * t01.re - (sIr * t11.re - sIi * t11.im);
-                m01.im = cI * t01.im - (sIr * t11.im + sIi * t11.re);
-                m11.re = cI * t11.re + (sIr * t01.re + sIi * t01.im);
-                m11.im = cI * t11.im + (sIr * t01.im - sIi * t01.re);
-                if (I == J) {   // the annihilated pair: exact zeros, real diagonal
-                    m01.re = m01.im = 0.0; m10.re = m10.im = 0.0;
-                    m00.im = 0.0; m11.im = 0.0;
-                }
-                M[pI * LD + pJ] = m00; M[pI * LD + qJ] = m01;
-                M[qI * LD + pJ] = m10; M[qI * LD + qJ] = m11;
-                // eigenvector accumulation: rows 2I, 2I+1 of V, columns pJ, qJ
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const int row = 2 * I + a;
-                    const cplx u = V[row * LD + pJ], v = V[row * LD + qJ];
-                    cplx un, vn;
-                    un.re = cJ * u.re - (sJr * v.re + sJi * v.im);
-                    un.im = cJ * u.im - (sJr * v.im - sJi * v.re);
-                    vn.re = cJ * v.re + (sJr * u.re - sJi * u.im);
-                    vn.im = cJ * v.im + (sJr * u.im + sJi * u.re);
-                    V[row * LD + pJ] = un; V[row * LD + qJ] = vn;
-                }
+                Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;
+                Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
             }
             __syncthreads();
         }
@@ -213,19 +305,118 @@ __device__ int jacobi_eigh_lds(cplx* M, cplx* V, double* rot, int lane) {
     return sweep;
 }
 
-// block (I, J) of sum_k lam[k] v_k v_k^H for the eigenvectors in V; terms with lam[k] == 0
-// are skipped (wave-uniform branch).
-template <int N, int LD>
-__device__ __forceinline__ Blk reconstruct_blk(const cplx* V, const double* lam, int lane) {
-    constexpr int NB = N / 2;
+// Pipelined form (N >= 6): the rotation of next round's pair k depends only on the rotated
+// diagonals of two current pivots and on ONE entry of ONE lane's updated block, so that lane
+// computes it right after its own update and publishes a 48-byte record {c, s, a', d'}.  Lanes
+// then read two records per round instead of six pivot entries and evaluate one rotation chain
+// instead of two, and that chain overlaps the rest of the block update.
+template <int N>
+__device__ int jacobi_eigh_pipelined(cplx* Ms, cplx* Vs, JRec* rec, int lane) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    static_assert(LS <= 64 && N >= 6, "one wavefront per matrix; distinct source pairs");
+    const bool act = lane < LS;
+    const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
+    const int me = act ? lane : 0;
+    int wm[4], wv[4];
+    int nk = -1, ne = 0;            // next-round pair this lane feeds, and with which block entry
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
+        wm[e] = ((sa & 1) * 2 + (sb & 1)) * LS + (sa >> 1) * NB + (sb >> 1);
+        wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
+        if (act && I != J && (sa & 1) == 0 && sb == sa + 1) { nk = sa >> 1; ne = e; }
+    }
+    const int recSlot = nk >= 0 ? nk : NB;     // rec has NB + 1 slots; the last one is a sink
+    const bool rowSecond = (ne >> 1) != 0, colSecond = (ne & 1) != 0;
+    cplx m00, m01, m10, m11;
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cplx v; v.re = (2 * I + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; v.im = 0.0;
+            Vs[e * LS + me] = v;
+        }
+    }
+    // prologue: the diagonal lanes publish the rotations of round 0
+    m00 = Ms[0 * LS + me]; m01 = Ms[1 * LS + me]; m11 = Ms[3 * LS + me];
+    {
+        const JRot r0 = jacobi_rotation(m00.re, m11.re, m01.re, m01.im);
+        if (act && I == J) {
+            JRec q; q.c = r0.c; q.sr = r0.sr; q.si = r0.si; q.an = r0.an; q.dn = r0.dn; q.pad = 0.0;
+            rec[I] = q;
+        }
+    }
+    __syncthreads();
+    int sweep = 0;
+    for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
+        for (int r = 0; r < N - 1; ++r) {
+            const JRec qI = rec[I], qJ = rec[J];
+            m00 = Ms[0 * LS + me]; m01 = Ms[1 * LS + me];
+            m10 = Ms[2 * LS + me]; m11 = Ms[3 * LS + me];
+            cplx v0p = Vs[0 * LS + me], v0q = Vs[1 * LS + me];
+            cplx v1p = Vs[2 * LS + me], v1q = Vs[3 * LS + me];
+            if (r == 0) {               // slot == index here: convergence test on the fresh matrix
+                double o2 = 0.0, n2 = 0.0;
+                const double a00 = fma(m00.re, m00.re, m00.im * m00.im), a01 = fma(m01.re, m01.re, m01.im * m01.im);
+                const double a10 = fma(m10.re, m10.re, m10.im * m10.im), a11 = fma(m11.re, m11.re, m11.im * m11.im);
+                n2 = (a00 + a11) + (a01 + a10);
+                o2 = (I == J) ? (a01 + a10) : n2;
+                if (!act) { o2 = 0.0; n2 = 0.0; }
+                o2 = uniform(wave_sum(o2));
+                n2 = uniform(wave_sum(n2));
+                if (!(o2 > FBX_JACOBI_TOL2 * n2)) return sweep;
+            }
+            __syncthreads();            // everything read before anyone overwrites it
+            jacobi_apply_m(qI.c, qI.sr, qI.si, qJ.c, qJ.sr, qJ.si, m00, m01, m10, m11);
+            // next round's rotation for pair nk from this lane's entry `ne` and the rotated
+            // diagonals of its row / column pivots; evaluated by every lane (non-feeders park the
+            // record in the spare slot) so that the chain sits in the main block and overlaps the
+            // eigenvector update below
+            {
+                const cplx bsel = (ne == 0) ? m00 : (ne == 1) ? m01 : (ne == 2) ? m10 : m11;
+                const double an = rowSecond ? qI.dn : qI.an;
+                const double dn = colSecond ? qJ.dn : qJ.an;
+                const JRot rn = jacobi_rotation(an, dn, bsel.re, bsel.im);
+                JRec q; q.c = rn.c; q.sr = rn.sr; q.si = rn.si; q.an = rn.an; q.dn = rn.dn; q.pad = 0.0;
+                rec[recSlot] = q;
+            }
+            jacobi_apply_v(qJ.c, qJ.sr, qJ.si, v0p, v0q, v1p, v1q);
+            if (I == J) {               // the annihilated pair: exact zeros, published diagonal
+                m01.re = m01.im = 0.0; m10.re = m10.im = 0.0;
+                m00.re = qI.an; m11.re = qI.dn; m00.im = 0.0; m11.im = 0.0;
+            }
+            if (act) {
+                Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;
+                Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
+            }
+            __syncthreads();
+        }
+    }
+    return sweep;
+}
+
+template <int N>
+__device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, int lane) {
+#ifdef FBX_JACOBI_PIPELINED     // measured equal-or-slower than the simple form at 1 wave/SIMD
+    if constexpr (N >= 6) return jacobi_eigh_pipelined<N>(Ms, Vs, rec, lane);
+#endif
+    (void)rec;
+    return jacobi_eigh_simple<N>(Ms, Vs, lane);
+}
+
+// block (I, J) of sum_k lam[k] v_k v_k^H for the eigenvectors in Vs (element-major layout);
+// terms with lam[k] == 0 are skipped (wave-uniform branch).
+template <int N>
+__device__ __forceinline__ Blk reconstruct_blk(const cplx* Vs, const double* lam, int lane) {
+    constexpr int NB = N / 2, LS = NB * NB;
     Blk out = blk_zero();
-    const bool act = lane < NB * NB;
+    const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
     for (int k = 0; k < N; ++k) {
-        const double l = lam[k];
+        const double l = uniform(lam[k]);
         if (l == 0.0) continue;
-        const cplx r0 = V[(2 * I) * LD + k], r1 = V[(2 * I + 1) * LD + k];
-        const cplx c0 = V[(2 * J) * LD + k], c1 = V[(2 * J + 1) * LD + k];
+        const int kb = k >> 1, ke = k & 1;
+        const cplx r0 = Vs[(0 + ke) * LS + I * NB + kb], r1 = Vs[(2 + ke) * LS + I * NB + kb];
+        const cplx c0 = Vs[(0 + ke) * LS + J * NB + kb], c1 = Vs[(2 + ke) * LS + J * NB + kb];
         const double w0r = l * r0.re, w0i = l * r0.im, w1r = l * r1.re, w1i = l * r1.im;
         // w * conj(c)
         out.re[0] += w0r * c0.re + w0i * c0.im; out.im[0] += w0i * c0.re - w0r * c0.im;

@@ -13,6 +13,7 @@
 //   _cost / _grad_cost      tomography.py:597-633
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
 #include "fbx_choi.hpp"
+#include <cstdlib>
 
 namespace fbx {
 
@@ -34,7 +35,7 @@ struct PgdbLds {
         constexpr int D = ChoiLds<NQ>::D;
         size_t choi = ChoiLds<NQ>::bytes();
         size_t h = sizeof(double) * 2 * (size_t)m;
-        size_t jac = sizeof(cplx) * 2 * D * ChoiLds<NQ>::LD;
+        size_t jac = sizeof(cplx) * (D * ChoiLds<NQ>::LD + 2 * D * D);
         size_t extra = h > jac ? h - jac : 0;     // h aliases Mw..Vw, spill past them if longer
         return choi + extra + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + 64;
     }
@@ -42,7 +43,7 @@ struct PgdbLds {
         constexpr int D = ChoiLds<NQ>::D;
         char* base = p;
         size_t h = sizeof(double) * 2 * (size_t)m;
-        size_t jac = sizeof(cplx) * 2 * D * ChoiLds<NQ>::LD;
+        size_t jac = sizeof(cplx) * (D * ChoiLds<NQ>::LD + 2 * D * D);
         if (h > jac) {            // put the h arrays first, Jacobi matrices inside them
             hs = (double*)p; hd = hs + m;
             choi.carve(p);
@@ -78,7 +79,8 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
             double* __restrict__ choi_out, int* __restrict__ iters_out,
             int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-            double* __restrict__ cost_out, int* __restrict__ sweeps_out) {
+            double* __restrict__ cost_out, int* __restrict__ sweeps_out,
+            long long* __restrict__ phase_out) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
@@ -143,6 +145,8 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     for (int idx = lane; idx < S * D; idx += 64) L.Tupd[idx] = 0.0;
 
     int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
+    PhaseClock pc; pc.reset(); L.choi.pc = &pc;
+    PH_START(pc);
     double old_cost = 0.0, new_cost = 0.0;
     bool have_cost = false;
 
@@ -156,6 +160,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         __syncthreads();
         predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
         __syncthreads();
+        PH_STOP(pc, 3);
         if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }   // tomography.py:565
 
         // ---- gradient (tomography.py:617-633): eta = n / clip(p); W_s = sum eta Pi
@@ -197,11 +202,13 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         }
         __syncthreads();
         const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, lane);
+        PH_STOP(pc, 4);
 
         // ---- projected step (tomography.py:572)
         const Blk x = blk_axpy(est, -inv_mu, grad);
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps);
         const Blk upd = blk_sub(proj, est);
+        PH_STOP(pc, 2);
 
         // ---- prediction table of the update direction
         __syncthreads();
@@ -212,6 +219,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         predict_table<NQ>(L.Rb, L.Cl, L.Tupd, S, lane);
         __syncthreads();
 
+        PH_STOP(pc, 3);
         // ---- backtracking line search (tomography.py:575-585)
         double ipr, ipi;
         blk_dotc(upd, grad, ipr, ipi);
@@ -226,6 +234,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             ++backtracks;
             if (alpha < PGDB_ALPHA_MIN) break;
         }
+        PH_STOP(pc, 5);
         est = blk_axpy(est, alpha, upd);            // tomography.py:588
         ++iters;
         if (mode == FBX_MODE_CONVERGE) {
@@ -252,7 +261,12 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         if (cost_out) cost_out[item] = have_cost ? new_cost : 0.0;
         if (sweeps_out) sweeps_out[item] = sweeps;
     }
+#ifdef FBX_PHASE_TIMERS
+    if (lane == 0 && phase_out) for (int i = 0; i < FBX_NPHASE; ++i) phase_out[item * FBX_NPHASE + i] = pc.acc[i];
+#endif
 }
+
+static long long* g_phase_out = nullptr;   // diagnostics: set by fbx_debug_set_phase_buffer
 
 template <int NQ, int MAXJ>
 static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
@@ -266,7 +280,8 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     auto kern = pgdb_kernel<NQ, MAXJ>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream(), des->dev, (long long)B, e, c, tp,
-                       mode, max_iters, choi, it, dy, bt, cost, (int*)nullptr);
+                       mode, max_iters, choi, it, dy, getenv("FBX_DEBUG_SWEEPS") ? nullptr : bt, cost,
+                       getenv("FBX_DEBUG_SWEEPS") ? bt : (int*)nullptr, g_phase_out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;
 }
@@ -303,6 +318,10 @@ static int pgdb_check(const fbx_design* des, int64_t B, const void* e, const voi
 using namespace fbx;
 
 extern "C" {
+
+// diagnostics only (not part of include/fbx.h): device buffer of 8 int64 per item that a
+// -DFBX_PHASE_TIMERS build fills with per-phase shader cycles
+int fbx_debug_set_phase_buffer(long long* d_buf) { g_phase_out = d_buf; return FBX_OK; }
 
 int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
                          const double* d_counts, int trace_preserving, int mode, int max_iters,

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libfbx.so")
+_LIB_PATH = os.environ.get("FBX_LIBRARY", os.path.join(os.path.dirname(_HERE), "libfbx.so"))
 
 FBX_OK, FBX_ERR_BAD_ARG, FBX_ERR_HIP, FBX_ERR_NO_DEVICE, FBX_ERR_UNSUPPORTED, FBX_ERR_NOMEM = range(6)
 KIND_STATE, KIND_PROCESS = 0, 1

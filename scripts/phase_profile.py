@@ -1,0 +1,30 @@
+"""Per-phase cycle breakdown of the PGDB kernel (needs libfbx_prof.so: build.py --profile)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["FBX_LIBRARY"] = os.path.join(ROOT, "forest-benchmarking_amd", "libfbx_prof.so")
+sys.path.insert(0, os.path.join(ROOT, 'forest-benchmarking_amd'))
+import numpy as np
+from fbx import synthetic, tomography, _lib
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+mode = sys.argv[2] if len(sys.argv) > 2 else 'fixed'
+design, us, e, c = synthetic.process_batch(2, 'pauli', B)
+_lib.set_device(0)
+lib = _lib.lib()
+buf = _lib.DeviceBuffer(B * 8 * 8)
+lib.fbx_debug_set_phase_buffer.argtypes = [ctypes.c_void_p]
+lib.fbx_debug_set_phase_buffer(buf.ptr)
+import time
+for rep in range(2):
+    t = time.time()
+    choi, st = tomography.pgdb_process_estimate_batch(design, e, c, mode=mode, max_iters=100 if mode == 'fixed' else 0, return_stats=True)
+    dt = time.time() - t
+ph = buf.to_array(np.int64, (B, 8))
+names = ['jacobi', 'reconstruct', 'dykstra-other', 'transforms', 'gradient', 'linesearch', '-', '-']
+tot = ph.sum(1)
+print('B', B, mode, 'time %.1f ms' % (1e3 * dt), 'recon/s %.0f' % (B / dt))
+print('cycles/item mean %.3e max %.3e' % (tot.mean(), tot.max()))
+for i, n in enumerate(names[:6]):
+    print('  %-14s mean %.3e (%.1f%%)  max-item share %.3e' % (n, ph[:, i].mean(), 100 * ph[:, i].sum() / tot.sum(), ph[tot.argmax(), i]))
+print('per eigh jacobi cycles %.0f ; dykstra iters mean %.1f max %d; backtracks mean %.1f max %d' % (
+    ph[:, 0].sum() / st['dykstra'].sum(), st['dykstra'].mean(), st['dykstra'].max(), st['backtracks'].mean(), st['backtracks'].max()))
+print('per cost eval cycles %.0f' % (ph[:, 5].sum() / (st['backtracks'].sum() + 100 * B)))
