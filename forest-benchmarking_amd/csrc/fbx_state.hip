@@ -1,0 +1,581 @@
+// fbx_state.hip -- batched state-tomography estimators and state measures on d x d (d = 2^n,
+// n <= 3) density matrices.  One 64-lane wavefront per item; lane t < d*d owns matrix entry
+// (t / d, t % d); Pauli expectations and the R operator are evaluated through the sparsity of
+// the Pauli matrices (P_p[r][c] != 0 iff c = r ^ x_p), never by building d x d operators.
+//
+// Reference functions (file:line under forest/benchmarking/):
+//   linear_inv_state_estimate        tomography.py:130-165
+//   iterative_mle_state_estimate     tomography.py:168-270   (+ _R, :273-338)
+//   state_log_likelihood             tomography.py:341-375
+//   project_state_matrix_to_physical operator_tools/project_state_matrix.py:6-52
+//   purity / fidelity / trace_distance / hilbert_schmidt_ip   distance_measures.py:14-114,198-216
+//   sqrtm_psd                        operator_tools/calculational.py:77-91
+#include "fbx_eigh.hpp"
+#include <cfloat>
+
+namespace fbx {
+
+template <int NQ>
+struct StateLds {
+    static constexpr int d = 1 << NQ, D = d * d;
+    cplx *rho, *U, *tmp, *aux;     // [d*d] row-major
+    cplx *Ms, *Vs;                 // [d*d] Jacobi layout
+    JRec* rec;                     // [d/2 + 1]
+    double *w, *r, *lam;           // [D], [D], [d]
+    double *hs, *hd;               // [m] per-setting scratch
+    static size_t bytes(int m) {
+        return sizeof(cplx) * 6 * D + sizeof(JRec) * (d / 2 + 1) + sizeof(double) * (2 * D + d + 2 * (size_t)m) + 64;
+    }
+    __device__ void carve(char* p, int m) {
+        rho = (cplx*)p; p += sizeof(cplx) * D;  U = (cplx*)p; p += sizeof(cplx) * D;
+        tmp = (cplx*)p; p += sizeof(cplx) * D;  aux = (cplx*)p; p += sizeof(cplx) * D;
+        Ms = (cplx*)p; p += sizeof(cplx) * D;   Vs = (cplx*)p; p += sizeof(cplx) * D;
+        rec = (JRec*)p; p += sizeof(JRec) * (d / 2 + 1);
+        w = (double*)p; p += sizeof(double) * D; r = (double*)p; p += sizeof(double) * D;
+        lam = (double*)p; p += sizeof(double) * d;
+        hs = (double*)p; p += sizeof(double) * m; hd = (double*)p;
+    }
+};
+
+// P_p[row][row ^ x] = i^{ny} (-1)^{popc((row ^ x) & z)}
+template <int NQ>
+__device__ __forceinline__ void pauli_entry(int x, int z, int ny, int row, int& col, int& ph, int& neg) {
+    col = row ^ x; ph = ny & 3; neg = __popc(col & z) & 1;
+}
+
+// r[p] = Re tr(P_p rho) for every Pauli index p (lanes p < D)
+template <int NQ>
+__device__ void pauli_expectations(const cplx* rho, double* r, int lane) {
+    constexpr int d = 1 << NQ, D = d * d;
+    if (lane < D) {
+        int x, z, ny; pauli_masks<NQ>(lane, x, z, ny);
+        double acc = 0.0;
+#pragma unroll
+        for (int row = 0; row < d; ++row) {
+            int col, ph, neg; pauli_entry<NQ>(x, z, ny, row, col, ph, neg);
+            const cplx v = rho[col * d + row];                 // rho[col][row]
+            const double t = (ph == 0) ? v.re : (ph == 1) ? -v.im : (ph == 2) ? -v.re : v.im;
+            acc += neg ? -t : t;
+        }
+        r[lane] = acc;
+    }
+}
+
+// element (row, col) of  w0 * I + sum_p w[p] P_p
+template <int NQ>
+__device__ __forceinline__ cplx pauli_synthesis(const double* w, double w0, int row, int col) {
+    constexpr int d = 1 << NQ;
+    const int x = row ^ col;
+    double re = (row == col) ? w0 : 0.0, im = 0.0;
+#pragma unroll
+    for (int z = 0; z < d; ++z) {
+        const int p = pauli_index<NQ>(x, z);
+        const int ph = __popc(x & z) & 3, neg = __popc(col & z) & 1;
+        double v = w[p]; v = neg ? -v : v;
+        if (ph == 0) re += v; else if (ph == 1) im += v; else if (ph == 2) re -= v; else im -= v;
+    }
+    cplx o; o.re = re; o.im = im; return o;
+}
+
+// R operator of tomography.py:273-338 for the state in L.rho; result element of this lane.
+template <int NQ>
+__device__ cplx r_operator_elem(const DesignDev& des, const double* __restrict__ e, StateLds<NQ>& L, int lane) {
+    constexpr int d = 1 << NQ, D = d * d;
+    const int m = des.m;
+    pauli_expectations<NQ>(L.rho, L.r, lane);
+    __syncthreads();
+    double s0 = 0.0;
+    for (int g = lane; g < m; g += 64) {
+        const int p = des.sp[g] & 0xffff;
+        const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+        const double me = e[des.order[g]], pe = cf * L.r[p];
+        const double gp = ((1.0 + me) * 0.5) / ((1.0 + pe) * 0.5 + DBL_MIN);
+        const double gm = ((1.0 - me) * 0.5) / ((1.0 - pe) * 0.5 + DBL_MIN);
+        L.hs[g] = 0.5 * (gp + gm);
+        L.hd[g] = cf * 0.5 * (gp - gm);
+        s0 += 0.5 * (gp + gm);
+    }
+    s0 = wave_sum(s0);
+    __syncthreads();
+    if (lane < D) {
+        double acc = 0.0;
+        for (int g = 0; g < m; ++g) if ((int)(des.sp[g] & 0xffff) == lane) acc += L.hd[g];
+        L.w[lane] = acc / m;
+    }
+    __syncthreads();
+    cplx out; out.re = 0.0; out.im = 0.0;
+    if (lane < D) out = pauli_synthesis<NQ>(L.w, s0 / m + 0.0, lane / d, lane % d);
+    // identity-observable settings contribute through w[0] as well as through s0: P_0 = I
+    return out;
+}
+
+// Hermitian function of a d x d matrix staged row-major in `src`: out = V f(lambda) V^H with
+// f selected by `fn` (0: log, 1: pseudo-inverse, 2: sqrt(max(.,0))); eigenvalues left in L.lam
+template <int NQ>
+__device__ void herm_function(const cplx* src, cplx* dst, int fn, StateLds<NQ>& L, int lane, bool lower_only) {
+    constexpr int d = 1 << NQ, NB = d / 2;
+    Blk h = blk_zero();
+    if (lane < NB * NB) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
+            if (lower_only) {                       // scipy / numpy eigh read the lower triangle
+                if (r > c) { h.re[e] = src[r * d + c].re; h.im[e] = src[r * d + c].im; }
+                else if (r < c) { h.re[e] = src[c * d + r].re; h.im[e] = -src[c * d + r].im; }
+                else { h.re[e] = src[r * d + c].re; h.im[e] = 0.0; }
+            } else {
+                const cplx a = src[r * d + c], b = src[c * d + r];
+                h.re[e] = 0.5 * (a.re + b.re); h.im[e] = 0.5 * (a.im - b.im);
+            }
+        }
+    }
+    __syncthreads();
+    sys_store<d>(L.Ms, lane, h);
+    __syncthreads();
+    jacobi_eigh_lds<d>(L.Ms, L.Vs, L.rec, lane);
+    double lmax = 0.0;
+    if (lane < d) lmax = fabs(L.Ms[sys_index<d>(lane, lane)].re);
+    lmax = wave_max(lmax);
+    if (lane < d) {
+        const double l = L.Ms[sys_index<d>(lane, lane)].re;
+        double f;
+        if (fn == 0) f = log(l);
+        else if (fn == 1) f = (fabs(l) > d * DBL_EPSILON * lmax) ? 1.0 / l : 0.0;   // scipy pinv cut-off
+        else f = sqrt(l > 0.0 ? l : 0.0);
+        L.lam[lane] = f;
+    }
+    __syncthreads();
+    const Blk o = reconstruct_blk<d>(L.Vs, L.lam, lane);
+    blk_store<d, d>(dst, lane, o);
+    __syncthreads();
+}
+
+// tmp2 = A * B (row-major d x d), one output element per lane
+template <int NQ>
+__device__ __forceinline__ cplx matmul_elem(const cplx* A, const cplx* Bm, int lane) {
+    constexpr int d = 1 << NQ;
+    cplx o; o.re = 0.0; o.im = 0.0;
+    if (lane < d * d) {
+        const int r = lane / d, c = lane % d;
+#pragma unroll
+        for (int k = 0; k < d; ++k) {
+            const cplx a = A[r * d + k], b = Bm[k * d + c];
+            o.re += a.re * b.re - a.im * b.im;
+            o.im += a.re * b.im + a.im * b.re;
+        }
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ void __launch_bounds__(64)
+mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
+                 double epsilon, double entropy_penalty, double beta, double tol, int maxiter,
+                 double* __restrict__ rho_out, int* __restrict__ iters_out, int* __restrict__ hit_out) {
+    constexpr int d = 1 << NQ, D = d * d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StateLds<NQ> L; L.carve(smem, des.m);
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    const double* e = expect + item * des.m;
+    const bool act = lane < D;
+    const int row = act ? lane / d : 0, col = act ? lane % d : 0;
+    double num_meas = 0.0;
+    for (int g = lane; g < des.m; g += 64) num_meas += counts[item * des.m + g];
+    num_meas = wave_sum(num_meas);
+    cplx rho; rho.re = (act && row == col) ? 1.0 / d : 0.0; rho.im = 0.0;
+    if (act) L.rho[lane] = rho;
+    __syncthreads();
+    int iteration = 1, hit = 0;
+    while (true) {
+        if (iteration >= maxiter) { hit = 1; break; }            // tomography.py:244-246
+        cplx T = r_operator_elem<NQ>(des, e, L, lane);             // R(rho)
+        if (act && row == col) T.re -= 1.0;                        // Tk = R - I
+        if (entropy_penalty > 0.0) {                               // tomography.py:252-254
+            herm_function<NQ>(L.rho, L.aux, 0, L, lane, false);    // logm(rho)
+            cplx lg; lg.re = 0.0; lg.im = 0.0;
+            if (act) lg = L.aux[lane];
+            const cplx rl = matmul_elem<NQ>(L.rho, L.aux, lane);   // rho @ logm(rho)
+            double tr_re = (act && row == col) ? rl.re : 0.0, tr_im = (act && row == col) ? rl.im : 0.0;
+            tr_re = wave_sum(tr_re); tr_im = wave_sum(tr_im);
+            if (act && row == col) { lg.re -= tr_re; lg.im -= tr_im; }
+            T.re -= entropy_penalty * lg.re; T.im -= entropy_penalty * lg.im;
+        }
+        if (beta > 0.0) {                                          // tomography.py:257-260
+            T.re *= num_meas / 2; T.im *= num_meas / 2;
+            herm_function<NQ>(L.rho, L.aux, 1, L, lane, false);    // pinv(rho)
+            cplx pi; pi.re = 0.0; pi.im = 0.0;
+            if (act) pi = L.aux[lane];
+            if (act && row == col) pi.re -= d;
+            T.re += beta * pi.re / 2; T.im += beta * pi.im / 2;
+        }
+        cplx Um; Um.re = epsilon * T.re + ((act && row == col) ? 1.0 : 0.0); Um.im = epsilon * T.im;
+        __syncthreads();
+        if (act) L.U[lane] = Um;
+        __syncthreads();
+        const cplx t1 = matmul_elem<NQ>(L.rho, L.U, lane);         // rho U
+        if (act) L.tmp[lane] = t1;
+        __syncthreads();
+        cplx nr = matmul_elem<NQ>(L.U, L.tmp, lane);               // U rho U
+        double tr_re = (act && row == col) ? nr.re : 0.0, tr_im = (act && row == col) ? nr.im : 0.0;
+        tr_re = wave_sum(tr_re); tr_im = wave_sum(tr_im);
+        {   // complex division by the trace
+            const double den = tr_re * tr_re + tr_im * tr_im;
+            const double qr = (nr.re * tr_re + nr.im * tr_im) / den, qi = (nr.im * tr_re - nr.re * tr_im) / den;
+            nr.re = qr; nr.im = qi;
+        }
+        double diff = act ? (nr.re - rho.re) * (nr.re - rho.re) + (nr.im - rho.im) * (nr.im - rho.im) : 0.0;
+        diff = uniform(wave_sum(diff));
+        rho = nr;
+        __syncthreads();
+        if (act) L.rho[lane] = rho;
+        __syncthreads();
+        if (sqrt(diff) < tol) break;
+        ++iteration;
+    }
+    if (act) { rho_out[(item * D + lane) * 2] = rho.re; rho_out[(item * D + lane) * 2 + 1] = rho.im; }
+    if (lane == 0) { if (iters_out) iters_out[item] = iteration; if (hit_out) hit_out[item] = hit; }
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(64)
+r_operator_kernel(DesignDev des, long long B, const double* __restrict__ rho_in, const double* __restrict__ expect,
+                  double* __restrict__ r_out) {
+    constexpr int d = 1 << NQ, D = d * d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StateLds<NQ> L; L.carve(smem, des.m);
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    if (lane < D) { L.rho[lane].re = rho_in[(item * D + lane) * 2]; L.rho[lane].im = rho_in[(item * D + lane) * 2 + 1]; }
+    __syncthreads();
+    const cplx R = r_operator_elem<NQ>(des, expect + item * des.m, L, lane);
+    if (lane < D) { r_out[(item * D + lane) * 2] = R.re; r_out[(item * D + lane) * 2 + 1] = R.im; }
+}
+
+// log-likelihood (log10), tomography.py:341-375
+template <int NQ>
+__global__ void __launch_bounds__(64)
+loglik_kernel(DesignDev des, long long B, const double* __restrict__ rho_in, const double* __restrict__ expect,
+              const double* __restrict__ counts, double* __restrict__ ll_out) {
+    constexpr int d = 1 << NQ, D = d * d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StateLds<NQ> L; L.carve(smem, des.m);
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    if (lane < D) { L.rho[lane].re = rho_in[(item * D + lane) * 2]; L.rho[lane].im = rho_in[(item * D + lane) * 2 + 1]; }
+    __syncthreads();
+    pauli_expectations<NQ>(L.rho, L.r, lane);
+    __syncthreads();
+    double ll = 0.0;
+    for (int g = lane; g < des.m; g += 64) {
+        const int k = des.order[g], p = des.sp[g] & 0xffff;
+        const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+        const double n = counts[item * des.m + k], me = expect[item * des.m + k], pe = cf * L.r[p];
+        const double pp = (1.0 + pe) / 2, pm = (1.0 - pe) / 2;
+        if (pp > 0.0) ll += n * (1.0 + me) / 2 * log10(pp);
+        if (pm > 0.0) ll += n * (1.0 - me) / 2 * log10(pm);
+    }
+    ll = wave_sum(ll);
+    if (lane == 0) ll_out[item] = ll;
+}
+
+// linear inversion, tomography.py:130-165: per Pauli a least-squares coefficient, then synthesis
+template <int NQ>
+__global__ void __launch_bounds__(64)
+linv_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, double* __restrict__ rho_out) {
+    constexpr int d = 1 << NQ, D = d * d;
+    __shared__ double w[D];
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    if (lane < D) {
+        double num = 0.0, den = 0.0;
+        for (int g = 0; g < des.m; ++g) {
+            if ((int)(des.sp[g] & 0xffff) != lane) continue;
+            const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+            num += cf * expect[item * des.m + des.order[g]];
+            den += cf * cf;
+        }
+        w[lane] = den > 0.0 ? num / (den * d) : 0.0;     // pinv of orthogonal rows c_k vec(P)^H
+    }
+    __syncthreads();
+    if (lane < D) {
+        const cplx v = pauli_synthesis<NQ>(w, 1.0 / d, lane / d, lane % d);   // + I/d, tomography.py:165
+        rho_out[(item * D + lane) * 2] = v.re; rho_out[(item * D + lane) * 2 + 1] = v.im;
+    }
+}
+
+// project_state_matrix_to_physical, project_state_matrix.py:6-52
+template <int NQ>
+__global__ void __launch_bounds__(64)
+proj_state_kernel(long long B, const double* __restrict__ rho_in, double* __restrict__ out) {
+    constexpr int d = 1 << NQ, D = d * d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StateLds<NQ> L; L.carve(smem, 1);
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    const bool act = lane < D;
+    cplx v; v.re = 0.0; v.im = 0.0;
+    if (act) { v.re = rho_in[(item * D + lane) * 2]; v.im = rho_in[(item * D + lane) * 2 + 1]; }
+    double tr_re = (act && lane / d == lane % d) ? v.re : 0.0, tr_im = (act && lane / d == lane % d) ? v.im : 0.0;
+    tr_re = wave_sum(tr_re); tr_im = wave_sum(tr_im);
+    const double den = tr_re * tr_re + tr_im * tr_im;
+    cplx q; q.re = (v.re * tr_re + v.im * tr_im) / den; q.im = (v.im * tr_re - v.re * tr_im) / den;
+    if (act) L.rho[lane] = q;
+    __syncthreads();
+    // eigh (lower triangle, like scipy.linalg.eigh)
+    constexpr int NB = d / 2;
+    Blk h = blk_zero();
+    if (lane < NB * NB) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
+            if (r > c) { h.re[e] = L.rho[r * d + c].re; h.im[e] = L.rho[r * d + c].im; }
+            else if (r < c) { h.re[e] = L.rho[c * d + r].re; h.im[e] = -L.rho[c * d + r].im; }
+            else { h.re[e] = L.rho[r * d + c].re; h.im[e] = 0.0; }
+        }
+    }
+    sys_store<d>(L.Ms, lane, h);
+    __syncthreads();
+    jacobi_eigh_lds<d>(L.Ms, L.Vs, L.rec, lane);
+    __shared__ int physical;
+    if (lane == 0) {
+        double ev[d]; int idx[d];
+        double mn = 1e300;
+        for (int k = 0; k < d; ++k) { ev[k] = L.Ms[sys_index<d>(k, k)].re; idx[k] = k; mn = fmin(mn, ev[k]); }
+        physical = mn >= 0.0;
+        // descending order
+        for (int a = 0; a < d; ++a) for (int b = a + 1; b < d; ++b)
+            if (ev[b] > ev[a]) { double t = ev[a]; ev[a] = ev[b]; ev[b] = t; int u = idx[a]; idx[a] = idx[b]; idx[b] = u; }
+        int i = d; double acc = 0.0;
+        while (i > 0 && ev[i - 1] + acc / (double)i < 0.0) { acc += ev[i - 1]; --i; }
+        for (int j = 0; j < d; ++j) L.lam[idx[j]] = (j < i) ? ev[j] + acc / (double)i : 0.0;
+    }
+    __syncthreads();
+    cplx o = q;
+    if (!physical) {
+        const Blk pb = reconstruct_blk<d>(L.Vs, L.lam, lane);
+        blk_store<d, d>(L.tmp, lane, pb);
+        __syncthreads();
+        if (act) o = L.tmp[lane];
+    }
+    if (act) { out[(item * D + lane) * 2] = o.re; out[(item * D + lane) * 2 + 1] = o.im; }
+}
+
+// purity / fidelity / trace distance / Hilbert-Schmidt inner product
+template <int NQ>
+__global__ void __launch_bounds__(64)
+state_measures_kernel(long long B, const double* __restrict__ rho_in, const double* __restrict__ sig_in,
+                      double* __restrict__ purity, double* __restrict__ fidelity, double* __restrict__ tdist,
+                      double* __restrict__ hsip) {
+    constexpr int d = 1 << NQ, D = d * d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StateLds<NQ> L; L.carve(smem, 1);
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    const bool act = lane < D;
+    cplx a, b; a.re = a.im = b.re = b.im = 0.0;
+    if (act) {
+        a.re = rho_in[(item * D + lane) * 2]; a.im = rho_in[(item * D + lane) * 2 + 1];
+        b.re = sig_in[(item * D + lane) * 2]; b.im = sig_in[(item * D + lane) * 2 + 1];
+        L.rho[lane] = a; L.U[lane] = b;
+    }
+    __syncthreads();
+    if (purity) {                                  // Re tr(rho rho)
+        double p = 0.0;
+        if (act) { const cplx t = L.rho[(lane % d) * d + lane / d]; p = a.re * t.re - a.im * t.im; }
+        p = wave_sum(p);
+        if (lane == 0) purity[item] = p;
+    }
+    if (hsip) {                                    // Re tr(A^H B)
+        double p = act ? a.re * b.re + a.im * b.im : 0.0;
+        p = wave_sum(p);
+        if (lane == 0) hsip[item] = p;
+    }
+    if (tdist) {                                   // 0.5 * max_c sum_r |rho - sigma|[r][c]
+        if (act) { const double dr = a.re - b.re, di = a.im - b.im; L.r[lane] = sqrt(dr * dr + di * di); }
+        __syncthreads();
+        double cs = 0.0;
+        if (lane < d) for (int r = 0; r < d; ++r) cs += L.r[r * d + lane];
+        cs = wave_max(cs);
+        if (lane == 0) tdist[item] = 0.5 * cs;
+        __syncthreads();
+    }
+    if (fidelity) {                                // (tr sqrtm_psd(sqrt_rho sigma sqrt_rho))^2
+        herm_function<NQ>(L.rho, L.aux, 2, L, lane, true);            // sqrt_rho
+        const cplx t1 = matmul_elem<NQ>(L.aux, L.U, lane);            // sqrt_rho sigma
+        if (act) L.tmp[lane] = t1;
+        __syncthreads();
+        const cplx t2 = matmul_elem<NQ>(L.tmp, L.aux, lane);          // ... sqrt_rho
+        __syncthreads();
+        if (act) L.tmp[lane] = t2;
+        __syncthreads();
+        herm_function<NQ>(L.tmp, L.aux, 2, L, lane, true);            // lam = sqrt(max(mu, 0))
+        double s = (lane < d) ? L.lam[lane] : 0.0;
+        s = wave_sum(s);
+        if (lane == 0) fidelity[item] = s * s;
+    }
+}
+
+}  // namespace fbx
+
+using namespace fbx;
+
+namespace {
+struct HostIO {
+    std::vector<DevBuf*> bufs;
+    ~HostIO() { for (auto* b : bufs) delete b; }
+    template <class T> int in(const T* host, size_t count, T** dev) {
+        auto* b = new DevBuf(); bufs.push_back(b);
+        int rc = b->alloc(sizeof(T) * count);
+        if (rc) return rc;
+        if (host && count) {
+            hipError_t e = hipMemcpyAsync(b->p, host, sizeof(T) * count, hipMemcpyHostToDevice, stream());
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(H2D)", __FILE__, __LINE__);
+        }
+        *dev = b->as<T>();
+        return FBX_OK;
+    }
+    template <class T> int out(size_t count, T** dev) {
+        auto* b = new DevBuf(); bufs.push_back(b);
+        int rc = b->alloc(sizeof(T) * count);
+        if (rc) return rc;
+        *dev = b->as<T>();
+        return FBX_OK;
+    }
+    template <class T> int back(T* host, const T* dev, size_t count) {
+        if (!host || !count) return FBX_OK;
+        hipError_t e = hipMemcpyAsync(host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, stream());
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(D2H)", __FILE__, __LINE__);
+        return FBX_OK;
+    }
+    int sync() { FBX_HIP(hipStreamSynchronize(stream())); return FBX_OK; }
+};
+#define FBX_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+#define FBX_DISPATCH_NQ(n, KERNEL, lds, B, ...)                                                    \
+    do {                                                                                           \
+        if ((n) == 1) hipLaunchKernelGGL(KERNEL<1>, dim3((unsigned)(B)), dim3(64), (lds), stream(), __VA_ARGS__); \
+        else if ((n) == 2) hipLaunchKernelGGL(KERNEL<2>, dim3((unsigned)(B)), dim3(64), (lds), stream(), __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<3>, dim3((unsigned)(B)), dim3(64), (lds), stream(), __VA_ARGS__); \
+    } while (0)
+
+size_t state_lds(int n, int m) {
+    return n == 1 ? StateLds<1>::bytes(m) : n == 2 ? StateLds<2>::bytes(m) : StateLds<3>::bytes(m);
+}
+int check_state_design(const fbx_design* des, const char* who) {
+    if (!des) { set_error(std::string(who) + ": NULL design"); return FBX_ERR_BAD_ARG; }
+    if (des->dev.kind != FBX_KIND_STATE) { set_error(std::string(who) + ": needs a state design"); return FBX_ERR_BAD_ARG; }
+    return FBX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fbx_linv_state(const fbx_design* design, int64_t B, const double* expect, double* rho_out) {
+    FBX_TRY(check_state_design(design, "fbx_linv_state"));
+    FBX_REQUIRE(B >= 0 && (B == 0 || (expect && rho_out)), "fbx_linv_state: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
+    HostIO io; double *de, *dr;
+    FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.out(D * 2 * B, &dr));
+    FBX_DISPATCH_NQ(n, linv_state_kernel, 0, B, design->dev, (long long)B, de, dr);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(rho_out, dr, D * 2 * B));
+    return io.sync();
+}
+
+int fbx_mle_state(const fbx_design* design, int64_t B, const double* expect, const double* counts,
+                  double epsilon, double entropy_penalty, double beta, double tol, int maxiter,
+                  double* rho_out, int32_t* iters_out, int32_t* hit_max_out) {
+    FBX_TRY(check_state_design(design, "fbx_mle_state"));
+    FBX_REQUIRE(!(entropy_penalty != 0.0 && beta != 0.0),
+                "One can't sensibly do entropy penalty and hedging. Do one or the other but not both.");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (expect && counts && rho_out)), "fbx_mle_state: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
+    const size_t lds = state_lds(n, (int)m);
+    if (lds > 64 * 1024) { set_error("fbx_mle_state: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    HostIO io; double *de, *dc, *dr; int32_t *di, *dh;
+    FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.in(counts, m * B, &dc));
+    FBX_TRY(io.out(D * 2 * B, &dr)); FBX_TRY(io.out((size_t)B, &di)); FBX_TRY(io.out((size_t)B, &dh));
+    FBX_DISPATCH_NQ(n, mle_state_kernel, lds, B, design->dev, (long long)B, de, dc, epsilon, entropy_penalty, beta, tol,
+                    maxiter, dr, di, dh);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(rho_out, dr, D * 2 * B)); FBX_TRY(io.back(iters_out, di, (size_t)B));
+    FBX_TRY(io.back(hit_max_out, dh, (size_t)B));
+    return io.sync();
+}
+
+int fbx_r_operator(const fbx_design* design, int64_t B, const double* rho, const double* expect, double* r_out) {
+    FBX_TRY(check_state_design(design, "fbx_r_operator"));
+    FBX_REQUIRE(B >= 0 && (B == 0 || (rho && expect && r_out)), "fbx_r_operator: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
+    const size_t lds = state_lds(n, (int)m);
+    if (lds > 64 * 1024) { set_error("fbx_r_operator: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    HostIO io; double *dr, *de, *dout;
+    FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.out(D * 2 * B, &dout));
+    FBX_DISPATCH_NQ(n, r_operator_kernel, lds, B, design->dev, (long long)B, dr, de, dout);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(r_out, dout, D * 2 * B));
+    return io.sync();
+}
+
+int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* rho, const double* expect,
+                             const double* counts, double* ll_out) {
+    FBX_TRY(check_state_design(design, "fbx_state_log_likelihood"));
+    FBX_REQUIRE(B >= 0 && (B == 0 || (rho && expect && counts && ll_out)), "fbx_state_log_likelihood: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
+    const size_t lds = state_lds(n, 1);
+    HostIO io; double *dr, *de, *dc, *dout;
+    FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.in(counts, m * B, &dc));
+    FBX_TRY(io.out((size_t)B, &dout));
+    FBX_DISPATCH_NQ(n, loglik_kernel, lds, B, design->dev, (long long)B, dr, de, dc, dout);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(ll_out, dout, (size_t)B));
+    return io.sync();
+}
+
+int fbx_proj_state_physical(int n_qubits, int64_t B, const double* rho, double* out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_proj_state_physical: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (rho && out)), "fbx_proj_state_physical: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d;
+    HostIO io; double *dr, *dout;
+    FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.out(D * 2 * B, &dout));
+    FBX_DISPATCH_NQ(n_qubits, proj_state_kernel, state_lds(n_qubits, 1), B, (long long)B, dr, dout);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(out, dout, D * 2 * B));
+    return io.sync();
+}
+
+int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double* sigma, double* purity_out,
+                       double* fidelity_out, double* trace_dist_out, double* hs_ip_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_state_measures: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (rho && sigma)), "fbx_state_measures: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d;
+    HostIO io; double *dr, *ds, *dp = nullptr, *df = nullptr, *dt = nullptr, *dh = nullptr;
+    FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.in(sigma, D * 2 * B, &ds));
+    if (purity_out) FBX_TRY(io.out((size_t)B, &dp));
+    if (fidelity_out) FBX_TRY(io.out((size_t)B, &df));
+    if (trace_dist_out) FBX_TRY(io.out((size_t)B, &dt));
+    if (hs_ip_out) FBX_TRY(io.out((size_t)B, &dh));
+    FBX_DISPATCH_NQ(n_qubits, state_measures_kernel, state_lds(n_qubits, 1), B, (long long)B, dr, ds, dp, df, dt, dh);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(purity_out, dp, (size_t)B)); FBX_TRY(io.back(fidelity_out, df, (size_t)B));
+    FBX_TRY(io.back(trace_dist_out, dt, (size_t)B)); FBX_TRY(io.back(hs_ip_out, dh, (size_t)B));
+    return io.sync();
+}
+
+}  // extern "C"

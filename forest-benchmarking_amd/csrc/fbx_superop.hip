@@ -1,0 +1,522 @@
+// fbx_superop.hip -- batched superoperator algebra: representation changes, Choi projections,
+// channel application, process fidelity.  One 64-lane wavefront per item; matrices are staged
+// in LDS and every basis change uses the sparsity of the Pauli matrices (each vec(P_k) has d
+// non-zero entries, all in {+-1, +-i}) instead of a dense D x D x D product.
+//
+// Reference functions (file:line under forest/benchmarking/):
+//   operator_tools/superoperator_transformations.py:82-371   (pairwise conversions)
+//   operator_tools/project_superoperators.py:19-144          (CP / TP / TNI / physical)
+//   operator_tools/apply_superoperator.py:60-90              (apply_choi_matrix_2_state)
+//   distance_measures.py:271-359                             (entanglement / process fidelity)
+#include "fbx_choi.hpp"
+
+namespace fbx {
+
+// ---------------------------------------------------------------------------------------------
+// device primitives on a D x D complex matrix, row-major with leading dimension LD, in LDS
+// ---------------------------------------------------------------------------------------------
+
+// vec(P_k)[c*d + r] = P_k[r][c]; non-zero iff c = r ^ x_k with value i^{ny} (-1)^{popc(c & z)}
+// multiply v by i^ph
+__device__ __forceinline__ cplx mul_iph(cplx v, int ph) {
+    cplx o;
+    switch (ph & 3) {
+        case 0: o = v; break;
+        case 1: o.re = -v.im; o.im = v.re; break;
+        case 2: o.re = -v.re; o.im = -v.im; break;
+        default: o.re = v.im; o.im = -v.re; break;
+    }
+    return o;
+}
+
+// out = scale * P2C^H in P2C  (superop -> Pauli-Liouville with scale 1/d; Choi -> chi with 1/d^2),
+// P2C columns = vec(P_k): out[k][l] = scale * sum_{r,s} conj(vP_k[r]) in[r][s] vP_l[s]
+template <int NQ>
+__device__ void to_pauli_basis(const cplx* in, cplx* out, double scale, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int k = idx / D, l = idx % D;
+        int xk, zk, yk, xl, zl, yl;
+        pauli_masks<NQ>(k, xk, zk, yk);
+        pauli_masks<NQ>(l, xl, zl, yl);
+        double re = 0.0, im = 0.0;
+        for (int rk = 0; rk < d; ++rk) {          // row index of P_k's non-zero: (rk, ck = rk ^ xk)
+            const int ck = rk ^ xk;
+            const int sk = __popc(ck & zk) & 1;
+#pragma unroll
+            for (int rl = 0; rl < d; ++rl) {
+                const int cl = rl ^ xl;
+                const int sl = __popc(cl & zl) & 1;
+                const cplx v = in[(ck * d + rk) * LD + cl * d + rl];
+                // conj(i^yk) * i^yl = i^(yl - yk)
+                const cplx w = mul_iph(v, (yl - yk) & 3);
+                if (sk ^ sl) { re -= w.re; im -= w.im; } else { re += w.re; im += w.im; }
+            }
+        }
+        cplx o; o.re = re * scale; o.im = im * scale;
+        out[k * LD + l] = o;
+    }
+}
+
+// out = scale * P2C in P2C^H: out[r][s] = scale * sum_{k,l} vP_k[r] in[k][l] conj(vP_l[s])
+template <int NQ>
+__device__ void from_pauli_basis(const cplx* in, cplx* out, double scale, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int r = idx / D, s = idx % D;
+        const int cr = r / d, rr = r % d, cs = s / d, rs = s % d;   // vec index = col * d + row
+        const int xk = rr ^ cr, xl = rs ^ cs;
+        double re = 0.0, im = 0.0;
+        for (int zk = 0; zk < d; ++zk) {
+            const int k = pauli_index<NQ>(xk, zk);
+            const int yk = __popc(xk & zk), sk = __popc(cr & zk) & 1;
+#pragma unroll
+            for (int zl = 0; zl < d; ++zl) {
+                const int l = pauli_index<NQ>(xl, zl);
+                const int yl = __popc(xl & zl), sl = __popc(cs & zl) & 1;
+                const cplx w = mul_iph(in[k * LD + l], (yk - yl) & 3);
+                if (sk ^ sl) { re -= w.re; im -= w.im; } else { re += w.re; im += w.im; }
+            }
+        }
+        cplx o; o.re = re * scale; o.im = im * scale;
+        out[r * LD + s] = o;
+    }
+}
+
+// choi <-> superop reshuffle (superoperator_transformations.py:267-277,351-361):
+// out[(p,q)][(r,s)] = in[(s,q)][(r,p)]
+template <int NQ>
+__device__ void reshuffle(const cplx* in, cplx* out, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int row = idx / D, col = idx % D;
+        const int p = row / d, q = row % d, r = col / d, s = col % d;
+        out[row * LD + col] = in[(s * d + q) * LD + r * d + p];
+    }
+}
+
+// kraus -> choi (sum vec(K) vec(K)^H) or superop (sum conj(K) (x) K); K ops row-major d x d in HBM
+template <int NQ>
+__device__ void kraus_to(const double* __restrict__ kraus, int K, bool to_superop, cplx* out, cplx* kb,
+                         int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    for (int idx = lane; idx < K * D; idx += 64) { kb[idx].re = kraus[2 * idx]; kb[idx].im = kraus[2 * idx + 1]; }
+    __syncthreads();
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int row = idx / D, col = idx % D;
+        double re = 0.0, im = 0.0;
+        for (int t = 0; t < K; ++t) {
+            cplx a, b;     // out += a * b (a possibly conjugated below)
+            if (to_superop) {   // kron(conj(K), K)[(i,k)][(j,l)] = conj(K[i][j]) K[k][l]
+                const int i = row / d, k = row % d, j = col / d, l = col % d;
+                a = kb[t * D + i * d + j]; a.im = -a.im;
+                b = kb[t * D + k * d + l];
+            } else {            // vec(K)[c*d + r] = K[r][c]; choi[row][col] = vK[row] conj(vK[col])
+                a = kb[t * D + (row % d) * d + row / d];
+                b = kb[t * D + (col % d) * d + col / d]; b.im = -b.im;
+            }
+            re += a.re * b.re - a.im * b.im;
+            im += a.re * b.im + a.im * b.re;
+        }
+        cplx o; o.re = re; o.im = im;
+        out[row * LD + col] = o;
+    }
+}
+
+// matrix absolute value through the eigendecomposition, as choi2kraus -> kraus2choi does it
+// (superoperator_transformations.py:325-336): numpy eigh reads the LOWER triangle; eigenvalues
+// with |lambda| <= tol are dropped; sqrt of a negative eigenvalue is imaginary, so the rebuilt
+// matrix is sum |lambda| v v^H.
+template <int NQ>
+__device__ void abs_via_eigh(const cplx* in, cplx* out, ChoiLds<NQ>& L, double tol, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2;
+    Blk h = blk_zero();
+    if (lane < NB * NB) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
+            if (r > c) { const cplx v = in[r * LD + c]; h.re[e] = v.re; h.im[e] = v.im; }
+            else if (r < c) { const cplx v = in[c * LD + r]; h.re[e] = v.re; h.im[e] = -v.im; }
+            else { h.re[e] = in[r * LD + c].re; h.im[e] = 0.0; }
+        }
+    }
+    __syncthreads();
+    sys_store<D>(L.Ms, lane, h);
+    __syncthreads();
+    jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane);
+    if (lane < D) {
+        const double l = fabs(L.Ms[sys_index<D>(lane, lane)].re);
+        L.lam[lane] = l > tol ? l : 0.0;
+    }
+    __syncthreads();
+    const Blk a = reconstruct_blk<D>(L.Vs, L.lam, lane);
+    blk_store<D, LD>(out, lane, a);
+    __syncthreads();
+}
+
+template <int NQ>
+__device__ void load_matrix(const double* __restrict__ g, cplx* m, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        cplx v; v.re = g[2 * idx]; v.im = g[2 * idx + 1];
+        m[(idx / D) * LD + idx % D] = v;
+    }
+}
+template <int NQ>
+__device__ void store_matrix(const cplx* m, double* __restrict__ g, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const cplx v = m[(idx / D) * LD + idx % D];
+        g[2 * idx] = v.re; g[2 * idx + 1] = v.im;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fbx_convert
+// ---------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ void __launch_bounds__(64)
+convert_kernel(int from, int to, long long B, const double* __restrict__ in, int K, double* __restrict__ out) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* p = smem;
+    ChoiLds<NQ> L; L.carve(p);
+    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    cplx* A = (cplx*)p; p += sizeof(cplx) * D * LD;
+    cplx* Bm = (cplx*)p; p += sizeof(cplx) * D * LD;
+    cplx* kb = (cplx*)p;
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    cplx* cur = A; cplx* nxt = Bm;
+    auto swap = [&]() { cplx* t = cur; cur = nxt; nxt = t; __syncthreads(); };
+    const double inv_d = 1.0 / d;
+
+    // stage 1: bring the input to Choi (or directly to the target when a shorter path exists)
+    int rep = from;
+    if (from == FBX_REP_KRAUS) {
+        const bool sup = (to == FBX_REP_SUPEROP || to == FBX_REP_PAULI_LIOUVILLE);
+        kraus_to<NQ>(in + item * (long long)K * D * 2, K, sup, cur, kb, lane);
+        __syncthreads();
+        rep = sup ? FBX_REP_SUPEROP : FBX_REP_CHOI;
+    } else {
+        load_matrix<NQ>(in + item * (long long)D * D * 2, cur, lane);
+        __syncthreads();
+    }
+    // walk the representation graph: chi -> choi <-> superop <-> pauli-liouville, choi -> chi
+    const bool kraus_chi = (from == FBX_REP_KRAUS && to == FBX_REP_CHI);
+    while (rep != to) {
+        if (rep == FBX_REP_CHI) {                       // chi2choi: p2c chi p2c^H
+            from_pauli_basis<NQ>(cur, nxt, 1.0, lane); swap(); rep = FBX_REP_CHOI;
+        } else if (rep == FBX_REP_CHOI) {
+            if (to == FBX_REP_CHI) {
+                if (!kraus_chi) {                       // through choi2kraus (eigh, |C|, tol 1e-9)
+                    abs_via_eigh<NQ>(cur, nxt, L, 1e-9, lane); swap();
+                }
+                to_pauli_basis<NQ>(cur, nxt, inv_d * inv_d, lane); swap(); rep = FBX_REP_CHI;
+            } else {
+                reshuffle<NQ>(cur, nxt, lane); swap(); rep = FBX_REP_SUPEROP;
+            }
+        } else if (rep == FBX_REP_SUPEROP) {
+            if (to == FBX_REP_PAULI_LIOUVILLE) {
+                to_pauli_basis<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
+            } else {
+                reshuffle<NQ>(cur, nxt, lane); swap(); rep = FBX_REP_CHOI;
+            }
+        } else {                                        // pauli-liouville -> superop
+            from_pauli_basis<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_SUPEROP;
+        }
+    }
+    store_matrix<NQ>(cur, out + item * (long long)D * D * 2, lane);
+}
+
+template <int NQ>
+static int launch_convert(int from, int to, int64_t B, const double* in, int K, double* out) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    const size_t lds = ChoiLds<NQ>::bytes() + 16 + sizeof(cplx) * (2 * D * LD + (size_t)(K > 0 ? K : 1) * D);
+    if (lds > 160 * 1024) { set_error("fbx_convert: too many Kraus operators for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    auto kern = convert_kernel<NQ>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream(), from, to, (long long)B, in, K, out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused Kraus sweep (BASELINE config 3)
+// ---------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ void __launch_bounds__(64)
+sweep_kernel(long long B, int K, const double* __restrict__ kraus, const double* __restrict__ ptm_ref,
+             double* __restrict__ choi_out, double* __restrict__ ptm_out, double* __restrict__ chi_out,
+             double* __restrict__ fid_out) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* C = (cplx*)smem;                 // Choi
+    cplx* S = C + D * LD;                  // superop, then chi
+    cplx* P = S + D * LD;                  // Pauli-Liouville
+    cplx* R = P + D * LD;                  // reference PTM
+    cplx* kb = R + D * LD;
+    const int lane = threadIdx.x;
+    if (ptm_ref) load_matrix<NQ>(ptm_ref, R, lane);
+    const double inv_d = 1.0 / d;
+    for (long long item = blockIdx.x; item < B; item += gridDim.x) {
+        __syncthreads();
+        kraus_to<NQ>(kraus + item * (long long)K * D * 2, K, false, C, kb, lane);
+        __syncthreads();
+        if (choi_out) store_matrix<NQ>(C, choi_out + item * (long long)D * D * 2, lane);
+        reshuffle<NQ>(C, S, lane);
+        __syncthreads();
+        to_pauli_basis<NQ>(S, P, inv_d, lane);
+        __syncthreads();
+        if (ptm_out) store_matrix<NQ>(P, ptm_out + item * (long long)D * D * 2, lane);
+        if (fid_out && ptm_ref) {          // process_fidelity(ref, ptm): (d Fe + 1)/(d + 1), Fe = tr(ref^H ptm)/d^2
+            double acc = 0.0;
+            for (int idx = lane; idx < D * D; idx += 64) {
+                const cplx a = R[(idx / D) * LD + idx % D], b = P[(idx / D) * LD + idx % D];
+                acc += a.re * b.re + a.im * b.im;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) fid_out[item] = (d * (acc / (double)(d * d)) + 1.0) / (d + 1.0);
+        }
+        if (chi_out) {                      // a Kraus set is CP: chi = c2p Choi c2p^H (= kraus2chi)
+            to_pauli_basis<NQ>(C, S, inv_d * inv_d, lane);
+            __syncthreads();
+            store_matrix<NQ>(S, chi_out + item * (long long)D * D * 2, lane);
+        }
+    }
+}
+
+template <int NQ>
+static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi,
+                        double* ptm, double* chi, double* fid) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    const size_t lds = sizeof(cplx) * (4 * D * LD + (size_t)K * D);
+    if (lds > 160 * 1024) { set_error("fbx_kraus_sweep: too many Kraus operators"); return FBX_ERR_UNSUPPORTED; }
+    auto kern = sweep_kernel<NQ>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)(B < 256 * 8 ? B : 256 * 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream(), (long long)B, K, kraus, ptm_ref, choi, ptm, chi, fid);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fbx_proj_choi
+// ---------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ void __launch_bounds__(64)
+proj_choi_kernel(int kind, long long B, const double* __restrict__ in, double* __restrict__ out,
+                 int* __restrict__ iters_out) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* p = smem;
+    ChoiLds<NQ> L; L.carve(p);
+    PhaseClock pc; pc.reset(); L.pc = &pc;
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    load_matrix<NQ>(in + item * (long long)D * D * 2, L.Mw, lane);
+    __syncthreads();
+    const Blk x = blk_load<D, LD>(L.Mw, lane);
+    __syncthreads();
+    int iters = 0, sweeps = 0;
+    Blk y;
+    if (kind == FBX_PROJ_CP) y = proj_cp_blk<NQ>(x, L, lane, sweeps);
+    else if (kind == FBX_PROJ_TP) y = proj_tp_blk<NQ>(x, L, lane);
+    else if (kind == FBX_PROJ_TNI) y = proj_tni_blk<NQ>(x, L, lane, sweeps);
+    else y = proj_physical_blk<NQ>(x, kind == FBX_PROJ_PHYSICAL_TP, L, lane, iters, sweeps);
+    __syncthreads();
+    blk_store<D, LD>(L.Mw, lane, y);
+    __syncthreads();
+    store_matrix<NQ>(L.Mw, out + item * (long long)D * D * 2, lane);
+    if (lane == 0 && iters_out) iters_out[item] = iters;
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply_choi_matrix_2_state: out[o][o'] = sum_{i,i'} rho[i'][i] C[(i',o)][(i,o')]
+// ---------------------------------------------------------------------------------------------
+__global__ void apply_choi_kernel(int d, long long B, const double* __restrict__ choi,
+                                  const double* __restrict__ rho, double* __restrict__ out) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int dd = d * d, D = dd;
+    if (t >= B * dd) return;
+    const long long item = t / dd;
+    const int o = (int)(t % dd) / d, op = (int)(t % dd) % d;
+    const double* C = choi + item * (long long)D * D * 2;
+    const double* r = rho + item * (long long)dd * 2;
+    double re = 0.0, im = 0.0;
+    for (int ip = 0; ip < d; ++ip)
+        for (int i = 0; i < d; ++i) {
+            const double ar = r[2 * (ip * d + i)], ai = r[2 * (ip * d + i) + 1];
+            const long long ci = ((long long)(ip * d + o) * D + (i * d + op)) * 2;
+            const double br = C[ci], bi = C[ci + 1];
+            re += ar * br - ai * bi; im += ar * bi + ai * br;
+        }
+    out[t * 2] = re; out[t * 2 + 1] = im;
+}
+
+// ---------------------------------------------------------------------------------------------
+// entanglement / process fidelity: Fe = Re tr(A^H B) / d^2 ; Fp = (d Fe + 1) / (d + 1)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+process_fidelity_kernel(int d, long long B, const double* __restrict__ a, const double* __restrict__ b,
+                        double* __restrict__ fe_out, double* __restrict__ fp_out) {
+    const int lane = threadIdx.x;
+    const int DD = d * d * d * d;
+    for (long long item = blockIdx.x; item < B; item += gridDim.x) {
+        const double* pa = a + item * (long long)DD * 2;
+        const double* pb = b + item * (long long)DD * 2;
+        double acc = 0.0;
+        for (int idx = lane; idx < 2 * DD; idx += 64) acc += pa[idx] * pb[idx];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const double fe = acc / (double)(d * d);
+            if (fe_out) fe_out[item] = fe;
+            if (fp_out) fp_out[item] = (d * fe + 1.0) / (d + 1.0);
+        }
+    }
+}
+
+}  // namespace fbx
+
+using namespace fbx;
+
+namespace {
+struct HostIO {     // host <-> device staging for the host-pointer entry points
+    std::vector<DevBuf*> bufs;
+    ~HostIO() { for (auto* b : bufs) delete b; }
+    template <class T> int in(const T* host, size_t count, T** dev) {
+        auto* b = new DevBuf(); bufs.push_back(b);
+        int rc = b->alloc(sizeof(T) * count);
+        if (rc) return rc;
+        if (host && count) {
+            hipError_t e = hipMemcpyAsync(b->p, host, sizeof(T) * count, hipMemcpyHostToDevice, stream());
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(H2D)", __FILE__, __LINE__);
+        }
+        *dev = b->as<T>();
+        return FBX_OK;
+    }
+    template <class T> int out(size_t count, T** dev) {
+        auto* b = new DevBuf(); bufs.push_back(b);
+        int rc = b->alloc(sizeof(T) * count);
+        if (rc) return rc;
+        *dev = b->as<T>();
+        return FBX_OK;
+    }
+    template <class T> int back(T* host, const T* dev, size_t count) {
+        if (!host || !count) return FBX_OK;
+        hipError_t e = hipMemcpyAsync(host, dev, sizeof(T) * count, hipMemcpyDeviceToHost, stream());
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(D2H)", __FILE__, __LINE__);
+        return FBX_OK;
+    }
+    int sync() { FBX_HIP(hipStreamSynchronize(stream())); return FBX_OK; }
+};
+#define FBX_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+}  // namespace
+
+extern "C" {
+
+int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K, double* out) {
+    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_convert: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(from_rep >= FBX_REP_KRAUS && from_rep <= FBX_REP_CHI, "fbx_convert: bad source representation");
+    FBX_REQUIRE(to_rep >= FBX_REP_CHOI && to_rep <= FBX_REP_CHI, "fbx_convert: bad target representation (Kraus output is not offered)");
+    FBX_REQUIRE(from_rep != to_rep, "fbx_convert: source and target representation are the same");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (in && out)), "fbx_convert: bad batch / NULL buffer");
+    FBX_REQUIRE(from_rep != FBX_REP_KRAUS || K >= 1, "fbx_convert: need K >= 1 Kraus operators");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d;
+    const size_t n_in = (from_rep == FBX_REP_KRAUS ? (size_t)K * D : D * D) * 2 * B, n_out = D * D * 2 * B;
+    HostIO io; double *d_in, *d_out;
+    FBX_TRY(io.in(in, n_in, &d_in)); FBX_TRY(io.out(n_out, &d_out));
+    if (n_qubits == 1) FBX_TRY(launch_convert<1>(from_rep, to_rep, B, d_in, K, d_out));
+    else FBX_TRY(launch_convert<2>(from_rep, to_rep, B, d_in, K, d_out));
+    FBX_TRY(io.back(out, d_out, n_out));
+    return io.sync();
+}
+
+int fbx_kraus_sweep_dev(int n_qubits, int64_t B, int K, const double* d_kraus, const double* d_ptm_ref,
+                        double* d_choi_out, double* d_ptm_out, double* d_chi_out, double* d_fid_out) {
+    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_kraus_sweep: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(B >= 0 && K >= 1 && (B == 0 || d_kraus), "fbx_kraus_sweep: bad arguments");
+    FBX_REQUIRE(!d_fid_out || d_ptm_ref, "fbx_kraus_sweep: fidelity output needs a reference PTM");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    if (n_qubits == 1) return launch_sweep<1>(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
+    return launch_sweep<2>(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
+}
+
+int fbx_kraus_sweep(int n_qubits, int64_t B, int K, const double* kraus, const double* ptm_ref,
+                    double* choi_out, double* ptm_out, double* chi_out, double* fid_out) {
+    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_kraus_sweep: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(B >= 0 && K >= 1 && (B == 0 || kraus), "fbx_kraus_sweep: bad arguments");
+    FBX_REQUIRE(!fid_out || ptm_ref, "fbx_kraus_sweep: fidelity output needs a reference PTM");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d, nm = D * D * 2 * B;
+    HostIO io; double *dk, *dr = nullptr, *dc = nullptr, *dp = nullptr, *dx = nullptr, *df = nullptr;
+    FBX_TRY(io.in(kraus, (size_t)K * D * 2 * B, &dk));
+    if (ptm_ref) FBX_TRY(io.in(ptm_ref, D * D * 2, &dr));
+    if (choi_out) FBX_TRY(io.out(nm, &dc));
+    if (ptm_out) FBX_TRY(io.out(nm, &dp));
+    if (chi_out) FBX_TRY(io.out(nm, &dx));
+    if (fid_out) FBX_TRY(io.out((size_t)B, &df));
+    FBX_TRY(fbx_kraus_sweep_dev(n_qubits, B, K, dk, dr, dc, dp, dx, df));
+    FBX_TRY(io.back(choi_out, dc, nm)); FBX_TRY(io.back(ptm_out, dp, nm)); FBX_TRY(io.back(chi_out, dx, nm));
+    FBX_TRY(io.back(fid_out, df, (size_t)B));
+    return io.sync();
+}
+
+int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, double* out, int32_t* iters_out) {
+    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_proj_choi: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(proj_kind >= FBX_PROJ_CP && proj_kind <= FBX_PROJ_PHYSICAL_TNI, "fbx_proj_choi: bad projection kind");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (choi && out)), "fbx_proj_choi: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d, nm = D * D * 2 * B;
+    HostIO io; double *d_in, *d_out; int32_t* d_it;
+    FBX_TRY(io.in(choi, nm, &d_in)); FBX_TRY(io.out(nm, &d_out)); FBX_TRY(io.out((size_t)B, &d_it));
+    if (n_qubits == 1) {
+        const size_t lds = ChoiLds<1>::bytes() + 64;
+        hipLaunchKernelGGL(proj_choi_kernel<1>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_in, d_out, d_it);
+    } else {
+        const size_t lds = ChoiLds<2>::bytes() + 64;
+        hipLaunchKernelGGL(proj_choi_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_in, d_out, d_it);
+    }
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(out, d_out, nm)); FBX_TRY(io.back(iters_out, d_it, (size_t)B));
+    return io.sync();
+}
+
+int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rho, double* out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_apply_choi: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (choi && rho && out)), "fbx_apply_choi: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d;
+    HostIO io; double *dc, *dr, *dout;
+    FBX_TRY(io.in(choi, D * D * 2 * B, &dc)); FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.out(D * 2 * B, &dout));
+    const long long total = (long long)B * D;
+    hipLaunchKernelGGL(apply_choi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(), (int)d, (long long)B, dc, dr, dout);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(out, dout, D * 2 * B));
+    return io.sync();
+}
+
+int fbx_process_fidelity(int n_qubits, int64_t B, const double* ptm0, const double* ptm1, double* fe_out, double* fp_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_process_fidelity: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (ptm0 && ptm1)), "fbx_process_fidelity: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d, nm = D * D * 2 * B;
+    HostIO io; double *da, *db, *dfe, *dfp;
+    FBX_TRY(io.in(ptm0, nm, &da)); FBX_TRY(io.in(ptm1, nm, &db));
+    FBX_TRY(io.out((size_t)B, &dfe)); FBX_TRY(io.out((size_t)B, &dfp));
+    const unsigned grid = (unsigned)(B < 8192 ? B : 8192);
+    hipLaunchKernelGGL(process_fidelity_kernel, dim3(grid), dim3(64), 0, stream(), (int)d, (long long)B, da, db, dfe, dfp);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(fe_out, dfe, (size_t)B)); FBX_TRY(io.back(fp_out, dfp, (size_t)B));
+    return io.sync();
+}
+
+}  // extern "C"

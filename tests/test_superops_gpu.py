@@ -1,0 +1,129 @@
+"""HIP superoperator tools vs the golden vectors produced by the reference (tests/golden)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-12
+
+
+def gold(n):
+    return np.load(os.path.join(GOLD, f"superops_{n}q.npz"))
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_kraus_conversions(gpu, n):
+    from fbx.operator_tools import convert_batch
+    g = gold(n)
+    for K in (1, 2, 4):
+        ks = g[f"kraus{K}"]
+        for dst, key in (("choi", "choi"), ("superop", "superop"), ("pauli_liouville", "ptm"), ("chi", "chi")):
+            got = convert_batch("kraus", dst, ks)
+            assert np.abs(got - g[f"kraus{K}_{key}"]).max() < TOL, (K, dst)
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_pairwise_conversions(gpu, n):
+    from fbx.operator_tools import convert_batch
+    g = gold(n)
+    cases = [("choi", "chi", "kraus4_choi", "choi2chi"), ("choi", "superop", "kraus4_choi", "choi2superop"),
+             ("choi", "pauli_liouville", "kraus4_choi", "choi2ptm"),
+             ("chi", "choi", "kraus4_chi", "chi2choi"), ("chi", "pauli_liouville", "kraus4_chi", "chi2ptm"),
+             ("chi", "superop", "kraus4_chi", "chi2superop"),
+             ("superop", "choi", "kraus4_superop", "superop2choi"),
+             ("superop", "pauli_liouville", "kraus4_superop", "superop2ptm"),
+             ("superop", "chi", "kraus4_superop", "superop2chi"),
+             ("pauli_liouville", "choi", "kraus4_ptm", "ptm2choi"),
+             ("pauli_liouville", "superop", "kraus4_ptm", "ptm2superop"),
+             ("pauli_liouville", "chi", "kraus4_ptm", "ptm2chi")]
+    for src, dst, kin, kout in cases:
+        got = convert_batch(src, dst, g[kin])
+        assert np.abs(got - g[kout]).max() < 1e-11, (src, dst)
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_choi2chi_non_cp_goes_through_abs(gpu, n):
+    """Reference quirk: choi2chi of a non-CP matrix is the chi form of |C|."""
+    from fbx.operator_tools import convert_batch
+    g = gold(n)
+    got = convert_batch("choi", "chi", g["herm"])
+    assert np.abs(got - g["herm_choi2chi"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_projections(gpu, n):
+    from fbx import _lib
+    from fbx.operator_tools.project_superoperators import proj_choi_batch
+    g = gold(n)
+    for name in ("gen", "near"):
+        x = g[f"proj_{name}_in"]
+        assert np.abs(proj_choi_batch(_lib.PROJ_CP, x) - g[f"proj_{name}_cp"]).max() < 1e-11
+        assert np.abs(proj_choi_batch(_lib.PROJ_TP, x) - g[f"proj_{name}_tp"]).max() < 1e-12
+        assert np.abs(proj_choi_batch(_lib.PROJ_TNI, x) - g[f"proj_{name}_tni"]).max() < 1e-11
+    x = g["proj_near_in"]
+    assert np.abs(proj_choi_batch(_lib.PROJ_PHYSICAL_TP, x) - g["proj_near_phys_tp"]).max() < 1e-10
+    assert np.abs(proj_choi_batch(_lib.PROJ_PHYSICAL_TNI, x) - g["proj_near_phys_tni"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_dykstra_iteration_counts_match_oracle(gpu, n):
+    from fbx import _lib
+    from fbx.operator_tools.project_superoperators import proj_choi_batch
+    from fbx_oracle import superops as so
+    g = gold(n)
+    x = g["proj_near_in"]
+    _, iters = proj_choi_batch(_lib.PROJ_PHYSICAL_TP, x, return_iters=True)
+    want = [so.proj_choi_to_physical(v, True, return_iters=True)[1] for v in x]
+    assert list(iters) == want
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_process_fidelity_and_apply(gpu, n):
+    from fbx import distance_measures as dm
+    from fbx.operator_tools import apply_choi_matrix_2_state_batch
+    g = gold(n)
+    fp = dm.process_fidelity_batch(g["ptm_ref"][None], g["kraus4_ptm"])
+    fe = dm.process_fidelity_batch(g["ptm_ref"][None], g["kraus4_ptm"], entanglement=True)
+    assert np.abs(fp - g["proc_fid"]).max() < 1e-13
+    assert np.abs(fe - g["ent_fid"]).max() < 1e-13
+    out = apply_choi_matrix_2_state_batch(g["kraus4_choi"], g["rho"])
+    assert np.abs(out - g["apply_choi"]).max() < 1e-13
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_kraus_sweep_fused(gpu, n):
+    """BASELINE config 3 pipeline: kraus -> choi -> PTM -> chi + process_fidelity, one kernel."""
+    import ctypes
+    from fbx import _lib
+    g = gold(n)
+    ks = np.ascontiguousarray(g["kraus4"])
+    B, D = ks.shape[0], 4 ** n
+    ref = np.ascontiguousarray(g["ptm_ref"], dtype=np.complex128)
+    choi = np.empty((B, D, D), complex); ptm = np.empty_like(choi); chi = np.empty_like(choi)
+    fid = np.empty(B)
+    _lib.check(_lib.lib().fbx_kraus_sweep(n, B, 4, _lib.dptr(ks.view(np.float64)), _lib.dptr(ref.view(np.float64)),
+                                          _lib.dptr(choi.view(np.float64)), _lib.dptr(ptm.view(np.float64)),
+                                          _lib.dptr(chi.view(np.float64)), _lib.dptr(fid)))
+    assert np.abs(choi - g["kraus4_choi"]).max() < TOL
+    assert np.abs(ptm - g["kraus4_ptm"]).max() < TOL
+    assert np.abs(chi - g["choi2chi"]).max() < 1e-11        # reference's eigh route, CP input
+    assert np.abs(fid - g["proc_fid"]).max() < 1e-13
+
+
+def test_reference_signature_wrappers(gpu):
+    """Same names / call shapes as forest.benchmarking.operator_tools on single matrices."""
+    from fbx import operator_tools as ot
+    g = gold(1)
+    ks = list(g["kraus2"][0])
+    assert np.abs(ot.kraus2choi(ks) - g["kraus2_choi"][0]).max() < TOL
+    assert np.abs(ot.kraus2choi(ks[0]) - ot.kraus2choi([ks[0]])).max() == 0      # single-ndarray form
+    choi = g["kraus4_choi"][0]
+    assert np.abs(ot.choi2pauli_liouville(choi) - g["choi2ptm"][0]).max() < 1e-12
+    assert np.abs(ot.proj_choi_to_physical(g["proj_near_in"][0]) - g["proj_near_phys_tp"][0]).max() < 1e-10
+    p2c = ot.pauli2computational_basis_matrix(2)
+    want = np.array([[1, 0, 0, 1], [0, 1, 1j, 0], [0, 1, -1j, 0], [1, 0, 0, -1]])
+    assert np.abs(p2c - want).max() < 1e-15
+    with pytest.raises(ValueError):
+        ot.convert_batch("choi", "chi", np.zeros((1, 3, 3)))
