@@ -49,6 +49,11 @@ struct DesignDev {
     const double* coef;      // [m] (grouped)
     const int* sptr;         // [S+1] grouped ranges per distinct input state
     const double* C;         // [D][S] Bloch coefficients c_j(s) = tr(P_j rho_s)
+    // linear inversion of process designs: settings grouped by observable, and the rows of the
+    // block pseudo-inverses (data independent; replaces pinv of tomography.py:482-488)
+    const int* porder;       // [m] position grouped by Pauli index -> caller's setting index
+    const int* pptr;         // [D+1]
+    const double* pinvT;     // [m][D]: R[i][:] = sum_{g in group i} e[porder[g]] * pinvT[g][:]
 };
 
 }  // namespace fbx
@@ -56,6 +61,7 @@ struct DesignDev {
 struct fbx_design {
     fbx::DesignDev dev;
     void* slab = nullptr;    // one device allocation backing every pointer in dev
+    void* slab2 = nullptr;   // linear-inversion tables (process designs)
     std::vector<double> C_host;
     std::vector<int> order_host;
     std::vector<uint32_t> sp_host;

@@ -167,6 +167,41 @@ static void bloch_of_state(int code, double r[4]) {
     r[3] = (r00 - r11).real();
 }
 
+// Cyclic Jacobi eigensolver for a small real symmetric matrix (host side, design constants only).
+static void host_sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::vector<double>& v) {
+    v.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, nrm = 0.0;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+            nrm += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+            if (i != j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+        }
+        if (off <= 1e-30 * nrm) break;
+        for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
+            const double apq = a[(size_t)p * n + q];
+            if (std::fabs(apq) < 1e-300) continue;
+            const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < n; ++k) {
+                const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+                a[(size_t)k * n + p] = c * akp - sn * akq; a[(size_t)k * n + q] = sn * akp + c * akq;
+            }
+            for (int k = 0; k < n; ++k) {
+                const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+                a[(size_t)p * n + k] = c * apk - sn * aqk; a[(size_t)q * n + k] = sn * apk + c * aqk;
+            }
+            for (int k = 0; k < n; ++k) {
+                const double vkp = v[(size_t)k * n + p], vkq = v[(size_t)k * n + q];
+                v[(size_t)k * n + p] = c * vkp - sn * vkq; v[(size_t)k * n + q] = sn * vkp + c * vkq;
+            }
+        }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = a[(size_t)i * n + i];
+}
+
 int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
                       const uint8_t* paulis, const double* coefs, fbx_design** out) {
     FBX_REQUIRE(out != nullptr, "fbx_design_create: NULL out");
@@ -270,6 +305,88 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
     des->dev.order = (const int*)(base + oOrder);
     des->dev.sp = (const uint32_t*)(base + oSp);
     des->dev.sptr = (const int*)(base + oPtr);
+    des->dev.porder = nullptr; des->dev.pptr = nullptr; des->dev.pinvT = nullptr;
+
+    if (kind == FBX_KIND_PROCESS) {
+        // ---- linear-inversion tables.  In the orthonormal operator basis {P_j^T (x) P_i / d} the
+        // measurement matrix of tomography.py:482-486 is block diagonal over the observable index i
+        // with blocks Abar_i[k][j] = coef_k * c_j(s_k); its pseudo-inverse is the block-wise one.
+        std::vector<int> porder(m), pptr(D + 1, 0);
+        for (int k = 0; k < m; ++k) porder[k] = k;
+        std::stable_sort(porder.begin(), porder.end(), [&](int a, int b) { return pidx[a] < pidx[b]; });
+        for (int k = 0; k < m; ++k) pptr[pidx[k] + 1]++;
+        for (int i = 0; i < D; ++i) pptr[i + 1] += pptr[i];
+        std::vector<double> pinvT((size_t)m * D, 0.0);
+        struct Block { std::vector<double> w, v; };
+        std::map<std::vector<double>, int> cache;          // signature -> first group with it
+        std::vector<Block> blocks(D);
+        std::vector<int> alias(D, -1);
+        double smax2 = 0.0;
+        for (int i = 0; i < D; ++i) {
+            const int g0 = pptr[i], g1 = pptr[i + 1];
+            if (g0 == g1) continue;
+            std::vector<double> sig;
+            for (int g = g0; g < g1; ++g) { sig.push_back(sidx[porder[g]]); sig.push_back(coefs ? coefs[porder[g]] : 1.0); }
+            auto it = cache.find(sig);
+            if (it != cache.end()) { alias[i] = it->second; continue; }
+            cache[sig] = i; alias[i] = i;
+            std::vector<double> gram((size_t)D * D, 0.0);
+            for (int g = g0; g < g1; ++g) {
+                const int k = porder[g]; const double ck = coefs ? coefs[k] : 1.0;
+                for (int a = 0; a < D; ++a) {
+                    const double ra = ck * des->C_host[(size_t)a * S + sidx[k]];
+                    if (ra == 0.0) continue;
+                    for (int b = 0; b < D; ++b) gram[(size_t)a * D + b] += ra * ck * des->C_host[(size_t)b * S + sidx[k]];
+                }
+            }
+            host_sym_eig(gram, D, blocks[i].w, blocks[i].v);
+            for (double l : blocks[i].w) smax2 = std::max(smax2, l);
+        }
+        // scipy.linalg.pinv cut-off: singular values <= max(M, N) * eps * sigma_max are dropped
+        const double rt = (double)std::max(m, D * D) * 2.220446049250313e-16;
+        const double cut2 = rt * rt * smax2;
+        for (int i = 0; i < D; ++i) {
+            const int g0 = pptr[i], g1 = pptr[i + 1];
+            if (g0 == g1) continue;
+            const Block& bl = blocks[alias[i]];
+            // G^+ = V diag(1/lambda) V^T ; pinv(Abar) = G^+ Abar^T  ->  column of setting k
+            std::vector<double> gp((size_t)D * D, 0.0);
+            for (int e = 0; e < D; ++e) {
+                if (!(bl.w[e] > cut2)) continue;
+                const double il = 1.0 / bl.w[e];
+                for (int a = 0; a < D; ++a) {
+                    const double va = bl.v[(size_t)a * D + e] * il;
+                    if (va == 0.0) continue;
+                    for (int b = 0; b < D; ++b) gp[(size_t)a * D + b] += va * bl.v[(size_t)b * D + e];
+                }
+            }
+            for (int g = g0; g < g1; ++g) {
+                const int k = porder[g]; const double ck = coefs ? coefs[k] : 1.0;
+                for (int a = 0; a < D; ++a) {
+                    double acc = 0.0;
+                    for (int b = 0; b < D; ++b) acc += gp[(size_t)a * D + b] * ck * des->C_host[(size_t)b * S + sidx[k]];
+                    pinvT[(size_t)g * D + a] = acc;
+                }
+            }
+        }
+        size_t oPo = 0, oPp = oPo + sizeof(int) * m, oPi = (oPp + sizeof(int) * (D + 1) + 15) & ~(size_t)15;
+        size_t total2 = oPi + sizeof(double) * (size_t)m * D;
+        std::vector<char> host2(total2);
+        memcpy(&host2[oPo], porder.data(), sizeof(int) * m);
+        memcpy(&host2[oPp], pptr.data(), sizeof(int) * (D + 1));
+        memcpy(&host2[oPi], pinvT.data(), sizeof(double) * (size_t)m * D);
+        e = hipMalloc(&des->slab2, total2);
+        if (e == hipSuccess) e = hipMemcpy(des->slab2, host2.data(), total2, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (des->slab2) (void)hipFree(des->slab2);
+            (void)hipFree(des->slab); delete des;
+            return hip_fail(e, "hipMalloc/hipMemcpy(design linear-inversion tables)", __FILE__, __LINE__);
+        }
+        char* b2 = (char*)des->slab2;
+        des->dev.porder = (const int*)(b2 + oPo);
+        des->dev.pptr = (const int*)(b2 + oPp);
+        des->dev.pinvT = (const double*)(b2 + oPi);
+    }
     *out = des;
     return FBX_OK;
 }
@@ -277,6 +394,7 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
 int fbx_design_destroy(fbx_design* design) {
     if (!design) return FBX_OK;
     if (design->slab) (void)hipFree(design->slab);
+    if (design->slab2) (void)hipFree(design->slab2);
     delete design;
     return FBX_OK;
 }

@@ -377,6 +377,37 @@ process_fidelity_kernel(int d, long long B, const double* __restrict__ a, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// linear_inv_process_estimate (tomography.py:459-491): R[i][:] = pinv(Abar_i) e_i, Choi by the
+// inverse Pauli transform, plus the explicit identity term I_D / d (tomography.py:491)
+// ---------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ void __launch_bounds__(64)
+linv_process_kernel(DesignDev des, long long B, const double* __restrict__ expect, double* __restrict__ out) {
+    constexpr int d = 1 << NQ, D = d * d, NB = D / 2;
+    __shared__ double Rb[D * D];
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int i = idx / D, j = idx % D;
+        double acc = 0.0;
+        for (int g = des.pptr[i]; g < des.pptr[i + 1]; ++g)
+            acc += expect[item * des.m + des.porder[g]] * des.pinvT[(size_t)g * D + j];
+        Rb[idx] = acc + ((idx == 0) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    const Blk c = pauli_real_to_choi_blk<NQ>(Rb, lane);
+    if (lane < NB * NB) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+            double* o = out + ((item * D + row) * D + col) * 2;
+            o[0] = c.re[e]; o[1] = c.im[e];
+        }
+    }
+}
+
 }  // namespace fbx
 
 using namespace fbx;
@@ -415,6 +446,24 @@ struct HostIO {     // host <-> device staging for the host-pointer entry points
 }  // namespace
 
 extern "C" {
+
+int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect, double* choi_out) {
+    FBX_REQUIRE(design != nullptr, "fbx_linv_process: NULL design");
+    FBX_REQUIRE(design->dev.kind == FBX_KIND_PROCESS, "fbx_linv_process: needs a process design");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (expect && choi_out)), "fbx_linv_process: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n;
+    if (n > 2) { set_error("fbx_linv_process: this build handles 1 and 2 qubits"); return FBX_ERR_UNSUPPORTED; }
+    const size_t m = design->dev.m, D = design->dev.D;
+    HostIO io; double *de, *dout;
+    FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.out(D * D * 2 * B, &dout));
+    if (n == 1) hipLaunchKernelGGL(linv_process_kernel<1>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, de, dout);
+    else hipLaunchKernelGGL(linv_process_kernel<2>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, de, dout);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(choi_out, dout, D * D * 2 * B));
+    return io.sync();
+}
 
 int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K, double* out) {
     FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_convert: this build handles 1 and 2 qubits");

@@ -1,0 +1,69 @@
+"""Host-side logic of the shim: designs, result flattening, synthetic data, sharding (CPU)."""
+import numpy as np
+import pytest
+
+
+def test_canonical_designs_sizes_and_order():
+    from fbx.design import process_design, state_design, traceless_pauli_codes
+    assert [state_design(n).m for n in (1, 2, 3)] == [3, 15, 63]
+    assert [process_design(n, "pauli").m for n in (1, 2)] == [18, 540]
+    assert [process_design(n, "sic").m for n in (1, 2)] == [12, 240]
+    p = traceless_pauli_codes(2)
+    assert p[0].tolist() == [0, 1] and p[3].tolist() == [1, 0] and p[-1].tolist() == [3, 3]
+    d = process_design(2, "pauli")
+    assert d.in_labels[0].tolist() == [0, 0] and d.in_labels[15].tolist() == [0, 1]   # X+X+ then X+X-
+    with pytest.raises(ValueError):
+        process_design(1, "nope")
+
+
+def test_flatten_results_matches_oracle_flattening():
+    from fbx import tomography as T
+    from fbx.design import flatten_results
+    from fbx.observable_estimation import ExperimentResult
+    from fbx_oracle import design as od
+    qubits = [4, 1]
+    settings = T.generate_process_tomography_settings(qubits, "sic")
+    rs = np.random.RandomState(0)
+    res = [ExperimentResult(s, rs.uniform(-1, 1), int(rs.randint(10, 99))) for s in settings]
+    d, e, c = flatten_results(res, qubits, "process")
+    o, oe_, oc = od.flatten_results(res, qubits, "process")
+    assert (d.in_labels == o.in_labels).all() and (d.paulis == o.paulis).all()
+    assert np.array_equal(e, oe_) and np.array_equal(c, oc)
+    assert (d.in_labels == od.process_design(2, "sic").in_labels).all()
+    d2, _, _ = flatten_results(res, qubits, "process")
+    assert d2 is d                                   # cached by content
+
+
+def test_setting_string_round_trip():
+    from fbx.observable_estimation import ExperimentSetting, TensorProductState
+    s = ExperimentSetting.from_str("X+_0 * Z-_1→(1+0j)*X0Z1")
+    assert str(s.in_state) == "X+_0 * Z-_1" and s.observable[0] == "X" and s.observable[1] == "Z"
+    assert s.observable[7] == "I"
+    assert str(TensorProductState.from_str("SIC2_3")) == "SIC2_3"
+
+
+def test_synthetic_expectations_are_exact_for_known_channels():
+    from fbx import synthetic
+    from fbx.design import process_design
+    d = process_design(1, "pauli")
+    e = synthetic.exact_process_expectations(d, np.eye(2)[None])
+    # identity channel: <P> on the +-1 eigenstate of P is +-1, other Paulis 0
+    want = []
+    for s in range(6):
+        for p in (1, 2, 3):
+            axis = s // 2 + 1
+            want.append((1 - 2 * (s % 2)) if axis == p else 0)
+    assert np.allclose(e[0], want)
+    ks = synthetic.kraus_batch(2, 4, 3)
+    assert np.allclose(np.einsum("bkji,bkjl->bil", ks.conj(), ks), np.eye(4))
+
+
+def test_shard_bounds_cover_everything_once():
+    from fbx.parallel import shard_bounds
+    for n in (0, 1, 7, 1024, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)

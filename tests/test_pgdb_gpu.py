@@ -70,3 +70,116 @@ def test_pgdb_trace_non_increasing(gpu):
     got = tomography.pgdb_process_estimate_batch(design, e, c, trace_preserving=False)
     want, _ = _oracle_pgdb(design, e, c, trace_preserving=False)
     assert np.abs(got - want).max() < CHOI_TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# against the golden vectors produced by running the reference itself (tests/golden/make_goldens.py)
+# ------------------------------------------------------------------------------------------------
+import os
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gold(n, basis):
+    return np.load(os.path.join(GOLD, f"process_{n}q_{basis}.npz"))
+
+
+@pytest.mark.parametrize("n,basis", [(1, "pauli"), (1, "sic"), (2, "sic"), (2, "pauli")])
+def test_pgdb_matches_reference_goldens(gpu, n, basis):
+    from fbx import tomography
+    from fbx.design import process_design
+    g = _gold(n, basis)
+    design = process_design(n, basis)
+    assert (design.in_labels == g["in_labels"]).all() and (design.paulis == g["paulis"]).all()
+    got = tomography.pgdb_process_estimate_batch(design, g["expectations"], g["counts"])
+    assert np.abs(got - g["pgdb"]).max() < CHOI_TOL
+    k = g["pgdb_tni"].shape[0]
+    got = tomography.pgdb_process_estimate_batch(design, g["expectations"][:k], g["counts"][:k],
+                                                 trace_preserving=False)
+    assert np.abs(got - g["pgdb_tni"]).max() < CHOI_TOL
+
+
+@pytest.mark.parametrize("n,basis", [(1, "pauli"), (1, "sic"), (2, "sic"), (2, "pauli")])
+def test_linear_inversion_process_matches_reference_goldens(gpu, n, basis):
+    from fbx import tomography
+    from fbx.design import process_design
+    g = _gold(n, basis)
+    got = tomography.linear_inv_process_estimate_batch(process_design(n, basis), g["expectations"])
+    assert np.abs(got - g["linv"]).max() < 1e-12
+
+
+def test_reference_signature_on_result_lists(gpu):
+    """pgdb_process_estimate(results, qubits) with the reference's argument shapes; also a
+    shuffled and a duplicated result list (general designs go through the same kernel)."""
+    from fbx import tomography as T
+    from fbx.observable_estimation import ExperimentResult
+    from fbx_oracle import design as od, estimators as oe
+    g = _gold(1, "pauli")
+    qubits = [0]
+    settings = T.generate_process_tomography_settings(qubits, "pauli")
+    res = [ExperimentResult(s, float(g["expectations"][0][k]), int(g["counts"][0][k]))
+           for k, s in enumerate(settings)]
+    np.testing.assert_allclose(T.pgdb_process_estimate(res, qubits), g["pgdb"][0], atol=CHOI_TOL)
+    np.testing.assert_allclose(T.linear_inv_process_estimate(res, qubits), g["linv"][0], atol=1e-12)
+    rs = np.random.RandomState(3)
+    perm = rs.permutation(len(res))
+    shuffled = [res[i] for i in perm] + [res[2], res[5]]          # reordered + two repeats
+    d, e, c = od.flatten_results(shuffled, qubits, "process")
+    want = oe.pgdb_process_estimate(d, e, c)
+    np.testing.assert_allclose(T.pgdb_process_estimate(shuffled, qubits), want, atol=CHOI_TOL)
+    want = oe.linear_inv_process_estimate(d, e)
+    np.testing.assert_allclose(T.linear_inv_process_estimate(shuffled, qubits), want, atol=1e-11)
+    with pytest.raises(ValueError):
+        T.generate_process_tomography_settings(qubits, "bogus")
+
+
+def test_two_qubit_order_convention(gpu):
+    """qubits[0] is the left-most tensor factor (tomography.py:149-158): estimating with the
+    qubit list reversed permutes the tensor factors of the Choi matrix."""
+    from fbx import tomography as T
+    from fbx.observable_estimation import ExperimentResult
+    g = _gold(2, "sic")
+    settings = T.generate_process_tomography_settings([0, 1], "sic")
+    res = [ExperimentResult(s, float(g["expectations"][0][k]), int(g["counts"][0][k]))
+           for k, s in enumerate(settings)]
+    a = T.linear_inv_process_estimate(res, [0, 1])
+    b = T.linear_inv_process_estimate(res, [1, 0])
+    np.testing.assert_allclose(a, g["linv"][0], atol=1e-12)
+    swap = np.eye(4)[[0, 2, 1, 3]]
+    perm = np.kron(swap, swap)
+    np.testing.assert_allclose(perm @ a @ perm.T, b, atol=1e-12)
+
+
+def test_full_size_batch_properties(gpu):
+    """BASELINE config 2 size (1024 x 2 qubits, 100 fixed iterations): size-independent checks --
+    every estimate is Hermitian and trace preserving to rounding, its cost is not above the
+    cost of the initial point, repeated items give bit-identical answers, and the batch split
+    (first/second half) reproduces the whole."""
+    from fbx import synthetic, tomography
+    design, us, e, c = synthetic.process_batch(2, "pauli", 256)
+    e = np.tile(e, (4, 1)); c = np.tile(c, (4, 1))
+    got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=100, return_stats=True)
+    assert (st["iterations"] == 100).all()
+    assert np.abs(got - got.conj().transpose(0, 2, 1)).max() < 1e-12
+    pt = np.einsum("biojo->bij", got.reshape(-1, 4, 4, 4, 4))
+    assert np.abs(pt - np.eye(4)).max() < 1e-12
+    assert np.array_equal(got[:256], got[256:512]) and np.array_equal(got[:256], got[768:])
+    half = tomography.pgdb_process_estimate_batch(design, e[:512], c[:512], mode="fixed", max_iters=100)
+    assert np.array_equal(half, got[:512])
+    from fbx_oracle import superops as so, measures as om
+    fids = [om.process_fidelity(so.kraus2pauli_liouville(us[b]), so.choi2pauli_liouville(got[b])) for b in range(16)]
+    assert min(fids) > 0.9
+
+
+def test_bad_arguments_and_empty_batch(gpu):
+    from fbx import tomography
+    from fbx.design import process_design, state_design
+    d = process_design(1, "pauli")
+    out = tomography.pgdb_process_estimate_batch(d, np.zeros((0, d.m)), np.zeros((0, d.m)))
+    assert out.shape == (0, 4, 4)
+    with pytest.raises(ValueError):
+        tomography.pgdb_process_estimate_batch(d, np.zeros((2, d.m + 1)), np.zeros((2, d.m + 1)))
+    with pytest.raises(ValueError):
+        tomography.pgdb_process_estimate_batch(d, np.zeros((1, d.m)), np.ones((1, d.m)), mode="nope")
+    with pytest.raises(ValueError):      # a state design is not a process design
+        tomography.pgdb_process_estimate_batch(state_design(1), np.zeros((1, 3)), np.ones((1, 3)))
