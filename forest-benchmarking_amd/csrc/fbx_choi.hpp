@@ -11,6 +11,10 @@
 #pragma once
 #include "fbx_eigh.hpp"
 
+#ifndef FBX_WARM_START
+#define FBX_WARM_START 1     // reuse the previous eigenvectors inside one Dykstra run (reset per run)
+#endif
+
 namespace fbx {
 
 // LDS work area shared by the routines below (carved by the kernel)
@@ -45,7 +49,7 @@ struct ChoiLds {
 // project_superoperators.py:19-34.  `x` need not be Hermitian.  `sweeps` accumulates Jacobi
 // sweeps (diagnostics).
 template <int NQ>
-__device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps) {
+__device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, bool warm = false) {
     constexpr int D = ChoiLds<NQ>::D;
     __syncthreads();                       // previous readers of Ms / Vs are done
     sys_store<D>(L.Ms, lane, x);
@@ -58,7 +62,10 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps) 
     sys_store<D>(L.Ms, lane, h);
     __syncthreads();
     PH_STOP(*L.pc, 2);
-    sweeps += jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane);
+    // warm start: the eigenvectors of the previous projection (still in Vs) nearly diagonalise
+    // this matrix, because consecutive Dykstra iterates are close
+    if (warm) jacobi_rotate_into_basis<D>(L.Ms, L.Vs, (cplx*)L.Mw, lane);
+    sweeps += jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane, !warm);
     PH_STOP(*L.pc, 0);
     if (lane < D) {
         const double l = L.Ms[sys_index<D>(lane, lane)].re;
@@ -159,7 +166,7 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
     for (int it = 0; it < max_iter; ++it) {
         ++iters;
         const Blk pre_cp = blk_sub(last_state, old_cp);
-        const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps);
+        const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, FBX_WARM_START && it > 0);
         const Blk new_cp = blk_sub(cp, pre_cp);
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = trace_preserving ? proj_tp_blk<NQ>(pre_tp, L, lane)

@@ -239,7 +239,7 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 //
 // Simple form (any even N <= 16): every lane derives its two rotations from the pivots in LDS.
 template <int N>
-__device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane) {
+__device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true) {
     constexpr int NB = N / 2, LS = NB * NB;
     static_assert(LS <= 64, "one wavefront per matrix");
     const bool act = lane < LS;
@@ -253,7 +253,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane) {
         wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
     }
     const int dI = I * NB + I, dJ = J * NB + J;            // lanes owning the pivot blocks
-    if (act) {
+    if (act && init_identity) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cplx v; v.re = (2 * I + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; v.im = 0.0;
@@ -394,13 +394,64 @@ __device__ int jacobi_eigh_pipelined(cplx* Ms, cplx* Vs, JRec* rec, int lane) {
     return sweep;
 }
 
+// Warm start: replace the matrix in Ms by V^H Ms V for the (unitary) V already in Vs, so that the
+// sweeps start from a nearly diagonal matrix when V diagonalises a nearby matrix.  `Ts` is 4*LS
+// cplx of scratch.  All three arrays use the element-major block layout.
 template <int N>
-__device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, int lane) {
+__device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int lane) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    const bool act = lane < LS;
+    const int I = act ? lane / NB : 0, J = act ? lane % NB : 0, me = act ? lane : 0;
+    cplx t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { t[e].re = 0.0; t[e].im = 0.0; }
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int ke = 0; ke < 2; ++ke) {
+            const cplx h0 = Ms[(0 + ke) * LS + I * NB + kb], h1 = Ms[(2 + ke) * LS + I * NB + kb];   // H[2I+a][k]
+            const cplx v0 = Vs[(ke * 2 + 0) * LS + kb * NB + J], v1 = Vs[(ke * 2 + 1) * LS + kb * NB + J]; // V[k][2J+b]
+            t[0].re += h0.re * v0.re - h0.im * v0.im; t[0].im += h0.re * v0.im + h0.im * v0.re;
+            t[1].re += h0.re * v1.re - h0.im * v1.im; t[1].im += h0.re * v1.im + h0.im * v1.re;
+            t[2].re += h1.re * v0.re - h1.im * v0.im; t[2].im += h1.re * v0.im + h1.im * v0.re;
+            t[3].re += h1.re * v1.re - h1.im * v1.im; t[3].im += h1.re * v1.im + h1.im * v1.re;
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ts[e * LS + me] = t[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { t[e].re = 0.0; t[e].im = 0.0; }
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int ke = 0; ke < 2; ++ke) {
+            const cplx u0 = Vs[(ke * 2 + 0) * LS + kb * NB + I], u1 = Vs[(ke * 2 + 1) * LS + kb * NB + I]; // V[k][2I+a]
+            const cplx w0 = Ts[(ke * 2 + 0) * LS + kb * NB + J], w1 = Ts[(ke * 2 + 1) * LS + kb * NB + J]; // T[k][2J+b]
+            // conj(u) * w
+            t[0].re += u0.re * w0.re + u0.im * w0.im; t[0].im += u0.re * w0.im - u0.im * w0.re;
+            t[1].re += u0.re * w1.re + u0.im * w1.im; t[1].im += u0.re * w1.im - u0.im * w1.re;
+            t[2].re += u1.re * w0.re + u1.im * w0.im; t[2].im += u1.re * w0.im - u1.im * w0.re;
+            t[3].re += u1.re * w1.re + u1.im * w1.im; t[3].im += u1.re * w1.im - u1.im * w1.re;
+        }
+    }
+    __syncthreads();
+    if (act) {
+        if (I == J) { t[0].im = 0.0; t[3].im = 0.0; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ms[e * LS + me] = t[e];
+    }
+    __syncthreads();
+}
+
+template <int N>
+__device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, int lane,
+                                               bool init_identity = true) {
 #ifdef FBX_JACOBI_PIPELINED     // measured equal-or-slower than the simple form at 1 wave/SIMD
     if constexpr (N >= 6) return jacobi_eigh_pipelined<N>(Ms, Vs, rec, lane);
 #endif
     (void)rec;
-    return jacobi_eigh_simple<N>(Ms, Vs, lane);
+    return jacobi_eigh_simple<N>(Ms, Vs, lane, init_identity);
 }
 
 // block (I, J) of sum_k lam[k] v_k v_k^H for the eigenvectors in Vs (element-major layout);
