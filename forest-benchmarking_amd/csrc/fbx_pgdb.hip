@@ -113,22 +113,41 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     const double half_dd = 0.5 / (double)(d * d);      // 1 / (2 d^2)
     const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
 
-    // negative log-likelihood at est + alpha * update from the two prediction tables
+    // per-setting design words stay in registers for the whole reconstruction
+    uint32_t spw[MAXJ]; double cfw[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int g = lane + 64 * j;
+        spw[j] = g < m ? des.sp[g] : 0u;
+        cfw[j] = (g < m && !des.unit_coefs) ? des.coef[g] : 1.0;
+    }
+    // model probabilities of the current estimate (pe) and of the update direction (pu), per owned
+    // setting and outcome: p(alpha) = pe + alpha * pu, so a line-search step touches no memory
+    double pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
+    auto load_probs = [&](const double* T, double* pp, double* pm) {
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = lane + 64 * j;
+            if (g < m) {
+                const int s = spw[j] >> 16, p = spw[j] & 0xffff;
+                const double tr = T[s * D], ex = cfw[j] * T[s * D + p];
+                pp[j] = (tr + ex) * half_dd; pm[j] = (tr - ex) * half_dd;
+            }
+        }
+    };
+    // negative log-likelihood at est + alpha * update (tomography.py:597-614)
     auto cost_at = [&](double alpha) -> double {
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
             if (g < m) {
-                const uint32_t sp = des.sp[g];
-                const int s = sp >> 16, p = sp & 0xffff;
-                const double cf = des.unit_coefs ? 1.0 : des.coef[g];
-                const double tr = L.Test[s * D] + alpha * L.Tupd[s * D];
-                const double ex = cf * (L.Test[s * D + p] + alpha * L.Tupd[s * D + p]);
-                double pp = (tr + ex) * half_dd, pm = (tr - ex) * half_dd;
+                double pp = fma(alpha, pup[j], pep[j]), pm = fma(alpha, pum[j], pem[j]);
                 pp = pp < PGDB_EPS ? PGDB_EPS : pp;
                 pm = pm < PGDB_EPS ? PGDB_EPS : pm;
-                acc -= npl[j] * log(pp) + nmi[j] * log(pm);
+                acc -= npl[j] * fast_log_pos(pp) + nmi[j] * fast_log_pos(pm);
             }
         }
         return uniform(wave_sum(acc));
@@ -141,8 +160,6 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         if (I == J) { est.re[0] = 1.0 / d; est.re[3] = 1.0 / d; }
     }
     __syncthreads();
-    // zero update table so cost_at(0) sees only Test
-    for (int idx = lane; idx < S * D; idx += 64) L.Tupd[idx] = 0.0;
 
     int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
     PhaseClock pc; pc.reset(); L.choi.pc = &pc;
@@ -161,6 +178,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
         __syncthreads();
         PH_STOP(pc, 3);
+        load_probs(L.Test, pep, pem);
         if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }   // tomography.py:565
 
         // ---- gradient (tomography.py:617-633): eta = n / clip(p); W_s = sum eta Pi
@@ -168,16 +186,11 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
             if (g < m) {
-                const uint32_t sp = des.sp[g];
-                const int s = sp >> 16, p = sp & 0xffff;
-                const double cf = des.unit_coefs ? 1.0 : des.coef[g];
-                const double tr = L.Test[s * D], ex = cf * L.Test[s * D + p];
-                double pp = (tr + ex) * half_dd, pm = (tr - ex) * half_dd;
-                pp = pp < PGDB_EPS ? PGDB_EPS : pp;
-                pm = pm < PGDB_EPS ? PGDB_EPS : pm;
+                const double pp = pep[j] < PGDB_EPS ? PGDB_EPS : pep[j];
+                const double pm = pem[j] < PGDB_EPS ? PGDB_EPS : pem[j];
                 const double ep = npl[j] / pp, em = nmi[j] / pm;
                 L.hs[g] = 0.5 * (ep + em);
-                L.hd[g] = cf * 0.5 * (ep - em);
+                L.hd[g] = cfw[j] * 0.5 * (ep - em);
             }
         }
         double* W = L.Tupd;                         // [D][S]
@@ -218,7 +231,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         __syncthreads();
         predict_table<NQ>(L.Rb, L.Cl, L.Tupd, S, lane);
         __syncthreads();
-
+        load_probs(L.Tupd, pup, pum);
         PH_STOP(pc, 3);
         // ---- backtracking line search (tomography.py:575-585)
         double ipr, ipi;
@@ -264,6 +277,11 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 #ifdef FBX_PHASE_TIMERS
     if (lane == 0 && phase_out) for (int i = 0; i < FBX_NPHASE; ++i) phase_out[item * FBX_NPHASE + i] = pc.acc[i];
 #endif
+}
+
+__global__ void debug_log_kernel(const double* x, double* out, long long n) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fast_log_pos(x[i]);
 }
 
 static long long* g_phase_out = nullptr;   // diagnostics: set by fbx_debug_set_phase_buffer
@@ -322,6 +340,21 @@ extern "C" {
 // diagnostics only (not part of include/fbx.h): device buffer of 8 int64 per item that a
 // -DFBX_PHASE_TIMERS build fills with per-phase shader cycles
 int fbx_debug_set_phase_buffer(long long* d_buf) { g_phase_out = d_buf; return FBX_OK; }
+
+// diagnostics only: the device natural log used by the PGDB line search, on host arrays
+int fbx_debug_log(const double* x, double* out, int64_t n) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf dx, dout;
+    if ((rc = dx.alloc(sizeof(double) * n)) || (rc = dout.alloc(sizeof(double) * n))) return rc;
+    FBX_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(debug_log_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
+                       dx.as<double>(), dout.as<double>(), (long long)n);
+    FBX_HIP(hipGetLastError());
+    FBX_HIP(hipMemcpyAsync(out, dout.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
 
 int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
                          const double* d_counts, int trace_preserving, int mode, int max_iters,
