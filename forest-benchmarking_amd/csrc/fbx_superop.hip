@@ -9,6 +9,7 @@
 //   operator_tools/apply_superoperator.py:60-90              (apply_choi_matrix_2_state)
 //   distance_measures.py:271-359                             (entanglement / process fidelity)
 #include "fbx_choi.hpp"
+#include <cstdlib>
 
 namespace fbx {
 
@@ -287,12 +288,138 @@ sweep_kernel(long long B, int K, const double* __restrict__ kraus, const double*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2-qubit sweep, tuned: the two basis changes are radix-2 butterflies over the four tensor sites
+// (each site pairs two index bits; I/Z = sum/difference of the (0,0),(1,1) entries, X/Y = sum /
+// +-i difference of the (0,1),(1,0) entries), done in place in LDS with one quad per lane, followed
+// by a bit-permuting gather so that every HBM store is a coalesced 1 KiB wave transaction.
+// Per item: 1 KiB read (K = 4), 12 KiB + 8 B written; 8 butterfly stages instead of two
+// 16 x 16 x 16 dense products.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int insert_zero_bits(int v, int lo, int hi) {   // lo < hi bit positions
+    int r = (v & ((1 << lo) - 1)) | ((v >> lo) << (lo + 1));                  // zero at `lo`
+    r = (r & ((1 << hi) - 1)) | ((r >> hi) << (hi + 1));                      // zero at `hi`
+    return r;
+}
+// one butterfly stage on the 16 x 16 matrix M (leading dimension 17): P / Q = bit positions in the
+// 8-bit element index row*16 + col; ysign = +1 / -1 selects +i / -i for the Y combination
+__device__ __forceinline__ void pauli_stage(cplx* M, int lane, int pbit, int qbit, double ysign) {
+    const int lo = pbit < qbit ? pbit : qbit, hi = pbit < qbit ? qbit : pbit;
+    const int base = insert_zero_bits(lane, lo, hi);
+    const int i00 = base, i11 = base | (1 << pbit) | (1 << qbit), i01 = base | (1 << qbit), i10 = base | (1 << pbit);
+    auto addr = [](int idx) { return (idx >> 4) * 17 + (idx & 15); };
+    const cplx c00 = M[addr(i00)], c11 = M[addr(i11)], c01 = M[addr(i01)], c10 = M[addr(i10)];
+    cplx oi, oz, ox, oy;
+    oi.re = c00.re + c11.re; oi.im = c00.im + c11.im;
+    oz.re = c00.re - c11.re; oz.im = c00.im - c11.im;
+    ox.re = c01.re + c10.re; ox.im = c01.im + c10.im;
+    const double dr = c01.re - c10.re, di = c01.im - c10.im;                 // +-i * (dr + i di)
+    oy.re = -ysign * di; oy.im = ysign * dr;
+    M[addr(i00)] = oi; M[addr(i11)] = oz; M[addr(i01)] = ox; M[addr(i10)] = oy;
+}
+
+__global__ void __launch_bounds__(64)
+sweep2q_kernel(long long B, int K, const double* __restrict__ kraus, const double* __restrict__ ptm_ref,
+               double* __restrict__ choi_out, double* __restrict__ ptm_out, double* __restrict__ chi_out,
+               double* __restrict__ fid_out) {
+    constexpr int D = 16, LD = 17;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* A = (cplx*)smem;                 // Choi -> Pauli-Liouville
+    cplx* W = A + D * LD;                  // Choi -> chi
+    cplx* kb = W + D * LD;                 // vec of the Kraus operators
+    const int lane = threadIdx.x;
+    const int col = lane & 15, q = lane >> 4;
+    cplx ref[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ref[r].re = ref[r].im = 0.0;
+        if (ptm_ref) { ref[r].re = ptm_ref[2 * (lane + 64 * r)]; ref[r].im = ptm_ref[2 * (lane + 64 * r) + 1]; }
+    }
+    for (long long item = blockIdx.x; item < B; item += gridDim.x) {
+        // ---- Kraus operators: coalesced 16-byte loads, stored as vec(K_t)[c*4 + r] = K_t[r][c]
+        const double* kp = kraus + item * (long long)K * D * 2;
+        __syncthreads();
+        for (int idx = lane; idx < K * D; idx += 64) {
+            const double2 v = *reinterpret_cast<const double2*>(kp + 2 * idx);
+            const int t = idx >> 4, rr = (idx >> 2) & 3, cc = idx & 3;
+            cplx c; c.re = v.x; c.im = v.y;
+            kb[t * D + cc * 4 + rr] = c;
+        }
+        __syncthreads();
+        // ---- kraus2choi: C[row][col] = sum_t vK_t[row] conj(vK_t[col]); lane owns rows q + 4 r
+        cplx acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r].re = acc[r].im = 0.0;
+        for (int t = 0; t < K; ++t) {
+            const cplx b = kb[t * D + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const cplx a = kb[t * D + q + 4 * r];
+                acc[r].re += a.re * b.re + a.im * b.im;
+                acc[r].im += a.im * b.re - a.re * b.im;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            A[(q + 4 * r) * LD + col] = acc[r];
+            W[(q + 4 * r) * LD + col] = acc[r];
+            if (choi_out) {
+                double2 v; v.x = acc[r].re; v.y = acc[r].im;
+                *reinterpret_cast<double2*>(choi_out + (item * D * D + lane + 64 * r) * 2) = v;
+            }
+        }
+        __syncthreads();
+        // ---- Pauli-Liouville: sites pair (row bit, col bit); element index = row * 16 + col, so the
+        // row bits are index bits 7..4 (a1 a0 b1 b0) and the col bits 3..0
+        pauli_stage(A, lane, 7, 3, -1.0); __syncthreads();     // input qubit 0:  P_j^T  -> -i
+        pauli_stage(A, lane, 6, 2, -1.0); __syncthreads();     // input qubit 1
+        pauli_stage(A, lane, 5, 1, +1.0); __syncthreads();     // output qubit 0: P_i    -> +i
+        pauli_stage(A, lane, 4, 0, +1.0); __syncthreads();     // output qubit 1
+        // ---- chi: sites pair (a bit, b bit) of the same index; rows carry vec(P_k)^H, columns vec(P_l)
+        pauli_stage(W, lane, 7, 5, -1.0); __syncthreads();
+        pauli_stage(W, lane, 6, 4, -1.0); __syncthreads();
+        pauli_stage(W, lane, 3, 1, +1.0); __syncthreads();
+        pauli_stage(W, lane, 2, 0, +1.0); __syncthreads();
+        // ---- gather to matrix order, scale, store; process fidelity on the fly
+        double fr = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = lane + 64 * r, i = idx >> 4, j = idx & 15;
+            {   // R[i][j]: digits (2 rowbit + colbit): i = 8 b1 + 4 b1' + 2 b0 + b0', j likewise from a
+                const int row = ((j >> 3) & 1) << 3 | ((j >> 1) & 1) << 2 | ((i >> 3) & 1) << 1 | ((i >> 1) & 1);
+                const int cl = ((j >> 2) & 1) << 3 | (j & 1) << 2 | ((i >> 2) & 1) << 1 | (i & 1);
+                cplx v = A[row * LD + cl]; v.re *= 0.25; v.im *= 0.25;
+                fr += ref[r].re * v.re + ref[r].im * v.im;
+                if (ptm_out) { double2 o; o.x = v.re; o.y = v.im; *reinterpret_cast<double2*>(ptm_out + (item * D * D + idx) * 2) = o; }
+            }
+            if (chi_out) {   // chi[k][l]: k = 8 a1 + 4 b1 + 2 a0 + b0 over the row bits (a1 a0 b1 b0)
+                const int row = ((i >> 3) & 1) << 3 | ((i >> 1) & 1) << 2 | ((i >> 2) & 1) << 1 | (i & 1);
+                const int cl = ((j >> 3) & 1) << 3 | ((j >> 1) & 1) << 2 | ((j >> 2) & 1) << 1 | (j & 1);
+                cplx v = W[row * LD + cl]; v.re *= 0.0625; v.im *= 0.0625;
+                double2 o; o.x = v.re; o.y = v.im;
+                *reinterpret_cast<double2*>(chi_out + (item * D * D + idx) * 2) = o;
+            }
+        }
+        if (fid_out) {
+            fr = wave_sum(fr);
+            if (lane == 0) fid_out[item] = (4.0 * (fr / 16.0) + 1.0) / 5.0;
+        }
+    }
+}
+
 template <int NQ>
 static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi,
                         double* ptm, double* chi, double* fid) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
     const size_t lds = sizeof(cplx) * (4 * D * LD + (size_t)K * D);
     if (lds > 160 * 1024) { set_error("fbx_kraus_sweep: too many Kraus operators"); return FBX_ERR_UNSUPPORTED; }
+    if (NQ == 2 && K <= 16 && !getenv("FBX_SWEEP_GENERIC")) {
+        const size_t lds2 = sizeof(cplx) * (2 * 16 * 17 + (size_t)K * 16);
+        const unsigned grid2 = (unsigned)(B < 256 * 16 ? B : 256 * 16);
+        hipLaunchKernelGGL(sweep2q_kernel, dim3(grid2), dim3(64), lds2, stream(), (long long)B, K, kraus, ptm_ref, choi, ptm, chi, fid);
+        FBX_HIP(hipGetLastError());
+        return FBX_OK;
+    }
     auto kern = sweep_kernel<NQ>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)(B < 256 * 8 ? B : 256 * 8);

@@ -73,6 +73,13 @@ int main(int argc, char** argv) {
         re -= V[(i * N + k) * 2] * W[k]; im -= V[(i * N + k) * 2 + 1] * W[k];
         res = fmax(res, sqrt(re * re + im * im));
     }
+#ifdef FBX_JACOBI_SEGTIME
+    long long seg[4]; hipMemcpyFromSymbol(seg, HIP_SYMBOL(fbx::g_seg), sizeof seg);
+    double tot = seg[0] + seg[1] + seg[2] + seg[3];
+    printf("segments (block 0, both launches): read+wait %.0f%%  rotations %.0f%%  update %.0f%%  write+sync %.0f%%  (cycles/round: %.0f %.0f %.0f %.0f)\n",
+           100 * seg[0] / tot, 100 * seg[1] / tot, 100 * seg[2] / tot, 100 * seg[3] / tot,
+           seg[0] / (2.0 * s[0] * 15), seg[1] / (2.0 * s[0] * 15), seg[2] / (2.0 * s[0] * 15), seg[3] / (2.0 * s[0] * 15));
+#endif
     printf("B=%d reps=%d kernel %.3f ms; per eigh: %.0f cycles, %.2f sweeps, %.0f cycles/round; residual %.2e; eigh/s %.3e\n",
            B, reps, ms, csum / B / reps, ssum / B / reps, csum / ssum / (N - 1), res, B * reps / (ms * 1e-3));
     return 0;
