@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--in-basis", default="pauli")
     ap.add_argument("--cpu-sample", type=int, default=12,
                     help="items timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--workload", default="pgdb", choices=["pgdb", "sweep"],
+                    help="pgdb = the headline metric (BASELINE configs[1]); sweep = the secondary "
+                         "HBM-bound conversion sweep of BASELINE configs[2] (1e6 Kraus sets)")
+    ap.add_argument("--sweep-items", type=int, default=1_000_000)
     return ap.parse_args()
 
 
@@ -62,6 +66,98 @@ def cpu_baseline(design, e, c, n_items, iters):
     return {"value": n_items / dt, "unit": "reconstructions/s", "cores": 1, "kind": "port",
             "sample": f"first {n_items} items of the bench batch, fixed {iters} iterations, "
                       f"numpy oracle with the design matrix hoisted, {dt:.1f} s"}
+
+
+def _profiled(key):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
+
+
+def sweep_cpu_baseline(ks, ref, n_items):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from fbx_oracle import superops as so, measures as om
+    t0 = time.perf_counter()
+    for b in range(n_items):
+        choi = so.kraus2choi(list(ks[b]))
+        ptm = so.choi2pauli_liouville(choi)
+        so.choi2chi(choi)
+        om.process_fidelity(ref, ptm)
+    dt = time.perf_counter() - t0
+    return {"value": n_items / dt, "unit": "items/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_items} Kraus sets, numpy oracle (reference-faithful: basis matrices "
+                      f"rebuilt per call, choi2chi through eigh), {dt:.1f} s"}
+
+
+def run_sweep(args, rank, world, dist, torch):
+    """Secondary line: kraus2choi -> choi2pauli_liouville -> choi2chi + process_fidelity on
+    `--sweep-items` random 2-qubit CPTP Kraus sets (K = 4) per GPU, inputs resident in HBM."""
+    import ctypes
+    from fbx import _lib, synthetic
+    n, K, D = 2, 4, 16
+    B = args.sweep_items
+    base = synthetic.kraus_batch(n, K, 8192, seed=17 + rank)
+    ks = np.ascontiguousarray(np.tile(base, (B // 8192 + 1, 1, 1, 1))[:B])
+    cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=np.complex128)
+    lib = _lib.lib()
+    ref = np.empty((1, D, D), dtype=np.complex128)
+    _lib.check(lib.fbx_convert(_lib.REP_KRAUS, _lib.REP_PAULI_LIOUVILLE, n, 1,
+                               _lib.dptr(np.ascontiguousarray(cnot[None, None]).view(np.float64)), 1,
+                               _lib.dptr(ref.view(np.float64))))
+    d_k = _lib.DeviceBuffer.from_array(ks)
+    d_r = _lib.DeviceBuffer.from_array(ref)
+    d_c = _lib.DeviceBuffer(B * D * D * 16); d_p = _lib.DeviceBuffer(B * D * D * 16)
+    d_x = _lib.DeviceBuffer(B * D * D * 16); d_f = _lib.DeviceBuffer(B * 8)
+
+    def step():
+        _lib.check(lib.fbx_kraus_sweep_dev(n, B, K, d_k.ptr, d_r.ptr, d_c.ptr, d_p.ptr, d_x.ptr, d_f.ptr))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        _lib.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ms = ctypes.c_double(0.0)
+    t0 = time.perf_counter()
+    _lib.check(lib.fbx_timer_begin())
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.fbx_timer_end(ctypes.byref(ms)))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed, ms.value], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kms = t.tolist()
+    else:
+        kms = ms.value
+    if rank == 0:
+        bytes_item = K * D * 16 + 3 * D * D * 16 + 8            # 13 320 B (SURVEY 8d)
+        ksec = kms / 1e3 / args.steps
+        gbs = B * bytes_item / ksec / 1e9
+        line = {"metric": "conversion sweep items/sec (2-qubit Kraus -> Choi -> PTM -> chi + process_fidelity)",
+                "value": world * B * args.steps / elapsed, "unit": "items/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"{B} random 2-qubit CPTP Kraus sets (K=4) per GPU, all three "
+                                       f"representations + fidelity written, inputs resident in HBM",
+                           "items_per_gpu": B, "parallelism": f"shard{world}"},
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "traffic": _profiled("sweep_kernel_hbm_bytes_per_launch"),
+                             "kernel": "sweep2q_kernel",
+                             "kernel_ms": 1e3 * ksec,
+                             "note": "achieved = 13 320 algorithmic bytes per item / HIP-event kernel time"}}
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = sweep_cpu_baseline(ks, ref[0], 2000)
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -85,6 +181,12 @@ def main():
     from fbx import _lib, synthetic
     _lib.set_device(local_rank)                       # fails loudly without a GPU
     dev_name, cus = _lib.device_name()
+    if args.workload == "sweep":
+        run_sweep(args, rank, world, dist, torch)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B = args.batch
     design, _, e, c = synthetic.process_batch(2, args.in_basis, B, first_item=rank * B)
@@ -138,13 +240,7 @@ def main():
         value = total_recons / elapsed
         kernel_s = kernel_ms_total / 1e3 / args.steps           # average launch duration
         achieved_tflops = B * ALGO_FLOP_PER_RECON * (args.iters / 100.0) / kernel_s / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("pgdb_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = _profiled("pgdb_kernel_hbm_bytes_per_launch")
         line = {
             "metric": "process-tomography MLE reconstructions/sec (2-qubit, 100 iters)",
             "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps,

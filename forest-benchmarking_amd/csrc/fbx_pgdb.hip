@@ -114,25 +114,26 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
 
     // per-setting design words stay in registers for the whole reconstruction
-    uint32_t spw[MAXJ]; double cfw[MAXJ];
+    uint32_t spw[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
         const int g = lane + 64 * j;
         spw[j] = g < m ? des.sp[g] : 0u;
-        cfw[j] = (g < m && !des.unit_coefs) ? des.coef[g] : 1.0;
     }
+    const bool unit_coefs = des.unit_coefs != 0;      // wave-uniform: coefficients re-read only when needed
     // model probabilities of the current estimate (pe) and of the update direction (pu), per owned
     // setting and outcome: p(alpha) = pe + alpha * pu, so a line-search step touches no memory
     double pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
-    auto load_probs = [&](const double* T, double* pp, double* pm) {
+    auto load_probs = [&](const double* T, double (&pp)[MAXJ], double (&pm)[MAXJ]) {
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
             if (g < m) {
                 const int s = spw[j] >> 16, p = spw[j] & 0xffff;
-                const double tr = T[s * D], ex = cfw[j] * T[s * D + p];
+                const double cf = unit_coefs ? 1.0 : des.coef[g];
+                const double tr = T[s * D], ex = cf * T[s * D + p];
                 pp[j] = (tr + ex) * half_dd; pm[j] = (tr - ex) * half_dd;
             }
         }
@@ -189,8 +190,9 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 const double pp = pep[j] < PGDB_EPS ? PGDB_EPS : pep[j];
                 const double pm = pem[j] < PGDB_EPS ? PGDB_EPS : pem[j];
                 const double ep = npl[j] / pp, em = nmi[j] / pm;
+                const double cf = unit_coefs ? 1.0 : des.coef[g];
                 L.hs[g] = 0.5 * (ep + em);
-                L.hd[g] = cfw[j] * 0.5 * (ep - em);
+                L.hd[g] = cf * 0.5 * (ep - em);
             }
         }
         double* W = L.Tupd;                         // [D][S]
