@@ -419,6 +419,52 @@ state_measures_kernel(long long B, const double* __restrict__ rho_in, const doub
     }
 }
 
+// generic batched eigh (lower triangle read, ascending eigenvalues, eigenvectors as columns)
+template <int N>
+__global__ void __launch_bounds__(64)
+eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_out, double* __restrict__ v_out) {
+    constexpr int NB = N / 2;
+    __shared__ cplx Ms[N * N];
+    __shared__ cplx Vs[N * N];
+    __shared__ JRec rec[NB + 1];
+    __shared__ double lam[N];
+    __shared__ int pos[N];
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    const double* src = a + item * (long long)N * N * 2;
+    Blk h = blk_zero();
+    if (lane < NB * NB) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
+            if (r > c) { h.re[e] = src[2 * (r * N + c)]; h.im[e] = src[2 * (r * N + c) + 1]; }
+            else if (r < c) { h.re[e] = src[2 * (c * N + r)]; h.im[e] = -src[2 * (c * N + r) + 1]; }
+            else { h.re[e] = src[2 * (r * N + c)]; h.im[e] = 0.0; }
+        }
+    }
+    sys_store<N>(Ms, lane, h);
+    __syncthreads();
+    jacobi_eigh_lds<N>(Ms, Vs, rec, lane);
+    if (lane < N) lam[lane] = Ms[sys_index<N>(lane, lane)].re;
+    __syncthreads();
+    if (lane < N) {                     // rank of eigenvalue `lane` in ascending order (stable)
+        int rank = 0;
+        for (int j = 0; j < N; ++j) rank += (lam[j] < lam[lane]) || (lam[j] == lam[lane] && j < lane);
+        pos[lane] = rank;
+        w_out[item * N + rank] = lam[lane];
+    }
+    __syncthreads();
+    if (v_out) {
+        for (int idx = lane; idx < N * N; idx += 64) {
+            const int r = idx / N, k = idx % N;
+            const cplx v = Vs[sys_index<N>(r, k)];
+            double* o = v_out + ((item * N + r) * N + pos[k]) * 2;
+            o[0] = v.re; o[1] = v.im;
+        }
+    }
+}
+
 }  // namespace fbx
 
 using namespace fbx;
@@ -541,6 +587,24 @@ int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* 
     FBX_DISPATCH_NQ(n, loglik_kernel, lds, B, design->dev, (long long)B, dr, de, dc, dout);
     FBX_HIP(hipGetLastError());
     FBX_TRY(io.back(ll_out, dout, (size_t)B));
+    return io.sync();
+}
+
+int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
+    FBX_REQUIRE(N == 2 || N == 4 || N == 8 || N == 16, "fbx_eigh: N must be 2, 4, 8 or 16");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (a && w_out)), "fbx_eigh: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t nn = (size_t)N * N * 2 * B;
+    HostIO io; double *da, *dw, *dv = nullptr;
+    FBX_TRY(io.in(a, nn, &da)); FBX_TRY(io.out((size_t)N * B, &dw));
+    if (v_out) FBX_TRY(io.out(nn, &dv));
+    if (N == 2) hipLaunchKernelGGL(eigh_kernel<2>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
+    else if (N == 4) hipLaunchKernelGGL(eigh_kernel<4>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
+    else if (N == 8) hipLaunchKernelGGL(eigh_kernel<8>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
+    else hipLaunchKernelGGL(eigh_kernel<16>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
+    FBX_HIP(hipGetLastError());
+    FBX_TRY(io.back(w_out, dw, (size_t)N * B)); FBX_TRY(io.back(v_out, dv, nn));
     return io.sync();
 }
 

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "fbx_apply_choi": [C.c_int, _i64, _dp, _dp, _dp],
     "fbx_process_fidelity": [C.c_int, _i64, _dp, _dp, _dp, _dp],
     "fbx_state_measures": [C.c_int, _i64, _dp, _dp, _dp, _dp, _dp, _dp],
+    "fbx_eigh": [C.c_int, _i64, _dp, _dp, _dp],
 }
 
 
@@ -140,6 +141,19 @@ def dptr(a):
 
 def iptr(a):
     return None if a is None else a.ctypes.data_as(_ip)
+
+
+def eigh_batch(a, eigenvectors=True):
+    """numpy.linalg.eigh semantics (lower triangle, ascending) for stacked [B, N, N], N in {2,4,8,16}."""
+    a = c128(a)
+    a = a.reshape((-1,) + a.shape[-2:])
+    B, N = a.shape[0], a.shape[-1]
+    if a.shape[-2] != N:
+        raise ValueError("matrices must be square")
+    w = np.empty((B, N))
+    v = np.empty((B, N, N), dtype=np.complex128) if eigenvectors else None
+    check(lib().fbx_eigh(N, B, dptr(a.view(np.float64)), dptr(w), dptr(v.view(np.float64)) if eigenvectors else None))
+    return (w, v) if eigenvectors else w
 
 
 class DeviceBuffer:

@@ -20,7 +20,8 @@ __all__ = ["vec", "unvec", "convert_batch", "kraus2chi", "kraus2superop", "kraus
            "superop2pauli_liouville", "superop2choi", "pauli_liouville2chi",
            "pauli_liouville2superop", "pauli_liouville2choi", "choi2chi", "choi2superop",
            "choi2pauli_liouville", "pauli2computational_basis_matrix",
-           "computational2pauli_basis_matrix"]
+           "computational2pauli_basis_matrix", "choi2kraus", "superop2kraus", "pauli_liouville2kraus",
+           "chi2kraus"]
 
 
 def vec(matrix: np.ndarray) -> np.ndarray:
@@ -144,6 +145,31 @@ def pauli_liouville2choi(pl_matrix):
     return _one("pauli_liouville", "choi", pl_matrix)
 
 
+def choi2kraus(choi, tol: float = 1e-9):
+    """superoperator_transformations.py:325-336: one Kraus operator sqrt(lambda_i) unvec(v_i) per
+    eigenpair of the Choi matrix with |lambda_i| > tol (eigendecomposition on the device; like the
+    reference's, the operators are defined up to the phase of each eigenvector)."""
+    choi = np.asarray(choi, dtype=np.complex128)
+    w, v = _lib.eigh_batch(choi[None])
+    return [np.lib.scimath.sqrt(ev) * unvec(np.array([evec]).T) for ev, evec in zip(w[0], v[0].T)
+            if abs(ev) > tol]
+
+
+def superop2kraus(superop):
+    """superoperator_transformations.py:229-238."""
+    return choi2kraus(superop2choi(superop))
+
+
+def pauli_liouville2kraus(pl_matrix):
+    """superoperator_transformations.py:280-288."""
+    return choi2kraus(pauli_liouville2choi(pl_matrix))
+
+
+def chi2kraus(chi_matrix):
+    """superoperator_transformations.py:195-204."""
+    return pauli_liouville2kraus(chi2pauli_liouville(chi_matrix))
+
+
 def choi2chi(choi):
     """superoperator_transformations.py:339-348 (through the eigendecomposition: |C| for
     non-CP input, eigenvalues with |lambda| <= 1e-9 dropped -- reproduced on the device)."""
@@ -161,19 +187,13 @@ def choi2pauli_liouville(choi):
 
 
 def pauli2computational_basis_matrix(dim) -> np.ndarray:
-    """superoperator_transformations.py:374-408: p2c = chi2choi-style basis change applied to
-    the identity is not needed -- the matrix is the superop form of the identity Pauli-Liouville
-    basis; obtained from the device conversion of unit vectors."""
-    n = int(np.log2(dim))
+    """superoperator_transformations.py:374-408: columns are vec(P_k).  Read off the device basis
+    change: chi2choi(e_k e_0^T) = vec(P_k) vec(I)^H, whose column 0 is vec(P_k)."""
     D = dim ** 2
-    # columns are vec(P_k): superop of the map with Pauli-Liouville matrix e_k e_0^T ... simpler:
-    # p2c[:, k] = vec(P_k); chi2choi(E_kk) = vec(P_k) vec(P_k)^H, whose first non-zero column
-    # gives vec(P_k) up to the (known, real-positive for these matrices) normalisation.
     eye = np.zeros((D, D, D), dtype=np.complex128)
     for k in range(D):
         eye[k, k, 0] = 1.0          # chi = e_k e_0^T  ->  choi = vec(P_k) vec(P_0)^H
     choi = convert_batch("chi", "choi", eye)
-    # vec(P_0) = vec(I) has ones at the diagonal positions; row 0 / col 0 entry is 1
     return np.ascontiguousarray(choi[:, :, 0].T)
 
 

@@ -186,15 +186,74 @@ def _resample_expectations_with_beta(results, prior_counts=1):
     return resampled
 
 
+def resample_expectations_with_beta_batch(expectations, total_counts, n_resamples, prior_counts=1):
+    """[n_resamples, m] Beta-resampled expectations drawn from the global np.random stream in the
+    order the reference draws them (resample by resample, result by result; tomography.py:391-402)."""
+    e = np.asarray(expectations, dtype=float)
+    c = np.asarray(total_counts, dtype=float)
+    num_plus = ((e + 1) / 2) * c
+    num_minus = c - num_plus
+    a = np.broadcast_to(num_plus + prior_counts, (n_resamples, e.size))
+    b = np.broadcast_to(num_minus + prior_counts, (n_resamples, e.size))
+    return 2 * np.random.beta(a, b) - 1
+
+
+_BATCHED_ESTIMATORS = {}     # filled below: reference-signature estimator -> batched implementation
+
+
+def _batched_form(tomo_estimator):
+    """(batched function, kwargs) when `tomo_estimator` is one of this module's state estimators
+    (possibly wrapped in functools.partial), else None."""
+    kwargs = {}
+    f = tomo_estimator
+    while isinstance(f, functools.partial):
+        if f.args:
+            return None
+        kwargs = {**f.keywords, **kwargs}
+        f = f.func
+    impl = _BATCHED_ESTIMATORS.get(f)
+    return (impl, kwargs) if impl is not None else None
+
+
 def estimate_variance(results: List[ExperimentResult], qubits: List[int], tomo_estimator: Callable,
                       functional: Callable, target_state=None, n_resamples: int = 40,
                       project_to_physical: bool = False) -> Tuple[float, float]:
-    """tomography.py:412-453 (bootstrap error bar of a functional of the state)."""
-    from .operator_tools.project_state_matrix import project_state_matrix_to_physical
+    """tomography.py:412-453 (bootstrap error bar of a functional of the state).
+
+    When `tomo_estimator` is one of this module's state estimators and `functional` one of
+    ``dm.purity / fidelity / infidelity / trace_distance / hilbert_schmidt_ip`` the whole bootstrap
+    is three batched device calls (estimate, project, measure) over the `n_resamples` resampled
+    experiments -- the resamples are the batch axis; any other callables take the reference's
+    one-at-a-time loop."""
+    from .operator_tools.project_state_matrix import (project_state_matrix_to_physical,
+                                                       project_state_matrix_to_physical_batch)
     if functional != dm.purity:
         if target_state is None:
             raise ValueError("You're not using the `purity` functional. "
                              "Please specify a target state.")
+    batched = _batched_form(tomo_estimator)
+    measures = {dm.purity: "purity", dm.fidelity: "fidelity", dm.infidelity: "fidelity",
+                dm.trace_distance: "trace_distance", dm.hilbert_schmidt_ip: "hs_ip"}
+    if batched is not None and functional in measures:
+        impl, kwargs = batched
+        design, e, c = flatten_results(results, qubits, "state")
+        e_rs = resample_expectations_with_beta_batch(e, c, n_resamples)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            rhos = impl(design, e_rs, np.broadcast_to(c, e_rs.shape), **kwargs)
+        for w in {str(w.message) for w in caught}:
+            warnings.warn(w)
+        if project_to_physical:
+            rhos = project_state_matrix_to_physical_batch(rhos)
+        key = measures[functional]
+        if functional == dm.purity:
+            vals = dm.state_measures_batch(rhos, None, (key,))[key]
+        else:
+            tgt = np.broadcast_to(np.asarray(target_state, dtype=np.complex128), rhos.shape)
+            vals = dm.state_measures_batch(np.ascontiguousarray(tgt), rhos, (key,))[key]
+            if functional == dm.infidelity:
+                vals = 1 - vals
+        return np.mean(vals), np.var(vals)
     sample_estimate = []
     for _ in range(n_resamples):
         resampled_results = _resample_expectations_with_beta(results)
@@ -206,6 +265,10 @@ def estimate_variance(results: List[ExperimentResult], qubits: List[int], tomo_e
         else:
             sample_estimate.append(np.real(functional(target_state, rho)))
     return np.mean(sample_estimate), np.var(sample_estimate)
+
+
+_BATCHED_ESTIMATORS[linear_inv_state_estimate] = lambda design, e, c: linear_inv_state_estimate_batch(design, e)
+_BATCHED_ESTIMATORS[iterative_mle_state_estimate] = iterative_mle_state_estimate_batch
 
 
 # ==================================================================================================

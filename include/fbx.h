@@ -177,6 +177,13 @@ int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double*
                        double* purity_out, double* fidelity_out, double* trace_dist_out,
                        double* hs_ip_out);
 
+/* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
+ * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16}.  This is the
+ * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators
+ * (validate_operator.py:118-150) and proj_choi_to_unitary (project_superoperators.py:147-175).
+ * w_out[B][N]; v_out[B][N][N] holds the eigenvectors as columns (phases arbitrary), may be NULL. */
+int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,73 @@ def test_reference_signatures_on_result_lists(gpu):
         warnings.simplefilter("ignore")
         np.testing.assert_allclose(T.iterative_mle_state_estimate(res, [0, 1], maxiter=100), g["mle100"][0], atol=1e-11)
     assert abs(T.state_log_likelihood(g["mle100"][0], res, [0, 1]) - g["loglik"][0]) < 1e-9 * abs(g["loglik"][0])
+
+
+def test_bootstrap_batched_equals_one_at_a_time(gpu):
+    """estimate_variance (tomography.py:412-453): the batched device path and the reference-style
+    loop consume the np.random stream identically, so they agree to rounding for the same seed."""
+    import functools
+    from fbx import distance_measures as dm, tomography as T
+    from fbx.observable_estimation import ExperimentResult
+    g = gold(2)
+    qubits = [0, 1]
+    settings = T.generate_state_tomography_settings(qubits)
+    res = [ExperimentResult(s, float(g["expectations"][0][k]), int(g["counts"][0][k])) for k, s in enumerate(settings)]
+    target = g["truth"][0]
+    est = functools.partial(T.iterative_mle_state_estimate, epsilon=0.5, tol=1e-6, maxiter=300)
+    np.random.seed(11)
+    fast = T.estimate_variance(res, qubits, est, dm.fidelity, target_state=target, n_resamples=12,
+                               project_to_physical=True)
+    np.random.seed(11)
+    slow = T.estimate_variance(res, qubits, lambda r, q: est(r, q), dm.fidelity, target_state=target,
+                               n_resamples=12, project_to_physical=True)       # opaque callable -> loop
+    assert abs(fast[0] - slow[0]) < 1e-9 and abs(fast[1] - slow[1]) < 1e-9
+    np.random.seed(3)
+    m, v = T.estimate_variance(res, qubits, T.linear_inv_state_estimate, dm.purity, n_resamples=40)
+    assert 0.2 < m < 1.2 and v >= 0
+    with pytest.raises(ValueError):
+        T.estimate_variance(res, qubits, T.linear_inv_state_estimate, dm.fidelity)
+
+
+def test_eigh_entry_point_and_validators(gpu):
+    from fbx import _lib
+    from fbx import operator_tools as ot
+    rs = np.random.RandomState(2)
+    for N in (2, 4, 8, 16):
+        a = rs.randn(5, N, N) + 1j * rs.randn(5, N, N)
+        w, v = _lib.eigh_batch(a)
+        for b in range(5):
+            ww = np.linalg.eigvalsh(a[b])                      # numpy reads the lower triangle too
+            assert np.abs(w[b] - ww).max() < 1e-12
+            low = np.tril(a[b], -1); h = low + low.conj().T + np.diag(np.diag(a[b]).real)
+            assert np.abs(h @ v[b] - v[b] * w[b]).max() < 1e-11
+            assert np.abs(v[b].conj().T @ v[b] - np.eye(N)).max() < 1e-12
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    cx = ot.kraus2choi(x)
+    assert ot.choi_is_cptp(cx) and ot.choi_is_unitary(cx) and ot.choi_is_unital(cx)
+    assert ot.choi_is_trace_preserving(cx) and ot.choi_is_completely_positive(cx)
+    assert not ot.choi_is_trace_preserving(ot.kraus2choi(x - 0.1 * np.eye(2)))
+    assert not ot.choi_is_completely_positive(-cx)
+    ks = [np.array([[1, 0], [0, np.sqrt(0.9)]]), np.array([[0, np.sqrt(0.1)], [0, 0]])]
+    assert ot.kraus_operators_are_valid(ks) and not ot.kraus_operators_are_valid([ks[0]])
+    assert not ot.choi_is_unitary(ot.kraus2choi(ks)) and not ot.choi_is_unital(ot.kraus2choi(ks))
+    ops = ot.choi2kraus(ot.kraus2choi(ks))
+    assert len(ops) == 2 and np.abs(ot.kraus2choi(ops) - ot.kraus2choi(ks)).max() < 1e-12
+    with pytest.raises(ValueError):
+        ot.is_positive_semidefinite_matrix(np.array([[1, 2], [3, 4.0]]))
+    with pytest.raises(ValueError):
+        ot.is_hermitian_matrix(np.zeros((2, 3)))
+
+
+def test_proj_choi_to_unitary(gpu):
+    """tests/test_project_superoperators.py:86-113 of the reference, as data."""
+    from fbx import operator_tools as ot
+    import known_answers as ka
+    for u in (ka.CNOT, ka.Z, ka.H):
+        c = ot.kraus2choi(u)
+        np.testing.assert_allclose(ot.proj_choi_to_unitary(c), c, atol=1e-10)
+
+    def bit_flip(p):
+        return [np.sqrt(1 - p) * ka.I2, np.sqrt(p) * ka.X]
+    np.testing.assert_allclose(ot.proj_choi_to_unitary(ot.kraus2choi(bit_flip(0.1))), ot.kraus2choi(ka.I2), atol=1e-10)
+    np.testing.assert_allclose(ot.proj_choi_to_unitary(ot.kraus2choi(bit_flip(0.9))), ot.kraus2choi(ka.X), atol=1e-10)
