@@ -158,15 +158,29 @@ __device__ Blk proj_tni_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps)
 // ---- Dykstra: project_superoperators.py:87-144.  Stops on the Birgin-Raydan functional
 // < 1e-4 (no iteration cap in the reference; `max_iter` is a safety net that is never the
 // binding constraint in practice).  Returns the last TP / TNI iterate.
+// `vfirst` (optional, D*D cplx in the Jacobi layout) carries the eigenvectors of the FIRST projection
+// of the previous call: successive PGDB iterations project nearby matrices, so they warm-start
+// that first eigendecomposition as well (`first_valid` says whether the buffer holds a basis).
 template <int NQ>
 __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ>& L, int lane,
-                                 int& iters, int& sweeps, int max_iter = 100000) {
+                                 int& iters, int& sweeps, int max_iter = 100000,
+                                 cplx* vfirst = nullptr, bool first_valid = false) {
+    constexpr int DD = ChoiLds<NQ>::D * ChoiLds<NQ>::D;
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
     for (int it = 0; it < max_iter; ++it) {
         ++iters;
         const Blk pre_cp = blk_sub(last_state, old_cp);
-        const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, FBX_WARM_START && it > 0);
+        bool warm = FBX_WARM_START && it > 0;
+        if (FBX_WARM_START && it == 0 && vfirst && first_valid) {
+            __syncthreads();
+            for (int idx = lane; idx < DD; idx += 64) L.Vs[idx] = vfirst[idx];
+            warm = true;
+        }
+        const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm);
+        if (FBX_WARM_START && it == 0 && vfirst) {
+            for (int idx = lane; idx < DD; idx += 64) vfirst[idx] = L.Vs[idx];
+        }
         const Blk new_cp = blk_sub(cp, pre_cp);
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = trace_preserving ? proj_tp_blk<NQ>(pre_tp, L, lane)
@@ -190,59 +204,104 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
 // ---- Choi <-> Pauli-coefficient transforms --------------------------------------------
 // R_ij = (1/d) tr[(P_j^T (x) P_i) E]  (real for Hermitian E; this is the Pauli-Liouville
 // matrix of the channel, superoperator_transformations.py:364-371), and its inverse
-// E = (1/d) sum_ij R_ij (P_j^T (x) P_i).  E is staged in Mw (complex, LD), R in `Rb`
-// (real, row-major D x D).  Every lane handles D*D/64 entries.
-template <int NQ>
-__device__ void choi_to_pauli_real(const cplx* Mw, double* Rb, int lane) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    for (int idx = lane; idx < D * D; idx += 64) {
-        const int i = idx / D, j = idx % D;
-        int xi, zi, yi, xj, zj, yj;
-        pauli_masks<NQ>(i, xi, zi, yi);
-        pauli_masks<NQ>(j, xj, zj, yj);
-        const int ph = (yi + yj) & 3;
-        double acc = 0.0;
-        for (int a = 0; a < d; ++a) {
-#pragma unroll
-            for (int b = 0; b < d; ++b) {
-                const cplx v = Mw[((a ^ xj) * d + (b ^ xi)) * LD + a * d + b];
-                const int sgn = (__popc(a & zj) + __popc((b ^ xi) & zi)) & 1;
-                // real part of i^ph * v
-                double t = (ph == 0) ? v.re : (ph == 1) ? -v.im : (ph == 2) ? -v.re : v.im;
-                acc += sgn ? -t : t;
-            }
+// E = (1/d) sum_ij R_ij (P_j^T (x) P_i).
+//
+// Both are radix-2 butterflies over the 2n tensor sites, in place on the row-major complex matrix
+// staged in Mw (leading dimension D + 1): a site pairs one row-index bit with one column-index
+// bit, and its four entries (c00, c11, c01, c10) go to (I, Z, X, Y) = (c00 + c11, c00 - c11,
+// c01 + c10, +-i (c01 - c10)); -i for input-qubit sites (P_j^T), +i for output-qubit sites (P_i).
+// One quad per lane and stage: 4 LDS reads + 4 writes + 8 adds, no index arithmetic beyond two
+// bit inserts -- against D terms per entry with per-term popcounts in the direct sum.
+__device__ __forceinline__ int insert_zero_bits2(int v, int lo, int hi) {   // lo < hi bit positions
+    int r = (v & ((1 << lo) - 1)) | ((v >> lo) << (lo + 1));
+    r = (r & ((1 << hi) - 1)) | ((r >> hi) << (hi + 1));
+    return r;
+}
+template <int NQ, bool INVERSE>
+__device__ __forceinline__ void pauli_site_stage(cplx* M, int lane, int pbit, int qbit, double ysign) {
+    constexpr int D = 1 << (2 * NQ), LD = D + 1, NQUAD = D * D / 4;
+    if (lane < NQUAD) {
+        const int lo = pbit < qbit ? pbit : qbit, hi = pbit < qbit ? qbit : pbit;
+        const int base = insert_zero_bits2(lane, lo, hi);
+        const int i00 = base, i11 = base | (1 << pbit) | (1 << qbit), i01 = base | (1 << qbit), i10 = base | (1 << pbit);
+        const int a00 = (i00 >> (2 * NQ)) * LD + (i00 & (D - 1)), a11 = (i11 >> (2 * NQ)) * LD + (i11 & (D - 1));
+        const int a01 = (i01 >> (2 * NQ)) * LD + (i01 & (D - 1)), a10 = (i10 >> (2 * NQ)) * LD + (i10 & (D - 1));
+        const cplx c00 = M[a00], c11 = M[a11], c01 = M[a01], c10 = M[a10];
+        cplx o00, o11, o01, o10;
+        if (!INVERSE) {
+            o00.re = c00.re + c11.re; o00.im = c00.im + c11.im;          // I
+            o11.re = c00.re - c11.re; o11.im = c00.im - c11.im;          // Z
+            o01.re = c01.re + c10.re; o01.im = c01.im + c10.im;          // X
+            const double dr = c01.re - c10.re, di = c01.im - c10.im;     // Y = +-i (c01 - c10)
+            o10.re = -ysign * di; o10.im = ysign * dr;
+        } else {                                                          // (I, Z, X, Y) at (00, 11, 01, 10)
+            o00.re = 0.5 * (c00.re + c11.re); o00.im = 0.5 * (c00.im + c11.im);
+            o11.re = 0.5 * (c00.re - c11.re); o11.im = 0.5 * (c00.im - c11.im);
+            // c01 = (X - s i Y)/2, c10 = (X + s i Y)/2 ;  i Y = (-Y.im, Y.re)
+            const double yr = -ysign * c10.im, yi = ysign * c10.re;       // s * i * Y
+            o01.re = 0.5 * (c01.re - yr); o01.im = 0.5 * (c01.im - yi);
+            o10.re = 0.5 * (c01.re + yr); o10.im = 0.5 * (c01.im + yi);
         }
-        Rb[idx] = acc / d;
+        M[a00] = o00; M[a11] = o11; M[a01] = o01; M[a10] = o10;
+    }
+}
+// (row, col) of the matrix entry that holds coefficient R[i][j] after the forward stages
+template <int NQ>
+__device__ __forceinline__ void pauli_coeff_position(int i, int j, int& row, int& col) {
+    row = 0; col = 0;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {                 // digit t (least significant first) = 2 rowbit + colbit
+        const int di = (i >> (2 * t)) & 3, dj = (j >> (2 * t)) & 3;
+        row |= ((di >> 1) & 1) << t; col |= (di & 1) << t;                    // output qubit -> low bits
+        row |= ((dj >> 1) & 1) << (NQ + t); col |= (dj & 1) << (NQ + t);      // input qubit -> high bits
     }
 }
 
+// E staged in Mw (destroyed) -> real coefficients Rb[D*D]
 template <int NQ>
-__device__ Blk pauli_real_to_choi_blk(const double* Rb, int lane) {
-    constexpr int d = 1 << NQ, D = d * d, NB = D / 2;
-    Blk out = blk_zero();
-    if (lane < NB * NB) {
-        const int I = lane / NB, J = lane % NB;
+__device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
-            const int ap = row / d, bp = row % d, a = col / d, b = col % d;
-            const int xj = a ^ ap, xi = b ^ bp;
-            double re = 0.0, im = 0.0;
-            for (int zj = 0; zj < d; ++zj) {
-#pragma unroll
-                for (int zi = 0; zi < d; ++zi) {
-                    const int j = pauli_index<NQ>(xj, zj), i = pauli_index<NQ>(xi, zi);
-                    const int ph = (__popc(xj & zj) + __popc(xi & zi)) & 3;
-                    const int sgn = (__popc(ap & zj) + __popc(b & zi)) & 1;
-                    double v = Rb[i * D + j];
-                    v = sgn ? -v : v;
-                    if (ph == 0) re += v; else if (ph == 1) im += v;
-                    else if (ph == 2) re -= v; else im -= v;
-                }
-            }
-            out.re[e] = re / d; out.im[e] = im / d;
-        }
+    for (int t = NQ - 1; t >= 0; --t) {            // input-qubit sites: row bit NQ + t, col bit NQ + t
+        pauli_site_stage<NQ, false>(Mw, lane, 2 * NQ + NQ + t, NQ + t, -1.0);
+        __syncthreads();
     }
+#pragma unroll
+    for (int t = NQ - 1; t >= 0; --t) {            // output-qubit sites
+        pauli_site_stage<NQ, false>(Mw, lane, 2 * NQ + t, t, +1.0);
+        __syncthreads();
+    }
+    for (int idx = lane; idx < D * D; idx += 64) {
+        int row, col;
+        pauli_coeff_position<NQ>(idx / D, idx % D, row, col);
+        Rb[idx] = Mw[row * LD + col].re / d;
+    }
+}
+
+// real coefficients Rb -> Choi block of this lane (Mw is scratch)
+template <int NQ>
+__device__ Blk pauli_real_to_choi_blk(const double* Rb, cplx* Mw, int lane) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
+    __syncthreads();
+    for (int idx = lane; idx < D * D; idx += 64) {
+        int row, col;
+        pauli_coeff_position<NQ>(idx / D, idx % D, row, col);
+        cplx v; v.re = Rb[idx] * d; v.im = 0.0;     // E = d * F^{-1}(R)
+        Mw[row * LD + col] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        pauli_site_stage<NQ, true>(Mw, lane, 2 * NQ + t, t, +1.0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        pauli_site_stage<NQ, true>(Mw, lane, 2 * NQ + NQ + t, NQ + t, -1.0);
+        __syncthreads();
+    }
+    const Blk out = blk_load<D, LD>(Mw, lane);
+    __syncthreads();
     return out;
 }
 

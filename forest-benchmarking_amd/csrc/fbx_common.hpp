@@ -114,9 +114,18 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // one cubically convergent step  y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2.
 // Avoids the IEEE sqrt / divide expansions in the Jacobi rotation's dependent chain.
 __device__ __forceinline__ double fast_rsqrt(double x) {
+#ifdef FBX_EXACT_RSQRT
+    return 1.0 / sqrt(x);
+#endif
     const double y = __builtin_amdgcn_rsq(x);
     const double e = fma(-x * y, y, 1.0);
     const double p = fma(0.375, e, 0.5);
+#ifdef FBX_RSQRT_EXTRA
+    double z = fma(y * e, p, y);
+    const double hx = 0.5 * x;
+    z = z * fma(-hx * z, z, 1.5);
+    return z;
+#endif
     return fma(y * e, p, y);
 }
 

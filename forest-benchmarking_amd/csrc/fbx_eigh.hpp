@@ -293,7 +293,9 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             jacobi_apply_v(rJ.c, rJ.sr, rJ.si, v0p, v0q, v1p, v1q);
             if (I == J) {   // the annihilated pair: exact zeros, real diagonal
                 m01.re = m01.im = 0.0; m10.re = m10.im = 0.0;
-                m00.re = rI.an; m11.re = rI.dn; m00.im = 0.0; m11.im = 0.0;
+                // keep the diagonal the rotation itself produced (consistent with the rest of the
+                // rows / columns to rounding); only its exactly-zero imaginary part is enforced
+                m00.im = 0.0; m11.im = 0.0;
             }
             if (act) {
                 Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;

@@ -14,6 +14,9 @@
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
 #include "fbx_choi.hpp"
 #include <cstdlib>
+#ifndef FBX_DBG_NOVALID
+#define FBX_DBG_NOVALID 0
+#endif
 
 namespace fbx {
 
@@ -29,6 +32,7 @@ struct PgdbLds {
     double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
     double* Tupd;   // [S*D]  same for the update direction; aliased as W[D][S] in the gradient
     double* Cl;     // [D*S]  Bloch coefficients of the input states
+    cplx* Vfirst;   // [D*D]  eigenvectors of the first projection of the previous outer iteration
     double* hs;     // [m] (eta+ + eta-)/2 ; aliases the Jacobi work matrices
     double* hd;     // [m] coef * (eta+ - eta-)/2
     static size_t bytes(int S, int m) {
@@ -37,7 +41,7 @@ struct PgdbLds {
         size_t h = sizeof(double) * 2 * (size_t)m;
         size_t jac = sizeof(cplx) * (D * ChoiLds<NQ>::LD + 2 * D * D);
         size_t extra = h > jac ? h - jac : 0;     // h aliases Mw..Vw, spill past them if longer
-        return choi + extra + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + 64;
+        return choi + extra + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + sizeof(cplx) * D * D + 64;
     }
     __device__ void carve(char* p, int S, int m) {
         constexpr int D = ChoiLds<NQ>::D;
@@ -56,7 +60,9 @@ struct PgdbLds {
         Rb = (double*)p; p += sizeof(double) * D * D;
         Test = (double*)p; p += sizeof(double) * S * D;
         Tupd = (double*)p; p += sizeof(double) * S * D;
-        Cl = (double*)p;
+        Cl = (double*)p; p += sizeof(double) * D * S;
+        p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        Vfirst = (cplx*)p;
     }
 };
 
@@ -216,12 +222,19 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             L.Rb[idx] = -acc / (double)(d * d);
         }
         __syncthreads();
-        const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, lane);
+        const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, L.choi.Mw, lane);
         PH_STOP(pc, 4);
 
         // ---- projected step (tomography.py:572)
         const Blk x = blk_axpy(est, -inv_mu, grad);
-        const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps);
+        // the cross-iteration basis is restarted every 16 iterations to bound the accumulated
+        // loss of unitarity (~1e-16 per rotation)
+        const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
+#ifdef FBX_NO_VFIRST
+                                               nullptr, false);
+#else
+                                               L.Vfirst, (iters & 15) != 0 && !FBX_DBG_NOVALID);
+#endif
         const Blk upd = blk_sub(proj, est);
         PH_STOP(pc, 2);
 

@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(64)
 linv_process_kernel(DesignDev des, long long B, const double* __restrict__ expect, double* __restrict__ out) {
     constexpr int d = 1 << NQ, D = d * d, NB = D / 2;
     __shared__ double Rb[D * D];
+    __shared__ cplx Mw[D * (D + 1)];
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
     for (int idx = lane; idx < D * D; idx += 64) {
@@ -523,7 +524,7 @@ linv_process_kernel(DesignDev des, long long B, const double* __restrict__ expec
         Rb[idx] = acc + ((idx == 0) ? 1.0 : 0.0);
     }
     __syncthreads();
-    const Blk c = pauli_real_to_choi_blk<NQ>(Rb, lane);
+    const Blk c = pauli_real_to_choi_blk<NQ>(Rb, Mw, lane);
     if (lane < NB * NB) {
         const int I = lane / NB, J = lane % NB;
 #pragma unroll
