@@ -1,0 +1,150 @@
+// fbx_shots.hip -- shots -> observable moments (observable_estimation.py:804-853): a byte-stream
+// reduction.  One 256-thread workgroup per setting; every lane streams 16-byte pieces of the
+// [n_shots][n_qubits] 0/1 byte array (coalesced 4 KiB per workgroup-instruction), masks the
+// observable's columns, folds the bytes of each shot with XOR (parity = eigenvalue sign) and
+// counts the -1 outcomes with popcounts; integer counts are reduced through the wave and LDS.
+// HBM-bound integer work: n_qubits bytes per shot in, 16 bytes per setting out.
+#include "fbx_common.hpp"
+
+namespace fbx {
+
+// number of shots with odd parity in one 64-bit word holding 8 / NQB shots of NQB masked bytes
+template <int NQB>
+__device__ __forceinline__ int odd_shots(unsigned long long x) {
+    if (NQB == 1) return __popcll(x & 0x0101010101010101ull);
+    if (NQB == 2) { x ^= x >> 8; return __popcll(x & 0x0001000100010001ull); }
+    if (NQB == 4) { x ^= x >> 16; x ^= x >> 8; return __popcll(x & 0x0000000100000001ull); }
+    x ^= x >> 32; x ^= x >> 16; x ^= x >> 8; return (int)(x & 1ull);      // NQB == 8
+}
+
+template <int NQB>      // NQB in {1, 2, 4, 8}: bytes per shot, 16-byte vector path
+__device__ long long count_minus_vec(const uint8_t* __restrict__ bits, long long n_shots, unsigned long long pat) {
+    const long long total = n_shots * NQB;
+    const long long nvec = total / 16;
+    const ulonglong2* v = reinterpret_cast<const ulonglong2*>(bits);
+    long long cnt = 0;
+    for (long long i = threadIdx.x; i < nvec; i += blockDim.x) {
+        const ulonglong2 w = v[i];
+        cnt += odd_shots<NQB>(w.x & pat) + odd_shots<NQB>(w.y & pat);
+    }
+    // tail (fewer than 16 bytes): whole shots, byte-wise, by one lane
+    if (threadIdx.x == 0) {
+        for (long long s = nvec * 16 / NQB; s < n_shots; ++s) {
+            int par = 0;
+            for (int q = 0; q < NQB; ++q) par ^= bits[s * NQB + q] & (int)((pat >> (8 * q)) & 1);
+            cnt += par;
+        }
+    }
+    return cnt;
+}
+
+__device__ long long count_minus_generic(const uint8_t* __restrict__ bits, long long n_shots, int n,
+                                         const uint8_t* __restrict__ mask) {
+    long long cnt = 0;
+    for (long long s = threadIdx.x; s < n_shots; s += blockDim.x) {
+        int par = 0;
+        for (int q = 0; q < n; ++q) par ^= (bits[s * n + q] & 1) & (mask[q] ? 1 : 0);
+        cnt += par;
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(256)
+shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __restrict__ bits,
+             const uint8_t* __restrict__ obs_mask, const double* __restrict__ coefs, int beta_prior,
+             double* __restrict__ mean_out, double* __restrict__ var_out) {
+    __shared__ long long part[4];
+    for (long long s = blockIdx.x; s < n_settings; s += gridDim.x) {
+        const uint8_t* mk = obs_mask + s * n;
+        const uint8_t* b = bits + s * n_shots * n;
+        bool any = false;
+        unsigned long long pat = 0;
+        for (int q = 0; q < n; ++q) any |= mk[q] != 0;
+        long long cnt = 0;
+        const bool aligned = ((uintptr_t)b & 15) == 0;
+        if (any) {
+            if ((n == 1 || n == 2 || n == 4 || n == 8) && aligned) {
+                for (int byte = 0; byte < 8; ++byte) pat |= (unsigned long long)(mk[byte % n] ? 1 : 0) << (8 * byte);
+                if (n == 1) cnt = count_minus_vec<1>(b, n_shots, pat);
+                else if (n == 2) cnt = count_minus_vec<2>(b, n_shots, pat);
+                else if (n == 4) cnt = count_minus_vec<4>(b, n_shots, pat);
+                else cnt = count_minus_vec<8>(b, n_shots, pat);
+            } else {
+                cnt = count_minus_generic(b, n_shots, n, mk);
+            }
+        }
+        // wave reduction of the integer count (as two 32-bit halves of an exact double)
+        double c = (double)cnt;
+        c = wave_sum(c);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (long long)c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long long n_minus = part[0] + part[1] + part[2] + part[3];
+            const long long n_plus = n_shots - n_minus;
+            const double coef = coefs ? coefs[s] : 1.0;
+            double mean, var;
+            if (!any) { mean = coef; var = 0.0; }                       // identity term (:826-827)
+            else if (beta_prior) {                                       // :837-846
+                const double a = (double)n_plus + 1.0, bb = (double)n_minus + 1.0;
+                const double bm = a / (a + bb), bv = a * bb / ((a + bb) * (a + bb) * (a + bb + 1.0));
+                mean = coef * (2.0 * bm - 1.0); var = coef * coef * 4.0 * bv;
+            } else {                                                     // :848-850
+                const double m = ((double)n_plus - (double)n_minus) / (double)n_shots;
+                mean = coef * m;
+                var = coef * coef * (1.0 - m * m) / (double)n_shots;
+            }
+            mean_out[s] = mean; var_out[s] = var;
+        }
+    }
+}
+
+}  // namespace fbx
+
+using namespace fbx;
+
+extern "C" {
+
+int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, const uint8_t* d_bits,
+                             const uint8_t* d_obs_mask, const double* d_coefs, int beta_prior,
+                             double* d_mean_out, double* d_var_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 64, "fbx_shots_to_moments: n_qubits must be 1..64");
+    FBX_REQUIRE(n_settings >= 0 && n_shots >= 1, "fbx_shots_to_moments: need n_settings >= 0 and n_shots >= 1");
+    FBX_REQUIRE(n_settings == 0 || (d_bits && d_obs_mask && d_mean_out && d_var_out), "fbx_shots_to_moments: NULL buffer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_settings == 0) return FBX_OK;
+    const unsigned grid = (unsigned)(n_settings < 256 * 16 ? n_settings : 256 * 16);
+    hipLaunchKernelGGL(shots_kernel, dim3(grid), dim3(256), 0, stream(), n_qubits, (long long)n_settings,
+                       (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_shots_to_moments(int n_qubits, int64_t n_settings, int64_t n_shots, const uint8_t* bits,
+                         const uint8_t* obs_mask, const double* coefs, int beta_prior,
+                         double* mean_out, double* var_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 64, "fbx_shots_to_moments: n_qubits must be 1..64");
+    FBX_REQUIRE(n_settings >= 0 && n_shots >= 1, "fbx_shots_to_moments: need n_settings >= 0 and n_shots >= 1");
+    FBX_REQUIRE(n_settings == 0 || (bits && obs_mask && mean_out && var_out), "fbx_shots_to_moments: NULL buffer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_settings == 0) return FBX_OK;
+    const size_t nb = (size_t)n_settings * n_shots * n_qubits, nm = (size_t)n_settings * n_qubits;
+    DevBuf db, dm, dc, dmean, dvar;
+    if ((rc = db.alloc(nb)) || (rc = dm.alloc(nm)) || (rc = dc.alloc(sizeof(double) * n_settings)) ||
+        (rc = dmean.alloc(sizeof(double) * n_settings)) || (rc = dvar.alloc(sizeof(double) * n_settings)))
+        return rc;
+    FBX_HIP(hipMemcpyAsync(db.p, bits, nb, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(dm.p, obs_mask, nm, hipMemcpyHostToDevice, stream()));
+    if (coefs) FBX_HIP(hipMemcpyAsync(dc.p, coefs, sizeof(double) * n_settings, hipMemcpyHostToDevice, stream()));
+    rc = fbx_shots_to_moments_dev(n_qubits, n_settings, n_shots, db.as<uint8_t>(), dm.as<uint8_t>(),
+                                  coefs ? dc.as<double>() : nullptr, beta_prior, dmean.as<double>(), dvar.as<double>());
+    if (rc) return rc;
+    FBX_HIP(hipMemcpyAsync(mean_out, dmean.p, sizeof(double) * n_settings, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipMemcpyAsync(var_out, dvar.p, sizeof(double) * n_settings, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
+
+}  // extern "C"

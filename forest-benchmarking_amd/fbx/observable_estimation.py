@@ -6,9 +6,12 @@ Plain-data mirrors of the reference classes the estimators consume
 to what the estimators read: ``term[qubit]`` and ``.coefficient``).  The estimators are
 duck-typed, so the reference's own objects work as well.
 """
+import ctypes as _C
 import re
 from dataclasses import dataclass
-from typing import Tuple, Union
+from typing import List, Tuple, Union
+
+import numpy as np
 
 
 @dataclass(frozen=True)
@@ -155,3 +158,49 @@ class ExperimentResult:
     calibration_expectation: Union[float, complex] = None
     calibration_std_err: Union[float, complex] = None
     calibration_counts: int = None
+
+
+# ==================================================================================================
+# shots -> moments (observable_estimation.py:804-853, :1052-1090): the step just before the estimators
+# ==================================================================================================
+def shots_to_obs_moments_batch(bitarrays, obs_masks, coefs=None, use_beta_dist_unbiased_prior=False):
+    """Mean and variance-of-the-mean of the +-1 products for S settings at once.
+
+    bitarrays [S, n_shots, n_qubits] of 0/1 (any integer dtype; converted to uint8),
+    obs_masks [S, n_qubits] non-zero where the setting's observable acts, coefs [S] (default 1)."""
+    from . import _lib
+    bits = np.ascontiguousarray(bitarrays, dtype=np.uint8)
+    if bits.ndim != 3:
+        raise ValueError("bitarrays must be [S, n_shots, n_qubits]")
+    S, shots, n = bits.shape
+    masks = np.ascontiguousarray(obs_masks, dtype=np.uint8).reshape(S, n)
+    cf = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64).reshape(S)
+    mean = np.empty(S)
+    var = np.empty(S)
+    u8 = _C.POINTER(_C.c_uint8)
+    _lib.check(_lib.lib().fbx_shots_to_moments(n, S, shots, bits.ctypes.data_as(u8), masks.ctypes.data_as(u8),
+                                               _lib.dptr(cf), int(bool(use_beta_dist_unbiased_prior)),
+                                               _lib.dptr(mean), _lib.dptr(var)))
+    return mean, var
+
+
+def shots_to_obs_moments(bitarray: np.ndarray, qubits: List[int], observable,
+                         use_beta_dist_unbiased_prior: bool = False) -> Tuple[float, float]:
+    """observable_estimation.py:804-853 with the reference's signature."""
+    coeff = complex(observable.coefficient)
+    if not np.isclose(coeff.imag, 0):
+        raise ValueError("The coefficient of an observable should not be complex.")
+    obs_qubits = [q for q, _ in observable]
+    mask = np.array([1 if q in obs_qubits else 0 for q in qubits], dtype=np.uint8)
+    if not mask.any():                      # identity term
+        return coeff.real, 0
+    bitarray = np.asarray(bitarray)
+    assert bitarray.shape[1] == len(qubits), 'qubits should label each column of the bitarray'
+    mean, var = shots_to_obs_moments_batch(bitarray[None], mask[None], [coeff.real],
+                                           use_beta_dist_unbiased_prior)
+    return float(mean[0]), float(var[0])
+
+
+def ratio_variance(a, var_a, b, var_b):
+    """observable_estimation.py:1052-1090: Var[A/B] ~ var_a / b^2 + a^2 var_b / b^4 (element-wise)."""
+    return var_a / b ** 2 + (a ** 2 * var_b) / b ** 4

@@ -177,6 +177,21 @@ int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double*
                        double* purity_out, double* fidelity_out, double* trace_dist_out,
                        double* hs_ip_out);
 
+/* ---------------------------------------------------------------- shots -> moments
+ * shots_to_obs_moments (observable_estimation.py:804-853), the reduction immediately before the
+ * estimators: for each of n_settings settings, bits[s] is a [n_shots][n_qubits] array of 0/1 bytes
+ * (one row per shot, as qc.run returns it), obs_mask[s][q] != 0 where the setting's observable acts
+ * on column q, coefs[s] its real coefficient (NULL = 1).  mean_out[s] = coef * mean of the +-1
+ * products, var_out[s] = variance of that mean (coef^2 (1 - m^2) / n_shots), or the Beta(n+ + 1,
+ * n- + 1) moments when beta_prior != 0 (use_beta_dist_unbiased_prior).  An all-zero mask is the
+ * identity term: (coef, 0). */
+int fbx_shots_to_moments(int n_qubits, int64_t n_settings, int64_t n_shots, const uint8_t* bits,
+                         const uint8_t* obs_mask, const double* coefs, int beta_prior,
+                         double* mean_out, double* var_out);
+int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, const uint8_t* d_bits,
+                             const uint8_t* d_obs_mask, const double* d_coefs, int beta_prior,
+                             double* d_mean_out, double* d_var_out);
+
 /* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
  * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16}.  This is the
  * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators

@@ -19,4 +19,4 @@ in :mod:`fbx_oracle.design` from its published algorithm.
 Every function cites the reference file:line it follows (paths relative to
 ``forest/benchmarking/`` of rigetti/forest-benchmarking v0.9.0).
 """
-from . import design, superops, measures, estimators  # noqa: F401
+from . import design, superops, measures, estimators, acquisition  # noqa: F401

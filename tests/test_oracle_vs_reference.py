@@ -114,3 +114,20 @@ def test_operator_tools_random(ref):
             assert np.isclose(getattr(DM, name)(rho, sig), getattr(om, name)(rho, sig), atol=1e-13), name
         assert np.isclose(DM.purity(rho), om.purity(rho))
         assert np.allclose(DM.watrous_bounds(h), om.watrous_bounds(h))
+
+
+def test_shots_to_obs_moments(ref):
+    from fbx_oracle import acquisition as oa
+    OE = ref.observable_estimation
+    rs = np.random.RandomState(9)
+    qubits = [3, 0, 5]
+    bits = (rs.uniform(size=(500, 3)) < 0.3).astype(int)
+    for ops, coef in (({3: "X", 5: "Z"}, 1.0), ({0: "Y"}, -0.7), ({}, 2.0), ({3: "Z", 0: "Z", 5: "Z"}, 1.0)):
+        term = ref.PauliTerm("I", 0, coef)
+        term._ops = dict(ops)
+        mask = [1 if q in ops else 0 for q in qubits]
+        for prior in (False, True):
+            want = OE.shots_to_obs_moments(bits, qubits, term, prior)
+            got = oa.shots_to_obs_moments(bits, mask, coef, prior)
+            assert np.allclose(want, got, rtol=0, atol=1e-15)
+    assert OE.ratio_variance(1.0, 0.1, 2.0, 0.05) == oa.ratio_variance(1.0, 0.1, 2.0, 0.05) == 0.028125
