@@ -217,9 +217,9 @@ __device__ __forceinline__ int insert_zero_bits2(int v, int lo, int hi) {   // l
     r = (r & ((1 << hi) - 1)) | ((r >> hi) << (hi + 1));
     return r;
 }
-template <int NQ, bool INVERSE>
+template <int NQ, bool INVERSE, int LDM = (1 << (2 * NQ)) + 1>
 __device__ __forceinline__ void pauli_site_stage(cplx* M, int lane, int pbit, int qbit, double ysign) {
-    constexpr int D = 1 << (2 * NQ), LD = D + 1, NQUAD = D * D / 4;
+    constexpr int D = 1 << (2 * NQ), LD = LDM, NQUAD = D * D / 4;
     if (lane < NQUAD) {
         const int lo = pbit < qbit ? pbit : qbit, hi = pbit < qbit ? qbit : pbit;
         const int base = insert_zero_bits2(lane, lo, hi);

@@ -102,6 +102,22 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
+// sum over all NT threads of the workgroup (every thread receives the same total, summed in one
+// fixed order); `red` is NT/64 doubles of LDS scratch, unused for single-wave workgroups
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    if constexpr (NT > 64) {
+        __syncthreads();                       // earlier readers of `red` are done
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) s += red[w];
+        return s;
+    }
+    return v;
+}
 // make a wave-uniform copy (lane 0's value) so branches on it are scalar
 __device__ __forceinline__ double uniform(double v) {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));

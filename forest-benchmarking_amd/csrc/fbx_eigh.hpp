@@ -238,10 +238,11 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 // the wave must call; (N/2)^2 of them work.  Returns the number of sweeps.
 //
 // Simple form (any even N <= 16): every lane derives its two rotations from the pivots in LDS.
-template <int N>
-__device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true) {
+template <int N, int NT = 64>
+__device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true,
+                                  double* red = nullptr) {
     constexpr int NB = N / 2, LS = NB * NB;
-    static_assert(LS <= 64, "one wavefront per matrix");
+    static_assert(LS <= NT, "one lane per 2x2 block");
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
     const int me = act ? lane : 0;
@@ -273,8 +274,8 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
                 if (!(I == J && (e == 0 || e == 3))) o2 += a2;
             }
             if (!act) { o2 = 0.0; n2 = 0.0; }
-            o2 = uniform(wave_sum(o2));
-            n2 = uniform(wave_sum(n2));
+            o2 = uniform(block_sum<NT>(o2, red));
+            n2 = uniform(block_sum<NT>(n2, red));
             if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
@@ -446,14 +447,14 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     __syncthreads();
 }
 
-template <int N>
+template <int N, int NT = 64>
 __device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, int lane,
-                                               bool init_identity = true) {
+                                               bool init_identity = true, double* red = nullptr) {
 #ifdef FBX_JACOBI_PIPELINED     // measured equal-or-slower than the simple form at 1 wave/SIMD
-    if constexpr (N >= 6) return jacobi_eigh_pipelined<N>(Ms, Vs, rec, lane);
+    if constexpr (N >= 6 && NT == 64) return jacobi_eigh_pipelined<N>(Ms, Vs, rec, lane);
 #endif
     (void)rec;
-    return jacobi_eigh_simple<N>(Ms, Vs, lane, init_identity);
+    return jacobi_eigh_simple<N, NT>(Ms, Vs, lane, init_identity, red);
 }
 
 // block (I, J) of sum_k lam[k] v_k v_k^H for the eigenvectors in Vs (element-major layout);

@@ -319,6 +319,9 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     return FBX_OK;
 }
 
+int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost);   // fbx_pgdb3.hip
+
 static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                          int mode, int max_iters, double* choi, int32_t* it, int32_t* dy,
                          int32_t* bt, double* cost) {
@@ -331,7 +334,10 @@ static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, cons
         if (m <= 576) return launch_pgdb<2, 9>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
         if (m <= 1024) return launch_pgdb<2, 16>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
     }
-    set_error("fbx_pgdb_process: this build handles 1- and 2-qubit designs (m <= 256 / 1024)");
+    else if (n == 3) {
+        return pgdb3_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+    }
+    set_error("fbx_pgdb_process: design outside the supported sizes (1 qubit m <= 256, 2 qubits m <= 1024)");
     return FBX_ERR_UNSUPPORTED;
 }
 

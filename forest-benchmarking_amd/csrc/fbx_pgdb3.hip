@@ -1,0 +1,403 @@
+// fbx_pgdb3.hip -- 3-qubit (64 x 64 Choi) projected-gradient process tomography
+// (BASELINE config 4).  Same algorithm and the same device routines as the 2-qubit kernel
+// (fbx_pgdb.hip), re-mapped to ONE 1024-THREAD WORKGROUP PER RECONSTRUCTION: the 64 x 64 matrices
+// are held as one 2x2 block per thread on a 32 x 32 thread grid, the systolic Jacobi runs with all
+// 16 wavefronts (63 rounds per sweep, two workgroup barriers per round), and the 160 KiB of LDS are
+// used to the byte:
+//     [ Ms 64 KiB | Vs 64 KiB (aliased by the row-major staging matrix Mw) | R 32 KiB ]
+// with the prediction tables T[s][i] / the gradient accumulator W[i][s] (up to 108 KiB for the
+// Pauli in-basis) overlaying Ms + Vs between projections, and the small Dykstra scratch overlaying R.
+// The Bloch matrix C (D x S doubles, 108 KiB for the Pauli in-basis) is read from L2.
+//
+// Reference: tomography.py:542-633, operator_tools/project_superoperators.py:19-144.
+#include "fbx_choi.hpp"
+
+namespace fbx {
+
+namespace p3 {
+constexpr int NQ = 3, d = 8, D = 64, NB = 32, NT = 1024, LD = 64, LDs = d + 1;
+constexpr double EPS = 1e-6, GAMMA = 0.3, STOP = 1e-10, ALPHA_MIN = 1e-15;
+
+struct Lds {
+    cplx* Ms;        // [4096] Jacobi work matrix (element-major)
+    cplx* Vs;        // [4096] eigenvectors
+    cplx* Mw;        // = Vs: row-major 64 x 64 staging (partial trace, Pauli butterflies)
+    double* T;       // = Ms..: prediction table [S][64] / gradient accumulator W[64][S]
+    double* Rt;      // [4096] Pauli coefficients, TRANSPOSED: Rt[j * 64 + i] = R[i][j]
+    // overlay on Rt (alive only while R is dead):
+    cplx* pt; cplx* pts; cplx* ptV; double* lam; double* red;
+    __device__ void carve(char* p) {
+        Ms = (cplx*)p; Vs = Ms + D * D; Mw = Vs; T = (double*)p;
+        Rt = (double*)(p + 2 * sizeof(cplx) * D * D);
+        char* q = (char*)Rt;
+        pt = (cplx*)q; q += sizeof(cplx) * d * LDs;
+        pts = (cplx*)q; q += sizeof(cplx) * d * d;
+        ptV = (cplx*)q; q += sizeof(cplx) * d * d;
+        lam = (double*)q; q += sizeof(double) * D;
+        red = (double*)q;
+    }
+    static constexpr size_t bytes() { return 2 * sizeof(cplx) * D * D + sizeof(double) * D * D; }
+};
+
+__device__ __forceinline__ double bsum(double v, Lds& L) { return block_sum<NT>(v, L.red); }
+
+// ---- CP projection (project_superoperators.py:19-34)
+__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps) {
+    __syncthreads();
+    sys_store<D>(L.Ms, t, x);
+    __syncthreads();
+    const Blk xa = sys_load_adjoint<D>(L.Ms, t);
+    Blk h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (x.re[e] + xa.re[e]); h.im[e] = 0.5 * (x.im[e] + xa.im[e]); }
+    __syncthreads();
+    sys_store<D>(L.Ms, t, h);
+    __syncthreads();
+    sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, true, L.red);
+    if (t < D) {
+        const double l = L.Ms[sys_index<D>(t, t)].re;
+        L.lam[t] = l < 0.0 ? 0.0 : l;
+    }
+    __syncthreads();
+    return reconstruct_blk<D>(L.Vs, L.lam, t);
+}
+
+// ---- partial trace over the output space into L.pt (calculational.py:5-35); stages x through Mw
+__device__ void partial_trace_out(const Blk& x, Lds& L, int t) {
+    __syncthreads();                                   // readers of Vs (reconstruct) are done
+    blk_store<D, LD>(L.Mw, t, x);
+    __syncthreads();
+    if (t < d * d) {
+        const int i = t / d, ip = t % d;
+        cplx s; s.re = 0.0; s.im = 0.0;
+#pragma unroll
+        for (int o = 0; o < d; ++o) { const cplx v = L.Mw[(i * d + o) * LD + ip * d + o]; s.re += v.re; s.im += v.im; }
+        L.pt[i * LDs + ip] = s;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const Lds& L, int t) {
+    Blk r = x;
+    const int I = t / NB, J = t % NB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+        if ((row % d) == (col % d)) { const cplx c = L.pt[(row / d) * LDs + (col / d)]; r.re[e] -= c.re / d; r.im[e] -= c.im / d; }
+    }
+    return r;
+}
+__device__ Blk proj_tp(const Blk& x, Lds& L, int t) {                 // project_superoperators.py:62-84
+    partial_trace_out(x, L, t);
+    if (t < d) L.pt[t * LDs + t].re -= 1.0;
+    __syncthreads();
+    return subtract_kron_pt(x, L, t);
+}
+__device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project_superoperators.py:37-59
+    partial_trace_out(x, L, t);
+    const Blk ptb = blk_load<d, LDs>(L.pt, t);
+    const Blk pta = blk_load_adjoint<d, LDs>(L.pt, t);
+    Blk h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (ptb.re[e] + pta.re[e]); h.im[e] = 0.5 * (ptb.im[e] + pta.im[e]); }
+    __syncthreads();
+    sys_store<d>(L.pts, t, h);
+    __syncthreads();
+    sweeps += jacobi_eigh_simple<d, NT>(L.pts, L.ptV, t, true, L.red);
+    if (t < d) { const double l = L.pts[sys_index<d>(t, t)].re; L.lam[t] = l > 1.0 ? 1.0 : l; }
+    __syncthreads();
+    const Blk proj = reconstruct_blk<d>(L.ptV, L.lam, t);
+    __syncthreads();
+    blk_store<d, LDs>(L.pt, t, blk_sub(ptb, proj));
+    __syncthreads();
+    return subtract_kron_pt(x, L, t);
+}
+
+// ---- Dykstra (project_superoperators.py:87-144)
+__device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, int& sweeps) {
+    Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
+    Blk last_state = x, new_state = x;
+    for (int it = 0; it < 100000; ++it) {
+        ++iters;
+        const Blk pre_cp = blk_sub(last_state, old_cp);
+        const Blk cp = proj_cp(pre_cp, L, t, sweeps);
+        const Blk new_cp = blk_sub(cp, pre_cp);
+        const Blk pre_tp = blk_sub(cp, old_tp);
+        new_state = tp ? proj_tp(pre_tp, L, t) : proj_tni(pre_tp, L, t, sweeps);
+        const Blk new_tp = blk_sub(new_state, pre_tp);
+        double s1 = blk_norm2(blk_sub(new_cp, old_cp)), s2 = blk_norm2(blk_sub(new_tp, old_tp));
+        double i1r, i1i, i2r, i2i;
+        blk_dotc(old_tp, blk_sub(new_state, last_state), i1r, i1i);
+        blk_dotc(old_cp, blk_sub(cp, last_cp), i2r, i2i);
+        s1 = bsum(s1, L); s2 = bsum(s2, L);
+        i1r = bsum(i1r, L); i1i = bsum(i1i, L); i2r = bsum(i2r, L); i2i = bsum(i2i, L);
+        const double crit = s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
+        if (crit < 1e-4) break;
+        old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
+    }
+    return new_state;
+}
+
+// ---- Choi (in registers) -> transposed Pauli coefficients Rt (uses Mw = Vs as staging)
+__device__ void choi_to_pauli(const Blk& x, Lds& L, int t) {
+    __syncthreads();
+    blk_store<D, LD>(L.Mw, t, x);
+    __syncthreads();
+#pragma unroll
+    for (int s = NQ - 1; s >= 0; --s) { pauli_site_stage<NQ, false, LD>(L.Mw, t, 2 * NQ + NQ + s, NQ + s, -1.0); __syncthreads(); }
+#pragma unroll
+    for (int s = NQ - 1; s >= 0; --s) { pauli_site_stage<NQ, false, LD>(L.Mw, t, 2 * NQ + s, s, +1.0); __syncthreads(); }
+    for (int idx = t; idx < D * D; idx += NT) {
+        const int i = idx % D, j = idx / D;           // idx = j * 64 + i: coalesced Rt writes
+        int row, col;
+        pauli_coeff_position<NQ>(i, j, row, col);
+        L.Rt[idx] = L.Mw[row * LD + col].re / d;
+    }
+    __syncthreads();
+}
+// ---- transposed Pauli coefficients Rt -> Choi block (Mw = Vs as scratch)
+__device__ Blk pauli_to_choi(Lds& L, int t) {
+    __syncthreads();
+    for (int idx = t; idx < D * D; idx += NT) {
+        const int i = idx % D, j = idx / D;
+        int row, col;
+        pauli_coeff_position<NQ>(i, j, row, col);
+        cplx v; v.re = L.Rt[idx] * d; v.im = 0.0;
+        L.Mw[row * LD + col] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) { pauli_site_stage<NQ, true, LD>(L.Mw, t, 2 * NQ + s, s, +1.0); __syncthreads(); }
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) { pauli_site_stage<NQ, true, LD>(L.Mw, t, 2 * NQ + NQ + s, NQ + s, -1.0); __syncthreads(); }
+    const Blk out = blk_load<D, LD>(L.Mw, t);
+    __syncthreads();
+    return out;
+}
+// ---- T[s][i] = sum_j R[i][j] C[j][s]  (T overlays Ms..; C from global memory)
+__device__ void predict_table(const DesignDev& des, Lds& L, int t) {
+    const int S = des.S;
+    __syncthreads();
+    for (int idx = t; idx < S * D; idx += NT) {
+        const int s = idx / D, i = idx % D;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < D; ++j) acc += L.Rt[j * D + i] * des.C[j * S + s];
+        L.T[idx] = acc;
+    }
+    __syncthreads();
+}
+}  // namespace p3
+
+template <int MAXJ>
+__global__ void __launch_bounds__(1024)
+pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
+             int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out,
+             int* __restrict__ iters_out, int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
+             double* __restrict__ cost_out) {
+    using namespace p3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds L; L.carve(smem);
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    const int m = des.m, S = des.S;
+    const bool unit_coefs = des.unit_coefs != 0;
+
+    double npl[MAXJ], nmi[MAXJ];
+    uint32_t spw[MAXJ];
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int g = t * MAXJ + j;
+        npl[j] = 0.0; nmi[j] = 0.0; spw[j] = 0u;
+        if (g < m) {
+            const int k = des.order[g];
+            const double e = expect[item * m + k], c = counts[item * m + k];
+            const double plus = (1.0 + e) / 2.0;
+            npl[j] = c * plus; nmi[j] = c * (1.0 - plus);
+            tot += c;
+            spw[j] = des.sp[g];
+        }
+    }
+    tot = bsum(tot, L);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { npl[j] /= tot; nmi[j] /= tot; }
+    const double half_dd = 0.5 / (double)(d * d), inv_mu = (2.0 * d * d) / 3.0;
+
+    double pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
+    auto load_probs = [&](double (&pp)[MAXJ], double (&pm)[MAXJ]) {
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = t * MAXJ + j;
+            if (g < m) {
+                const int s = spw[j] >> 16, p = spw[j] & 0xffff;
+                const double cf = unit_coefs ? 1.0 : des.coef[g];
+                const double tr = L.T[s * D], ex = cf * L.T[s * D + p];
+                pp[j] = (tr + ex) * half_dd; pm[j] = (tr - ex) * half_dd;
+            }
+        }
+    };
+    auto cost_at = [&](double alpha) -> double {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = t * MAXJ + j;
+            if (g < m) {
+                double pp = fma(alpha, pup[j], pep[j]), pm = fma(alpha, pum[j], pem[j]);
+                pp = pp < EPS ? EPS : pp; pm = pm < EPS ? EPS : pm;
+                acc -= npl[j] * fast_log_pos(pp) + nmi[j] * fast_log_pos(pm);
+            }
+        }
+        return bsum(acc, L);
+    };
+
+    Blk est = blk_zero();
+    { const int I = t / NB, J = t % NB; if (I == J) { est.re[0] = 1.0 / d; est.re[3] = 1.0 / d; } }
+    int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
+    double old_cost = 0.0, new_cost = 0.0;
+    bool have_cost = false;
+
+    while (true) {
+        if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
+        choi_to_pauli(est, L, t);
+        predict_table(des, L, t);
+        load_probs(pep, pem);
+        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }
+
+        // ---- gradient (tomography.py:617-633): W[i][s] = sum over the settings of state s.
+        // Threads own CONTIGUOUS runs of the state-grouped settings, so the identity row W[0][s]
+        // (one term per setting of the state) is reduced deterministically: a run that lies inside
+        // one thread is written directly, the first / last run of every thread goes to a partial
+        // array that one thread per state adds up in thread order.  The W[p][s] cells receive one
+        // term each (LDS atomics only matter for designs that repeat a setting).
+        __syncthreads();                              // T fully consumed
+        double* W = L.T;
+        double* pfirst = L.Rt + 512;                  // overlays R (dead here), past the small scratch
+        double* plast = pfirst + NT;
+        int* sfirst = (int*)(plast + NT);
+        int* slast = sfirst + NT;
+        for (int idx = t; idx < D * S; idx += NT) W[idx] = 0.0;
+        sfirst[t] = -1; slast[t] = -1; pfirst[t] = 0.0; plast[t] = 0.0;
+        __syncthreads();
+        {
+            int run_state = -1, first_state = -1; double run = 0.0; bool first_done = false;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int g = t * MAXJ + j;
+                if (g < m) {
+                    const int s = spw[j] >> 16, p = spw[j] & 0xffff;
+                    const double cf = unit_coefs ? 1.0 : des.coef[g];
+                    const double pp = pep[j] < EPS ? EPS : pep[j], pm = pem[j] < EPS ? EPS : pem[j];
+                    const double ep = npl[j] / pp, em = nmi[j] / pm;
+                    atomicAdd(&W[p * S + s], cf * 0.5 * (ep - em));
+                    if (s != run_state) {
+                        if (run_state >= 0) {                      // flush the finished run
+                            if (!first_done) { pfirst[t] = run; sfirst[t] = run_state; first_done = true; }
+                            else atomicAdd(&W[run_state], run);    // interior run: sole contributor
+                        }
+                        run_state = s; run = 0.0;
+                        if (first_state < 0) first_state = s;
+                    }
+                    run += 0.5 * (ep + em);
+                }
+            }
+            if (run_state >= 0) {
+                if (!first_done) { pfirst[t] = run; sfirst[t] = run_state; }
+                else { plast[t] = run; slast[t] = run_state; }
+            }
+        }
+        __syncthreads();
+        for (int s = t; s < S; s += NT) {
+            const int g0 = des.sptr[s], g1 = des.sptr[s + 1];
+            if (g1 > g0) {
+                double acc = 0.0;
+                for (int tt = g0 / MAXJ; tt <= (g1 - 1) / MAXJ; ++tt) {
+                    if (sfirst[tt] == s) acc += pfirst[tt];
+                    if (slast[tt] == s) acc += plast[tt];
+                }
+                W[s] += acc;
+            }
+        }
+        __syncthreads();
+        for (int idx = t; idx < D * D; idx += NT) {                    // Rg[i][j] = -(1/d^2) sum_s W[i][s] C[j][s]
+            const int i = idx % D, j = idx / D;
+            double acc = 0.0;
+            for (int s = 0; s < S; ++s) acc += W[i * S + s] * des.C[j * S + s];
+            L.Rt[idx] = -acc / (double)(d * d);
+        }
+        __syncthreads();
+        const Blk grad = pauli_to_choi(L, t);
+
+        const Blk x = blk_axpy(est, -inv_mu, grad);
+        const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps);
+        const Blk upd = blk_sub(proj, est);
+
+        choi_to_pauli(upd, L, t);
+        predict_table(des, L, t);
+        load_probs(pup, pum);
+
+        double ipr, ipi;
+        blk_dotc(upd, grad, ipr, ipi);
+        ipr = bsum(ipr, L);
+        double alpha = 1.0;
+        new_cost = cost_at(alpha);
+        double change = GAMMA * alpha * ipr;
+        while (new_cost > old_cost + change) {
+            alpha *= 0.5; change *= 0.5;
+            new_cost = cost_at(alpha);
+            ++backtracks;
+            if (alpha < ALPHA_MIN) break;
+        }
+        est = blk_axpy(est, alpha, upd);
+        ++iters;
+        if (mode == FBX_MODE_CONVERGE) {
+            if (old_cost - new_cost < STOP) break;
+            if (max_iters > 0 && iters >= max_iters) break;
+        }
+        old_cost = new_cost;
+    }
+    {
+        const int I = t / NB, J = t % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+            double* o = choi_out + ((item * D + row) * D + col) * 2;
+            o[0] = est.re[e]; o[1] = est.im[e];
+        }
+    }
+    if (t == 0) {
+        if (iters_out) iters_out[item] = iters;
+        if (dykstra_out) dykstra_out[item] = dyk;
+        if (backtracks_out) backtracks_out[item] = backtracks;
+        if (cost_out) cost_out[item] = have_cost ? new_cost : 0.0;
+    }
+}
+
+template <int MAXJ>
+static int launch3(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost) {
+    const size_t lds = p3::Lds::bytes();
+    if ((size_t)des->dev.S * p3::D * sizeof(double) > 2 * sizeof(cplx) * p3::D * p3::D) {
+        set_error("fbx_pgdb_process: too many distinct input states for the 3-qubit kernel");
+        return FBX_ERR_UNSUPPORTED;
+    }
+    auto kern = pgdb3_kernel<MAXJ>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(1024), lds, stream(), des->dev, (long long)B, e, c, tp, mode,
+                       max_iters, choi, it, dy, bt, cost);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+// called from fbx_pgdb.hip's dispatcher
+int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost) {
+    const int m = des->dev.m;
+    if (m <= 4096) return launch3<4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+    if (m <= 14336) return launch3<14>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+    set_error("fbx_pgdb_process: 3-qubit designs are limited to 14336 settings");
+    return FBX_ERR_UNSUPPORTED;
+}
+
+}  // namespace fbx

@@ -58,6 +58,20 @@ def make_process(n, basis, batch, tni_items):
     print("process", n, basis, "done")
 
 
+def make_process_3q():
+    """BASELINE config 4 shape: 3 qubits, SIC in-basis (4032 settings), one item -- the reference's
+    pgdb_process_estimate run to convergence (about a minute here)."""
+    qubits = [0, 1, 2]
+    design, us, e, c = synthetic.process_batch(3, "sic", 1)
+    settings = process_settings(qubits, "sic")
+    assert len(settings) == design.m
+    res = ref_results(settings, e[0], c[0])
+    est = T.pgdb_process_estimate(res, qubits)
+    np.savez_compressed(os.path.join(HERE, "process_3q_sic.npz"), n_qubits=3, unitaries=us,
+                        expectations=e, counts=c, pgdb=est[None])
+    print("process 3 sic done")
+
+
 def make_state(n, batch):
     qubits = list(range(n))
     design, rhos, e, c = synthetic.state_batch(n, batch, mixed=0.1)
@@ -154,6 +168,9 @@ def make_superops(n, batch):
 
 if __name__ == "__main__":
     np.random.seed(0)
+    if "--3q" in sys.argv:
+        make_process_3q()
+        sys.exit(0)
     make_process(1, "pauli", 6, 3)
     make_process(1, "sic", 6, 3)
     make_process(2, "sic", 4, 2)

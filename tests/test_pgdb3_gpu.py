@@ -1,0 +1,59 @@
+"""3-qubit (64 x 64 Choi) PGDB process tomography -- BASELINE config 4 -- vs the reference golden
+(one converged SIC-basis reconstruction produced by forest.benchmarking itself) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_converged_estimate_matches_reference_golden(gpu):
+    from fbx import tomography
+    from fbx.design import process_design
+    g = np.load(os.path.join(GOLD, "process_3q_sic.npz"))
+    design = process_design(3, "sic")
+    assert design.m == 4032 == g["expectations"].shape[1]
+    got, st = tomography.pgdb_process_estimate_batch(design, g["expectations"], g["counts"], return_stats=True)
+    assert np.abs(got - g["pgdb"]).max() < 1e-9
+    # physical sanity of the estimate itself: Hermitian, trace preserving
+    assert np.abs(got[0] - got[0].conj().T).max() < 1e-12
+    pt = np.einsum("iojo->ij", got[0].reshape(8, 8, 8, 8))
+    assert np.abs(pt - np.eye(8)).max() < 1e-12
+    from fbx_oracle import measures as om, superops as so
+    f = om.process_fidelity(so.kraus2pauli_liouville(g["unitaries"][0]), so.choi2pauli_liouville(got[0]))
+    f_ref = om.process_fidelity(so.kraus2pauli_liouville(g["unitaries"][0]), so.choi2pauli_liouville(g["pgdb"][0]))
+    assert abs(f - f_ref) < 1e-8 and f > 0.8
+
+
+def test_few_iterations_match_oracle_incl_counts(gpu):
+    """Fixed 3 outer iterations against the dense-A oracle (8064 x 4096 design matrix), two items,
+    trace-preserving and trace-non-increasing."""
+    from fbx import synthetic, tomography
+    from fbx_oracle import design as od, estimators as oe
+    design, us, e, c = synthetic.process_batch(3, "sic", 2, first_item=5)
+    d = od.Design(3, "process", design.in_labels, design.paulis, design.coefs)
+    A = oe.design_matrix_A(d)
+    for tp in (True, False):
+        got, st = tomography.pgdb_process_estimate_batch(design, e, c, trace_preserving=tp, mode="fixed",
+                                                         max_iters=3, return_stats=True)
+        for b in range(2):
+            want, ws = oe.pgdb_process_estimate(d, e[b], c[b], trace_preserving=tp, A=A, mode="fixed",
+                                                max_iters=3, return_stats=True)
+            assert np.abs(got[b] - want).max() < 1e-11
+            assert st["dykstra"][b] == ws["dykstra"] and st["backtracks"][b] == ws["backtracks"]
+            assert abs(st["cost"][b] - ws["cost"]) < 1e-11
+
+
+def test_batch_of_256_properties(gpu):
+    """Config 4 size (batch 256): every item Hermitian + trace preserving, duplicates bit-identical."""
+    from fbx import synthetic, tomography
+    design, us, e, c = synthetic.process_batch(3, "sic", 32)
+    e = np.tile(e, (8, 1)); c = np.tile(c, (8, 1))
+    got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=10, return_stats=True)
+    assert (st["iterations"] == 10).all()
+    assert np.abs(got - got.conj().transpose(0, 2, 1)).max() < 1e-12
+    pt = np.einsum("biojo->bij", got.reshape(-1, 8, 8, 8, 8))
+    assert np.abs(pt - np.eye(8)).max() < 1e-12
+    assert np.array_equal(got[:32], got[224:])
