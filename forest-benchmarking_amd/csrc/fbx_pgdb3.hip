@@ -173,16 +173,54 @@ __device__ Blk pauli_to_choi(Lds& L, int t) {
     __syncthreads();
     return out;
 }
-// ---- T[s][i] = sum_j R[i][j] C[j][s]  (T overlays Ms..; C from global memory)
+// ---- T[s][i] = sum_j R[i][j] C[j][s]: the dense basis-change GEMM of the 3-qubit path
+// ([S x 64] = C^T [S x 64] . R^T [64 x 64]) on the fp64 matrix cores.  v_mfma_f64_16x16x4_f64:
+// lane l feeds A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; its four accumulators are
+// D[row = (l >> 4) + 4 r][col = l & 15].  B = Rt is already [k][n] row-major in LDS; A = C^T comes
+// from L2 (C is [64][S]).  16 waves share the ceil(S/16) x 4 output tiles.
+typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ void predict_table(const DesignDev& des, Lds& L, int t) {
     const int S = des.S;
+    const int lane = t & 63, wave = t >> 6;
+    const int mtiles = (S + 15) / 16;
     __syncthreads();
-    for (int idx = t; idx < S * D; idx += NT) {
-        const int s = idx / D, i = idx % D;
-        double acc = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < D; ++j) acc += L.Rt[j * D + i] * des.C[j * S + s];
-        L.T[idx] = acc;
+    for (int tile = wave; tile < mtiles * 4; tile += NT / 64) {
+        const int ms = tile / 4, ni = tile % 4;
+        const int srow = ms * 16 + (lane & 15);
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int kk = 0; kk < D / 4; ++kk) {
+            const int k = 4 * kk + (lane >> 4);
+            const double a = srow < S ? des.C[k * S + srow] : 0.0;
+            const double b = L.Rt[k * D + ni * 16 + (lane & 15)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int srw = ms * 16 + (lane >> 4) + 4 * r;
+            if (srw < S) L.T[srw * D + ni * 16 + (lane & 15)] = acc[r];
+        }
+    }
+    __syncthreads();
+}
+// ---- Rt[j][i] = -(1/d^2) sum_s W[i][s] C[j][s]  ([64 x 64] = W [64 x S] . C^T [S x 64]), one
+// 16 x 16 output tile per wave; W from LDS, C from L2.  S is padded with zero terms to a multiple of 4.
+__device__ void gradient_coefficients(const DesignDev& des, Lds& L, const double* W, int t) {
+    const int S = des.S;
+    const int lane = t & 63, wave = t >> 6;
+    const int mi = wave / 4, nj = wave % 4;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < S; k0 += 4) {
+        const int k = k0 + (lane >> 4);
+        const double a = k < S ? W[(mi * 16 + (lane & 15)) * S + k] : 0.0;
+        const double b = k < S ? des.C[(nj * 16 + (lane & 15)) * S + k] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();                                   // Rt overlays the partial arrays read above
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = mi * 16 + (lane >> 4) + 4 * r, j = nj * 16 + (lane & 15);
+        L.Rt[j * D + i] = -acc[r] / (double)(d * d);
     }
     __syncthreads();
 }
@@ -320,13 +358,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
             }
         }
         __syncthreads();
-        for (int idx = t; idx < D * D; idx += NT) {                    // Rg[i][j] = -(1/d^2) sum_s W[i][s] C[j][s]
-            const int i = idx % D, j = idx / D;
-            double acc = 0.0;
-            for (int s = 0; s < S; ++s) acc += W[i * S + s] * des.C[j * S + s];
-            L.Rt[idx] = -acc / (double)(d * d);
-        }
-        __syncthreads();
+        gradient_coefficients(des, L, W, t);
         const Blk grad = pauli_to_choi(L, t);
 
         const Blk x = blk_axpy(est, -inv_mu, grad);
