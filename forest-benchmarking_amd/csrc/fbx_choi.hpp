@@ -25,7 +25,7 @@ struct ChoiLds {
     cplx* Ms;      // [D * D]    Jacobi work matrix, element-major block layout
     cplx* Vs;      // [D * D]    eigenvectors, same layout
     double* lam;   // [D]
-    JRec* rec;     // [D / 2]    published rotations of the pipelined Jacobi
+    JRec* rec;     // [D / 2 + 1] rotation records (scratch)
     cplx* pt;      // [d * LDs]  partial trace (d x d), row-major
     cplx* pts;     // [d * d]    partial trace in the Jacobi layout (TNI only)
     cplx* ptV;     // [d * d]    its eigenvectors (TNI only)

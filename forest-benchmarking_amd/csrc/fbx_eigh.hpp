@@ -229,7 +229,7 @@ __device__ __forceinline__ void jacobi_apply_v(double cJ, double sJr, double sJi
     v0p = u0; v0q = w0; v1p = u1; v1q = w1;
 }
 
-// LDS scratch of the pipelined solver: one 48-byte record per pair
+// per-pair record {c, s, rotated diagonal}; small LDS scratch reserved for publishing rotations
 struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 
 // In-LDS Hermitian eigendecomposition A = V diag(w) V^H.  On entry Ms holds the Hermitian matrix
@@ -237,7 +237,7 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 // sys_index(k, k)) and Vs holds the eigenvectors as columns in the same layout.  All 64 lanes of
 // the wave must call; (N/2)^2 of them work.  Returns the number of sweeps.
 //
-// Simple form (any even N <= 16): every lane derives its two rotations from the pivots in LDS.
+// Every lane derives the two rotations it needs from the pivot blocks in LDS.
 template <int N, int NT = 64>
 __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true,
                                   double* red = nullptr) {
@@ -308,95 +308,6 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
     return sweep;
 }
 
-// Pipelined form (N >= 6): the rotation of next round's pair k depends only on the rotated
-// diagonals of two current pivots and on ONE entry of ONE lane's updated block, so that lane
-// computes it right after its own update and publishes a 48-byte record {c, s, a', d'}.  Lanes
-// then read two records per round instead of six pivot entries and evaluate one rotation chain
-// instead of two, and that chain overlaps the rest of the block update.
-template <int N>
-__device__ int jacobi_eigh_pipelined(cplx* Ms, cplx* Vs, JRec* rec, int lane) {
-    constexpr int NB = N / 2, LS = NB * NB;
-    static_assert(LS <= 64 && N >= 6, "one wavefront per matrix; distinct source pairs");
-    const bool act = lane < LS;
-    const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
-    const int me = act ? lane : 0;
-    int wm[4], wv[4];
-    int nk = -1, ne = 0;            // next-round pair this lane feeds, and with which block entry
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
-        wm[e] = ((sa & 1) * 2 + (sb & 1)) * LS + (sa >> 1) * NB + (sb >> 1);
-        wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
-        if (act && I != J && (sa & 1) == 0 && sb == sa + 1) { nk = sa >> 1; ne = e; }
-    }
-    const int recSlot = nk >= 0 ? nk : NB;     // rec has NB + 1 slots; the last one is a sink
-    const bool rowSecond = (ne >> 1) != 0, colSecond = (ne & 1) != 0;
-    cplx m00, m01, m10, m11;
-    if (act) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            cplx v; v.re = (2 * I + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; v.im = 0.0;
-            Vs[e * LS + me] = v;
-        }
-    }
-    // prologue: the diagonal lanes publish the rotations of round 0
-    m00 = Ms[0 * LS + me]; m01 = Ms[1 * LS + me]; m11 = Ms[3 * LS + me];
-    {
-        const JRot r0 = jacobi_rotation(m00.re, m11.re, m01.re, m01.im);
-        if (act && I == J) {
-            JRec q; q.c = r0.c; q.sr = r0.sr; q.si = r0.si; q.an = r0.an; q.dn = r0.dn; q.pad = 0.0;
-            rec[I] = q;
-        }
-    }
-    __syncthreads();
-    int sweep = 0;
-    for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
-        for (int r = 0; r < N - 1; ++r) {
-            const JRec qI = rec[I], qJ = rec[J];
-            m00 = Ms[0 * LS + me]; m01 = Ms[1 * LS + me];
-            m10 = Ms[2 * LS + me]; m11 = Ms[3 * LS + me];
-            cplx v0p = Vs[0 * LS + me], v0q = Vs[1 * LS + me];
-            cplx v1p = Vs[2 * LS + me], v1q = Vs[3 * LS + me];
-            if (r == 0) {               // slot == index here: convergence test on the fresh matrix
-                double o2 = 0.0, n2 = 0.0;
-                const double a00 = fma(m00.re, m00.re, m00.im * m00.im), a01 = fma(m01.re, m01.re, m01.im * m01.im);
-                const double a10 = fma(m10.re, m10.re, m10.im * m10.im), a11 = fma(m11.re, m11.re, m11.im * m11.im);
-                n2 = (a00 + a11) + (a01 + a10);
-                o2 = (I == J) ? (a01 + a10) : n2;
-                if (!act) { o2 = 0.0; n2 = 0.0; }
-                o2 = uniform(wave_sum(o2));
-                n2 = uniform(wave_sum(n2));
-                if (!(o2 > FBX_JACOBI_TOL2 * n2)) return sweep;
-            }
-            __syncthreads();            // everything read before anyone overwrites it
-            jacobi_apply_m(qI.c, qI.sr, qI.si, qJ.c, qJ.sr, qJ.si, m00, m01, m10, m11);
-            // next round's rotation for pair nk from this lane's entry `ne` and the rotated
-            // diagonals of its row / column pivots; evaluated by every lane (non-feeders park the
-            // record in the spare slot) so that the chain sits in the main block and overlaps the
-            // eigenvector update below
-            {
-                const cplx bsel = (ne == 0) ? m00 : (ne == 1) ? m01 : (ne == 2) ? m10 : m11;
-                const double an = rowSecond ? qI.dn : qI.an;
-                const double dn = colSecond ? qJ.dn : qJ.an;
-                const JRot rn = jacobi_rotation(an, dn, bsel.re, bsel.im);
-                JRec q; q.c = rn.c; q.sr = rn.sr; q.si = rn.si; q.an = rn.an; q.dn = rn.dn; q.pad = 0.0;
-                rec[recSlot] = q;
-            }
-            jacobi_apply_v(qJ.c, qJ.sr, qJ.si, v0p, v0q, v1p, v1q);
-            if (I == J) {               // the annihilated pair: exact zeros, published diagonal
-                m01.re = m01.im = 0.0; m10.re = m10.im = 0.0;
-                m00.re = qI.an; m11.re = qI.dn; m00.im = 0.0; m11.im = 0.0;
-            }
-            if (act) {
-                Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;
-                Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
-            }
-            __syncthreads();
-        }
-    }
-    return sweep;
-}
-
 // Warm start: replace the matrix in Ms by V^H Ms V for the (unitary) V already in Vs, so that the
 // sweeps start from a nearly diagonal matrix when V diagonalises a nearby matrix.  `Ts` is 4*LS
 // cplx of scratch.  All three arrays use the element-major block layout.
@@ -450,10 +361,7 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
 template <int N, int NT = 64>
 __device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, int lane,
                                                bool init_identity = true, double* red = nullptr) {
-#ifdef FBX_JACOBI_PIPELINED     // measured equal-or-slower than the simple form at 1 wave/SIMD
-    if constexpr (N >= 6 && NT == 64) return jacobi_eigh_pipelined<N>(Ms, Vs, rec, lane);
-#endif
-    (void)rec;
+    (void)rec;      // (a variant that publishes next-round rotations through `rec` measured no faster)
     return jacobi_eigh_simple<N, NT>(Ms, Vs, lane, init_identity, red);
 }
 
