@@ -41,8 +41,53 @@ struct Lds {
 
 __device__ __forceinline__ double bsum(double v, Lds& L) { return block_sum<NT>(v, L.red); }
 
+// ---- warm start: Ms <- V^H Ms V for the eigenvectors V of the previous projection (still in Vs).
+// LDS is full, so the intermediate product T = Ms V goes through a 64 KiB L2-resident scratch of
+// this workgroup (`Tg`, element-major); agent-scope fences around the barrier make the other
+// waves' stores visible past the per-CU L1.
+__device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
+    const int I = t / NB, J = t % NB;
+    cplx acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e].re = 0.0; acc[e].im = 0.0; }
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int ke = 0; ke < 2; ++ke) {
+            const cplx h0 = L.Ms[(0 + ke) * NT + I * NB + kb], h1 = L.Ms[(2 + ke) * NT + I * NB + kb];
+            const cplx v0 = L.Vs[(ke * 2 + 0) * NT + kb * NB + J], v1 = L.Vs[(ke * 2 + 1) * NT + kb * NB + J];
+            acc[0].re += h0.re * v0.re - h0.im * v0.im; acc[0].im += h0.re * v0.im + h0.im * v0.re;
+            acc[1].re += h0.re * v1.re - h0.im * v1.im; acc[1].im += h0.re * v1.im + h0.im * v1.re;
+            acc[2].re += h1.re * v0.re - h1.im * v0.im; acc[2].im += h1.re * v0.im + h1.im * v0.re;
+            acc[3].re += h1.re * v1.re - h1.im * v1.im; acc[3].im += h1.re * v1.im + h1.im * v1.re;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Tg[e * NT + t] = acc[e];
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e].re = 0.0; acc[e].im = 0.0; }
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int ke = 0; ke < 2; ++ke) {
+            const cplx u0 = L.Vs[(ke * 2 + 0) * NT + kb * NB + I], u1 = L.Vs[(ke * 2 + 1) * NT + kb * NB + I];
+            const cplx w0 = Tg[(ke * 2 + 0) * NT + kb * NB + J], w1 = Tg[(ke * 2 + 1) * NT + kb * NB + J];
+            acc[0].re += u0.re * w0.re + u0.im * w0.im; acc[0].im += u0.re * w0.im - u0.im * w0.re;
+            acc[1].re += u0.re * w1.re + u0.im * w1.im; acc[1].im += u0.re * w1.im - u0.im * w1.re;
+            acc[2].re += u1.re * w0.re + u1.im * w0.im; acc[2].im += u1.re * w0.im - u1.im * w0.re;
+            acc[3].re += u1.re * w1.re + u1.im * w1.im; acc[3].im += u1.re * w1.im - u1.im * w1.re;
+        }
+    }
+    __syncthreads();                                   // every thread is done reading Ms
+    if (I == J) { acc[0].im = 0.0; acc[3].im = 0.0; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) L.Ms[e * NT + t] = acc[e];
+    __syncthreads();
+}
+
 // ---- CP projection (project_superoperators.py:19-34)
-__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps) {
+__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr) {
     __syncthreads();
     sys_store<D>(L.Ms, t, x);
     __syncthreads();
@@ -53,7 +98,8 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps) {
     __syncthreads();
     sys_store<D>(L.Ms, t, h);
     __syncthreads();
-    sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, true, L.red);
+    if (warm) rotate_into_basis(L, Tg, t);
+    sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, !warm, L.red);
     if (t < D) {
         const double l = L.Ms[sys_index<D>(t, t)].re;
         L.lam[t] = l < 0.0 ? 0.0 : l;
@@ -64,14 +110,17 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps) {
 
 // ---- partial trace over the output space into L.pt (calculational.py:5-35); stages x through Mw
 __device__ void partial_trace_out(const Blk& x, Lds& L, int t) {
-    __syncthreads();                                   // readers of Vs (reconstruct) are done
-    blk_store<D, LD>(L.Mw, t, x);
+    // staged row-major through Ms (dead between the reconstruction and the next projection), NOT
+    // through Mw = Vs: the eigenvectors in Vs must survive for the warm start of the next projection
+    cplx* St = L.Ms;
+    __syncthreads();
+    blk_store<D, LD>(St, t, x);
     __syncthreads();
     if (t < d * d) {
         const int i = t / d, ip = t % d;
         cplx s; s.re = 0.0; s.im = 0.0;
 #pragma unroll
-        for (int o = 0; o < d; ++o) { const cplx v = L.Mw[(i * d + o) * LD + ip * d + o]; s.re += v.re; s.im += v.im; }
+        for (int o = 0; o < d; ++o) { const cplx v = St[(i * d + o) * LD + ip * d + o]; s.re += v.re; s.im += v.im; }
         L.pt[i * LDs + ip] = s;
     }
     __syncthreads();
@@ -113,13 +162,15 @@ __device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project
 }
 
 // ---- Dykstra (project_superoperators.py:87-144)
-__device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, int& sweeps) {
+__device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, int& sweeps, cplx* Tg) {
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
     for (int it = 0; it < 100000; ++it) {
         ++iters;
         const Blk pre_cp = blk_sub(last_state, old_cp);
-        const Blk cp = proj_cp(pre_cp, L, t, sweeps);
+        // consecutive Dykstra iterates are close: start from the previous eigenvectors (cold again
+        // at the first projection of every call, which also bounds the loss of unitarity)
+        const Blk cp = proj_cp(pre_cp, L, t, sweeps, it > 0 && Tg != nullptr, Tg);
         const Blk new_cp = blk_sub(cp, pre_cp);
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = tp ? proj_tp(pre_tp, L, t) : proj_tni(pre_tp, L, t, sweeps);
@@ -231,7 +282,7 @@ __global__ void __launch_bounds__(1024)
 pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
              int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out,
              int* __restrict__ iters_out, int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-             double* __restrict__ cost_out) {
+             double* __restrict__ cost_out, cplx* __restrict__ scratch) {
     using namespace p3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds L; L.carve(smem);
@@ -362,7 +413,8 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         const Blk grad = pauli_to_choi(L, t);
 
         const Blk x = blk_axpy(est, -inv_mu, grad);
-        const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps);
+        const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
+                                       scratch ? scratch + (size_t)blockIdx.x * D * D : nullptr);
         const Blk upd = blk_sub(proj, est);
 
         choi_to_pauli(upd, L, t);
@@ -416,9 +468,23 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     }
     auto kern = pgdb3_kernel<MAXJ>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(1024), lds, stream(), des->dev, (long long)B, e, c, tp, mode,
-                       max_iters, choi, it, dy, bt, cost);
-    FBX_HIP(hipGetLastError());
+    // 64 KiB of L2-resident scratch per workgroup for the warm-start product; batches are processed
+    // in chunks so the scratch stays bounded (512 workgroups = 32 MiB)
+    constexpr int64_t CHUNK = 512;
+    cplx* scratch = nullptr;
+    FBX_HIP(hipMalloc((void**)&scratch, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK)));
+    const size_t m = des->dev.m, DD = (size_t)p3::D * p3::D;
+    for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
+        const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), des->dev, (long long)nb,
+                           e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
+                           dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch);
+    }
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipStreamSynchronize(stream());
+    (void)hipFree(scratch);
+    if (le != hipSuccess) return hip_fail(le, "pgdb3_kernel launch", __FILE__, __LINE__);
+    if (se != hipSuccess) return hip_fail(se, "pgdb3_kernel", __FILE__, __LINE__);
     return FBX_OK;
 }
 
