@@ -160,7 +160,10 @@ __device__ __forceinline__ Blk sys_load_adjoint(const cplx* Ms, int lane) {
 }
 
 constexpr int FBX_JACOBI_MAX_SWEEPS = 40;
-constexpr double FBX_JACOBI_TOL2 = 1e-26;   // stop when off(A)^2 <= TOL2 * ||A||_F^2
+#ifndef FBX_JACOBI_TOL2_VALUE
+#define FBX_JACOBI_TOL2_VALUE 1e-26
+#endif
+constexpr double FBX_JACOBI_TOL2 = FBX_JACOBI_TOL2_VALUE;   // stop when off(A)^2 <= TOL2 * ||A||_F^2
 
 // Rotation helpers ----------------------------------------------------------------------------
 // Rotation R = [[c, s], [-conj(s), c]] that diagonalises the Hermitian pivot [[a, b], [conj(b), d]]

@@ -488,6 +488,79 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     return FBX_OK;
 }
 
+// ---- 3-qubit Choi projections (fbx_proj_choi) and linear inversion (fbx_linv_process) on the same
+// 1024-thread building blocks
+__global__ void __launch_bounds__(1024)
+proj_choi3_kernel(int kind, long long B, const double* __restrict__ in, double* __restrict__ out,
+                  int* __restrict__ iters_out) {
+    using namespace p3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds L; L.carve(smem);
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    const int I = t / NB, J = t % NB;
+    Blk x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+        const double* p = in + ((item * D + row) * D + col) * 2;
+        x.re[e] = p[0]; x.im[e] = p[1];
+    }
+    int iters = 0, sweeps = 0;
+    Blk y;
+    if (kind == FBX_PROJ_CP) y = proj_cp(x, L, t, sweeps);
+    else if (kind == FBX_PROJ_TP) y = proj_tp(x, L, t);
+    else if (kind == FBX_PROJ_TNI) y = proj_tni(x, L, t, sweeps);
+    else y = proj_physical(x, kind == FBX_PROJ_PHYSICAL_TP, L, t, iters, sweeps, nullptr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+        double* p = out + ((item * D + row) * D + col) * 2;
+        p[0] = y.re[e]; p[1] = y.im[e];
+    }
+    if (t == 0 && iters_out) iters_out[item] = iters;
+}
+
+__global__ void __launch_bounds__(1024)
+linv_process3_kernel(DesignDev des, long long B, const double* __restrict__ expect, double* __restrict__ out) {
+    using namespace p3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds L; L.carve(smem);
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    for (int idx = t; idx < D * D; idx += NT) {       // Rt[j * 64 + i] = R[i][j] (+ the identity term)
+        const int i = idx % D, j = idx / D;
+        double acc = 0.0;
+        for (int g = des.pptr[i]; g < des.pptr[i + 1]; ++g)
+            acc += expect[item * des.m + des.porder[g]] * des.pinvT[(size_t)g * D + j];
+        L.Rt[idx] = acc + ((idx == 0) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    const Blk c = pauli_to_choi(L, t);
+    const int I = t / NB, J = t % NB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+        double* p = out + ((item * D + row) * D + col) * 2;
+        p[0] = c.re[e]; p[1] = c.im[e];
+    }
+}
+
+int proj_choi3_launch(int kind, int64_t B, const double* d_in, double* d_out, int32_t* d_iters) {
+    const size_t lds = p3::Lds::bytes();
+    FBX_HIP(hipFuncSetAttribute((const void*)proj_choi3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(proj_choi3_kernel, dim3((unsigned)B), dim3(1024), lds, stream(), kind, (long long)B, d_in, d_out, d_iters);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+int linv_process3_launch(const fbx_design* des, int64_t B, const double* d_expect, double* d_out) {
+    const size_t lds = p3::Lds::bytes();
+    FBX_HIP(hipFuncSetAttribute((const void*)linv_process3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(linv_process3_kernel, dim3((unsigned)B), dim3(1024), lds, stream(), des->dev, (long long)B, d_expect, d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 // called from fbx_pgdb.hip's dispatcher
 int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
                    int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost) {

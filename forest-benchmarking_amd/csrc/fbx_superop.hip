@@ -32,10 +32,10 @@ __device__ __forceinline__ cplx mul_iph(cplx v, int ph) {
 
 // out = scale * P2C^H in P2C  (superop -> Pauli-Liouville with scale 1/d; Choi -> chi with 1/d^2),
 // P2C columns = vec(P_k): out[k][l] = scale * sum_{r,s} conj(vP_k[r]) in[r][s] vP_l[s]
-template <int NQ>
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
 __device__ void to_pauli_basis(const cplx* in, cplx* out, double scale, int lane) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    for (int idx = lane; idx < D * D; idx += 64) {
+    constexpr int d = 1 << NQ, D = d * d;
+    for (int idx = lane; idx < D * D; idx += NT) {
         const int k = idx / D, l = idx % D;
         int xk, zk, yk, xl, zl, yl;
         pauli_masks<NQ>(k, xk, zk, yk);
@@ -60,10 +60,10 @@ __device__ void to_pauli_basis(const cplx* in, cplx* out, double scale, int lane
 }
 
 // out = scale * P2C in P2C^H: out[r][s] = scale * sum_{k,l} vP_k[r] in[k][l] conj(vP_l[s])
-template <int NQ>
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
 __device__ void from_pauli_basis(const cplx* in, cplx* out, double scale, int lane) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    for (int idx = lane; idx < D * D; idx += 64) {
+    constexpr int d = 1 << NQ, D = d * d;
+    for (int idx = lane; idx < D * D; idx += NT) {
         const int r = idx / D, s = idx % D;
         const int cr = r / d, rr = r % d, cs = s / d, rs = s % d;   // vec index = col * d + row
         const int xk = rr ^ cr, xl = rs ^ cs;
@@ -86,10 +86,10 @@ __device__ void from_pauli_basis(const cplx* in, cplx* out, double scale, int la
 
 // choi <-> superop reshuffle (superoperator_transformations.py:267-277,351-361):
 // out[(p,q)][(r,s)] = in[(s,q)][(r,p)]
-template <int NQ>
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
 __device__ void reshuffle(const cplx* in, cplx* out, int lane) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    for (int idx = lane; idx < D * D; idx += 64) {
+    constexpr int d = 1 << NQ, D = d * d;
+    for (int idx = lane; idx < D * D; idx += NT) {
         const int row = idx / D, col = idx % D;
         const int p = row / d, q = row % d, r = col / d, s = col % d;
         out[row * LD + col] = in[(s * d + q) * LD + r * d + p];
@@ -97,13 +97,13 @@ __device__ void reshuffle(const cplx* in, cplx* out, int lane) {
 }
 
 // kraus -> choi (sum vec(K) vec(K)^H) or superop (sum conj(K) (x) K); K ops row-major d x d in HBM
-template <int NQ>
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
 __device__ void kraus_to(const double* __restrict__ kraus, int K, bool to_superop, cplx* out, cplx* kb,
                          int lane) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    for (int idx = lane; idx < K * D; idx += 64) { kb[idx].re = kraus[2 * idx]; kb[idx].im = kraus[2 * idx + 1]; }
+    constexpr int d = 1 << NQ, D = d * d;
+    for (int idx = lane; idx < K * D; idx += NT) { kb[idx].re = kraus[2 * idx]; kb[idx].im = kraus[2 * idx + 1]; }
     __syncthreads();
-    for (int idx = lane; idx < D * D; idx += 64) {
+    for (int idx = lane; idx < D * D; idx += NT) {
         const int row = idx / D, col = idx % D;
         double re = 0.0, im = 0.0;
         for (int t = 0; t < K; ++t) {
@@ -156,18 +156,18 @@ __device__ void abs_via_eigh(const cplx* in, cplx* out, ChoiLds<NQ>& L, double t
     __syncthreads();
 }
 
-template <int NQ>
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
 __device__ void load_matrix(const double* __restrict__ g, cplx* m, int lane) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    for (int idx = lane; idx < D * D; idx += 64) {
+    constexpr int d = 1 << NQ, D = d * d;
+    for (int idx = lane; idx < D * D; idx += NT) {
         cplx v; v.re = g[2 * idx]; v.im = g[2 * idx + 1];
         m[(idx / D) * LD + idx % D] = v;
     }
 }
-template <int NQ>
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
 __device__ void store_matrix(const cplx* m, double* __restrict__ g, int lane) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    for (int idx = lane; idx < D * D; idx += 64) {
+    constexpr int d = 1 << NQ, D = d * d;
+    for (int idx = lane; idx < D * D; idx += NT) {
         const cplx v = m[(idx / D) * LD + idx % D];
         g[2 * idx] = v.re; g[2 * idx + 1] = v.im;
     }
@@ -239,6 +239,91 @@ static int launch_convert(int from, int to, int64_t B, const double* in, int K, 
     auto kern = convert_kernel<NQ>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream(), from, to, (long long)B, in, K, out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+// ---- three qubits: 64 x 64 matrices, one 1024-thread workgroup per item.  The two ping-pong
+// matrices (row-major, LD = 64) ARE the Jacobi work / eigenvector arrays of the |C| step: every
+// hand-over goes through registers, so the aliasing is safe.  LDS: [A 64K | B 64K | Kraus + scratch 32K].
+__global__ void __launch_bounds__(1024)
+convert3_kernel(int from, int to, long long B, const double* __restrict__ in, int K, double* __restrict__ out) {
+    constexpr int NQ = 3, d = 8, D = 64, LD = 64, NT = 1024, NB = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* A = (cplx*)smem;
+    cplx* Bm = A + D * D;
+    double* lam = (double*)(Bm + D * D);
+    double* red = lam + D;
+    cplx* kb = (cplx*)(red + 64);
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    cplx* cur = A; cplx* nxt = Bm;
+    auto swap = [&]() { cplx* q = cur; cur = nxt; nxt = q; __syncthreads(); };
+    const double inv_d = 1.0 / d;
+
+    int rep = from;
+    if (from == FBX_REP_KRAUS) {
+        const bool sup = (to == FBX_REP_SUPEROP || to == FBX_REP_PAULI_LIOUVILLE);
+        kraus_to<NQ, NT, LD>(in + item * (long long)K * D * 2, K, sup, cur, kb, t);
+        __syncthreads();
+        rep = sup ? FBX_REP_SUPEROP : FBX_REP_CHOI;
+    } else {
+        load_matrix<NQ, NT, LD>(in + item * (long long)D * D * 2, cur, t);
+        __syncthreads();
+    }
+    const bool kraus_chi = (from == FBX_REP_KRAUS && to == FBX_REP_CHI);
+    while (rep != to) {
+        if (rep == FBX_REP_CHI) {
+            from_pauli_basis<NQ, NT, LD>(cur, nxt, 1.0, t); swap(); rep = FBX_REP_CHOI;
+        } else if (rep == FBX_REP_CHOI) {
+            if (to == FBX_REP_CHI) {
+                if (!kraus_chi) {       // |C| = sum |lambda| v v^H, as choi2kraus -> kraus2chi (tol 1e-9)
+                    const int I = t / NB, J = t % NB;
+                    Blk h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {       // numpy eigh reads the lower triangle
+                        const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
+                        if (r > c) { const cplx v = cur[r * LD + c]; h.re[e] = v.re; h.im[e] = v.im; }
+                        else if (r < c) { const cplx v = cur[c * LD + r]; h.re[e] = v.re; h.im[e] = -v.im; }
+                        else { h.re[e] = cur[r * LD + c].re; h.im[e] = 0.0; }
+                    }
+                    __syncthreads();
+                    sys_store<D>(A, t, h);
+                    __syncthreads();
+                    jacobi_eigh_simple<D, NT>(A, Bm, t, true, red);
+                    if (t < D) {
+                        const double l = fabs(A[sys_index<D>(t, t)].re);
+                        lam[t] = l > 1e-9 ? l : 0.0;
+                    }
+                    __syncthreads();
+                    const Blk a = reconstruct_blk<D>(Bm, lam, t);
+                    __syncthreads();
+                    blk_store<D, LD>(nxt, t, a);
+                    swap();
+                }
+                to_pauli_basis<NQ, NT, LD>(cur, nxt, inv_d * inv_d, t); swap(); rep = FBX_REP_CHI;
+            } else {
+                reshuffle<NQ, NT, LD>(cur, nxt, t); swap(); rep = FBX_REP_SUPEROP;
+            }
+        } else if (rep == FBX_REP_SUPEROP) {
+            if (to == FBX_REP_PAULI_LIOUVILLE) {
+                to_pauli_basis<NQ, NT, LD>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
+            } else {
+                reshuffle<NQ, NT, LD>(cur, nxt, t); swap(); rep = FBX_REP_CHOI;
+            }
+        } else {
+            from_pauli_basis<NQ, NT, LD>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_SUPEROP;
+        }
+    }
+    store_matrix<NQ, NT, LD>(cur, out + item * (long long)D * D * 2, t);
+}
+
+static int launch_convert3(int from, int to, int64_t B, const double* in, int K, double* out) {
+    constexpr size_t D = 64;
+    const size_t lds = 2 * sizeof(cplx) * D * D + sizeof(double) * 128 + sizeof(cplx) * (size_t)(K > 0 ? K : 1) * D;
+    if (lds > 160 * 1024) { set_error("fbx_convert: too many Kraus operators for LDS staging (3 qubits: at most 31)"); return FBX_ERR_UNSUPPORTED; }
+    FBX_HIP(hipFuncSetAttribute((const void*)convert3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(convert3_kernel, dim3((unsigned)B), dim3(1024), lds, stream(), from, to, (long long)B, in, K, out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;
 }
@@ -538,6 +623,11 @@ linv_process_kernel(DesignDev des, long long B, const double* __restrict__ expec
 
 }  // namespace fbx
 
+namespace fbx {     // fbx_pgdb3.hip
+int proj_choi3_launch(int kind, int64_t B, const double* d_in, double* d_out, int32_t* d_iters);
+int linv_process3_launch(const fbx_design* des, int64_t B, const double* d_expect, double* d_out);
+}
+
 using namespace fbx;
 
 namespace {
@@ -582,11 +672,11 @@ int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect, 
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const int n = design->dev.n;
-    if (n > 2) { set_error("fbx_linv_process: this build handles 1 and 2 qubits"); return FBX_ERR_UNSUPPORTED; }
     const size_t m = design->dev.m, D = design->dev.D;
     HostIO io; double *de, *dout;
     FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.out(D * D * 2 * B, &dout));
-    if (n == 1) hipLaunchKernelGGL(linv_process_kernel<1>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, de, dout);
+    if (n == 3) FBX_TRY(linv_process3_launch(design, B, de, dout));
+    else if (n == 1) hipLaunchKernelGGL(linv_process_kernel<1>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, de, dout);
     else hipLaunchKernelGGL(linv_process_kernel<2>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, de, dout);
     FBX_HIP(hipGetLastError());
     FBX_TRY(io.back(choi_out, dout, D * D * 2 * B));
@@ -594,7 +684,7 @@ int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect, 
 }
 
 int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K, double* out) {
-    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_convert: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_convert: n_qubits must be 1..3");
     FBX_REQUIRE(from_rep >= FBX_REP_KRAUS && from_rep <= FBX_REP_CHI, "fbx_convert: bad source representation");
     FBX_REQUIRE(to_rep >= FBX_REP_CHOI && to_rep <= FBX_REP_CHI, "fbx_convert: bad target representation (Kraus output is not offered)");
     FBX_REQUIRE(from_rep != to_rep, "fbx_convert: source and target representation are the same");
@@ -606,7 +696,8 @@ int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double*
     const size_t n_in = (from_rep == FBX_REP_KRAUS ? (size_t)K * D : D * D) * 2 * B, n_out = D * D * 2 * B;
     HostIO io; double *d_in, *d_out;
     FBX_TRY(io.in(in, n_in, &d_in)); FBX_TRY(io.out(n_out, &d_out));
-    if (n_qubits == 1) FBX_TRY(launch_convert<1>(from_rep, to_rep, B, d_in, K, d_out));
+    if (n_qubits == 3) FBX_TRY(launch_convert3(from_rep, to_rep, B, d_in, K, d_out));
+    else if (n_qubits == 1) FBX_TRY(launch_convert<1>(from_rep, to_rep, B, d_in, K, d_out));
     else FBX_TRY(launch_convert<2>(from_rep, to_rep, B, d_in, K, d_out));
     FBX_TRY(io.back(out, d_out, n_out));
     return io.sync();
@@ -645,7 +736,7 @@ int fbx_kraus_sweep(int n_qubits, int64_t B, int K, const double* kraus, const d
 }
 
 int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, double* out, int32_t* iters_out) {
-    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_proj_choi: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_proj_choi: n_qubits must be 1..3");
     FBX_REQUIRE(proj_kind >= FBX_PROJ_CP && proj_kind <= FBX_PROJ_PHYSICAL_TNI, "fbx_proj_choi: bad projection kind");
     FBX_REQUIRE(B >= 0 && (B == 0 || (choi && out)), "fbx_proj_choi: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
@@ -653,7 +744,9 @@ int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, do
     const size_t d = (size_t)1 << n_qubits, D = d * d, nm = D * D * 2 * B;
     HostIO io; double *d_in, *d_out; int32_t* d_it;
     FBX_TRY(io.in(choi, nm, &d_in)); FBX_TRY(io.out(nm, &d_out)); FBX_TRY(io.out((size_t)B, &d_it));
-    if (n_qubits == 1) {
+    if (n_qubits == 3) {
+        FBX_TRY(proj_choi3_launch(proj_kind, B, d_in, d_out, d_it));
+    } else if (n_qubits == 1) {
         const size_t lds = ChoiLds<1>::bytes() + 64;
         hipLaunchKernelGGL(proj_choi_kernel<1>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_in, d_out, d_it);
     } else {

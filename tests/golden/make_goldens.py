@@ -67,8 +67,9 @@ def make_process_3q():
     assert len(settings) == design.m
     res = ref_results(settings, e[0], c[0])
     est = T.pgdb_process_estimate(res, qubits)
+    linv = T.linear_inv_process_estimate(res, qubits)
     np.savez_compressed(os.path.join(HERE, "process_3q_sic.npz"), n_qubits=3, unitaries=us,
-                        expectations=e, counts=c, pgdb=est[None])
+                        expectations=e, counts=c, pgdb=est[None], linv=linv[None])
     print("process 3 sic done")
 
 
@@ -170,6 +171,7 @@ if __name__ == "__main__":
     np.random.seed(0)
     if "--3q" in sys.argv:
         make_process_3q()
+        make_superops(3, 1)
         sys.exit(0)
     make_process(1, "pauli", 6, 3)
     make_process(1, "sic", 6, 3)

@@ -57,3 +57,46 @@ def test_batch_of_256_properties(gpu):
     pt = np.einsum("biojo->bij", got.reshape(-1, 8, 8, 8, 8))
     assert np.abs(pt - np.eye(8)).max() < 1e-12
     assert np.array_equal(got[:32], got[224:])
+
+
+def test_choi_projections_3q_match_oracle(gpu):
+    """project_superoperators.py:19-144 on 64 x 64 Choi matrices (1024-thread kernel)."""
+    from fbx.operator_tools import project_superoperators as ps
+    from fbx import _lib
+    from fbx_oracle import superops as so
+    rng = np.random.default_rng(33)
+    xs = []
+    for k in range(3):
+        a = rng.normal(size=(64, 64)) + 1j * rng.normal(size=(64, 64))
+        xs.append((a + a.conj().T) / 16 + np.eye(64) / 8 * (k != 2))
+    x = np.stack(xs)
+    got = ps.proj_choi_batch(_lib.PROJ_CP, x)
+    for b in range(3):
+        assert np.abs(got[b] - so.proj_choi_to_completely_positive(x[b])).max() < 1e-11
+    got = ps.proj_choi_batch(_lib.PROJ_TP, x)
+    for b in range(3):
+        assert np.abs(got[b] - so.proj_choi_to_trace_preserving(x[b])).max() < 1e-12
+    got = ps.proj_choi_batch(_lib.PROJ_TNI, x)
+    for b in range(3):
+        assert np.abs(got[b] - so.proj_choi_to_trace_non_increasing(x[b])).max() < 1e-11
+    for kind, tp in ((_lib.PROJ_PHYSICAL_TP, True), (_lib.PROJ_PHYSICAL_TNI, False)):
+        got, iters = ps.proj_choi_batch(kind, x, return_iters=True)
+        for b in range(3):
+            want, n_it = so.proj_choi_to_physical(x[b], tp, return_iters=True)
+            assert iters[b] == n_it
+            assert np.abs(got[b] - want).max() < 1e-10
+
+
+def test_linear_inversion_3q_matches_reference_golden_and_oracle(gpu):
+    """tomography.py:459-491 for three qubits: the golden holds the reference's own pinv solution."""
+    from fbx import synthetic, tomography
+    from fbx.design import process_design
+    from fbx_oracle import design as od, estimators as oe
+    g = np.load(os.path.join(GOLD, "process_3q_sic.npz"))
+    design = process_design(3, "sic")
+    got = tomography.linear_inv_process_estimate_batch(design, g["expectations"])
+    if "linv" in g.files:
+        assert np.abs(got - g["linv"]).max() < 1e-9
+    d = od.Design(3, "process", design.in_labels, design.paulis, design.coefs)
+    want = oe.linear_inv_process_estimate(d, g["expectations"][0])
+    assert np.abs(got[0] - want).max() < 1e-9

@@ -13,7 +13,7 @@ def gold(n):
     return np.load(os.path.join(GOLD, f"superops_{n}q.npz"))
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_kraus_conversions(gpu, n):
     from fbx.operator_tools import convert_batch
     g = gold(n)
@@ -24,7 +24,7 @@ def test_kraus_conversions(gpu, n):
             assert np.abs(got - g[f"kraus{K}_{key}"]).max() < TOL, (K, dst)
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_pairwise_conversions(gpu, n):
     from fbx.operator_tools import convert_batch
     g = gold(n)
@@ -43,7 +43,7 @@ def test_pairwise_conversions(gpu, n):
         assert np.abs(got - g[kout]).max() < 1e-11, (src, dst)
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_choi2chi_non_cp_goes_through_abs(gpu, n):
     """Reference quirk: choi2chi of a non-CP matrix is the chi form of |C|."""
     from fbx.operator_tools import convert_batch
@@ -52,7 +52,7 @@ def test_choi2chi_non_cp_goes_through_abs(gpu, n):
     assert np.abs(got - g["herm_choi2chi"]).max() < 1e-11
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_projections(gpu, n):
     from fbx import _lib
     from fbx.operator_tools.project_superoperators import proj_choi_batch
@@ -67,7 +67,7 @@ def test_projections(gpu, n):
     assert np.abs(proj_choi_batch(_lib.PROJ_PHYSICAL_TNI, x) - g["proj_near_phys_tni"]).max() < 1e-10
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_dykstra_iteration_counts_match_oracle(gpu, n):
     from fbx import _lib
     from fbx.operator_tools.project_superoperators import proj_choi_batch
@@ -79,7 +79,7 @@ def test_dykstra_iteration_counts_match_oracle(gpu, n):
     assert list(iters) == want
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_process_fidelity_and_apply(gpu, n):
     from fbx import distance_measures as dm
     from fbx.operator_tools import apply_choi_matrix_2_state_batch
