@@ -419,16 +419,19 @@ state_measures_kernel(long long B, const double* __restrict__ rho_in, const doub
     }
 }
 
-// generic batched eigh (lower triangle read, ascending eigenvalues, eigenvectors as columns)
-template <int N>
-__global__ void __launch_bounds__(64)
+// generic batched eigh (lower triangle read, ascending eigenvalues, eigenvectors as columns).
+// One workgroup of NT = max(64, (N/2)^2) threads per matrix: one wavefront up to 16 x 16, four for
+// 32 x 32, sixteen for 64 x 64 (128 KiB of LDS for the matrix and the eigenvectors).
+template <int N, int NT>
+__global__ void __launch_bounds__(NT)
 eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_out, double* __restrict__ v_out) {
     constexpr int NB = N / 2;
-    __shared__ cplx Ms[N * N];
-    __shared__ cplx Vs[N * N];
-    __shared__ JRec rec[NB + 1];
-    __shared__ double lam[N];
-    __shared__ int pos[N];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Ms = (cplx*)smem;
+    cplx* Vs = Ms + N * N;
+    double* lam = (double*)(Vs + N * N);
+    double* red = lam + N;
+    int* pos = (int*)(red + 64);
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
     const double* src = a + item * (long long)N * N * 2;
@@ -445,7 +448,7 @@ eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_ou
     }
     sys_store<N>(Ms, lane, h);
     __syncthreads();
-    jacobi_eigh_lds<N>(Ms, Vs, rec, lane);
+    jacobi_eigh_simple<N, NT>(Ms, Vs, lane, true, red);
     if (lane < N) lam[lane] = Ms[sys_index<N>(lane, lane)].re;
     __syncthreads();
     if (lane < N) {                     // rank of eigenvalue `lane` in ascending order (stable)
@@ -456,13 +459,24 @@ eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_ou
     }
     __syncthreads();
     if (v_out) {
-        for (int idx = lane; idx < N * N; idx += 64) {
+        for (int idx = lane; idx < N * N; idx += NT) {
             const int r = idx / N, k = idx % N;
             const cplx v = Vs[sys_index<N>(r, k)];
             double* o = v_out + ((item * N + r) * N + pos[k]) * 2;
             o[0] = v.re; o[1] = v.im;
         }
     }
+}
+
+template <int N>
+static int launch_eigh(int64_t B, const double* da, double* dw, double* dv) {
+    constexpr int NT = (N / 2) * (N / 2) > 64 ? (N / 2) * (N / 2) : 64;
+    const size_t lds = 2 * sizeof(cplx) * N * N + sizeof(double) * (N + 64) + sizeof(int) * N;
+    auto kern = eigh_kernel<N, NT>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(NT), lds, stream(), (long long)B, da, dw, dv);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
 }
 
 }  // namespace fbx
@@ -591,7 +605,7 @@ int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* 
 }
 
 int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
-    FBX_REQUIRE(N == 2 || N == 4 || N == 8 || N == 16, "fbx_eigh: N must be 2, 4, 8 or 16");
+    FBX_REQUIRE(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "fbx_eigh: N must be a power of two in 2..64");
     FBX_REQUIRE(B >= 0 && (B == 0 || (a && w_out)), "fbx_eigh: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
@@ -599,10 +613,14 @@ int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
     HostIO io; double *da, *dw, *dv = nullptr;
     FBX_TRY(io.in(a, nn, &da)); FBX_TRY(io.out((size_t)N * B, &dw));
     if (v_out) FBX_TRY(io.out(nn, &dv));
-    if (N == 2) hipLaunchKernelGGL(eigh_kernel<2>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
-    else if (N == 4) hipLaunchKernelGGL(eigh_kernel<4>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
-    else if (N == 8) hipLaunchKernelGGL(eigh_kernel<8>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
-    else hipLaunchKernelGGL(eigh_kernel<16>, dim3((unsigned)B), dim3(64), 0, stream(), (long long)B, da, dw, dv);
+    switch (N) {
+        case 2: FBX_TRY(launch_eigh<2>(B, da, dw, dv)); break;
+        case 4: FBX_TRY(launch_eigh<4>(B, da, dw, dv)); break;
+        case 8: FBX_TRY(launch_eigh<8>(B, da, dw, dv)); break;
+        case 16: FBX_TRY(launch_eigh<16>(B, da, dw, dv)); break;
+        case 32: FBX_TRY(launch_eigh<32>(B, da, dw, dv)); break;
+        default: FBX_TRY(launch_eigh<64>(B, da, dw, dv)); break;
+    }
     FBX_HIP(hipGetLastError());
     FBX_TRY(io.back(w_out, dw, (size_t)N * B)); FBX_TRY(io.back(v_out, dv, nn));
     return io.sync();

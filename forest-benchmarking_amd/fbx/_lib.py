@@ -146,7 +146,7 @@ def iptr(a):
 
 
 def eigh_batch(a, eigenvectors=True):
-    """numpy.linalg.eigh semantics (lower triangle, ascending) for stacked [B, N, N], N in {2,4,8,16}."""
+    """numpy.linalg.eigh semantics (lower triangle, ascending) for stacked [B, N, N], N in {2,4,8,16,32,64}."""
     a = c128(a)
     a = a.reshape((-1,) + a.shape[-2:])
     B, N = a.shape[0], a.shape[-1]

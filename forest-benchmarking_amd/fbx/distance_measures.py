@@ -2,10 +2,12 @@
 
 Mirror of forest/benchmarking/distance_measures.py.  Scalars are returned as python floats
 like the reference (``np.real_if_close(...).item()``).  ``*_batch`` variants take stacked
-matrices ``[B, d, d]``.  ``diamond_norm_distance`` (a cvxpy SDP in the reference,
-distance_measures.py:378-437) and ``quantum_chernoff_bound`` (a scalar minimisation over
-fractional matrix powers, :153-195) are outside the accelerated path and not provided.
+matrices ``[B, d, d]``.  ``quantum_chernoff_bound`` and ``watrous_bounds`` take their spectra from
+the device eigensolver; ``diamond_norm_distance`` is the reference's cvxpy semidefinite program
+(distance_measures.py:378-437) and, like there, needs cvxpy to be installed.
 """
+from typing import Tuple
+
 import numpy as np
 
 from . import _lib
@@ -75,6 +77,28 @@ def bures_angle(rho: np.ndarray, sigma: np.ndarray) -> float:
     return float(np.arccos(np.sqrt(fidelity(rho, sigma))))
 
 
+def quantum_chernoff_bound(rho: np.ndarray, sigma: np.ndarray, tol: float = 1000) -> Tuple[float, float]:
+    """distance_measures.py:153-195: min over 0 <= s <= 1 of tr(rho^s sigma^(1-s)) and its argmin.
+
+    Both spectra come from one ``fbx_eigh`` call; with rho = sum a_i |v_i><v_i| and
+    sigma = sum b_j |w_j><w_j| the objective is sum_ij a_i^s b_j^(1-s) |<v_i|w_j>|^2, minimised by
+    the same bounded scalar search the reference uses (scipy ``minimize_scalar``)."""
+    from scipy.optimize import minimize_scalar
+    w, v = _lib.eigh_batch(np.stack([_lib.c128(rho), _lib.c128(sigma)]))
+    a, b = np.maximum(w[0], 0.0), np.maximum(w[1], 0.0)
+    overlap = np.abs(v[0].conj().T @ v[1]) ** 2
+    pa, pb = a > 0, b > 0
+
+    def f(s):
+        s = float(np.real(s))
+        fa = np.where(pa, a, 1.0) ** s * pa
+        fb = np.where(pb, b, 1.0) ** (1.0 - s) * pb
+        return float(fa @ overlap @ fb)
+
+    res = minimize_scalar(f, bounds=(0, 1), method="bounded")
+    return np.real_if_close(res.fun, tol), np.real_if_close(res.x, tol)
+
+
 def hilbert_schmidt_ip(A: np.ndarray, B: np.ndarray, tol: float = 1000) -> float:
     """distance_measures.py:198-216 (real part; the reference returns a real for Hermitian input)."""
     return float(state_measures_batch(A, B, ("hs_ip",))["hs_ip"][0])
@@ -134,3 +158,74 @@ def process_fidelity(pauli_lio0: np.ndarray, pauli_lio1: np.ndarray) -> float:
 def process_infidelity(pauli_lio0: np.ndarray, pauli_lio1: np.ndarray) -> float:
     """distance_measures.py:362-375."""
     return 1 - process_fidelity(pauli_lio0, pauli_lio1)
+
+
+def _is_square(n):
+    return n == np.round(np.sqrt(n)) ** 2
+
+
+def _pow2_at_least(n):
+    p = 2
+    while p < n:
+        p *= 2
+    return p
+
+
+def _singular_values(a: np.ndarray) -> np.ndarray:
+    """Singular values through the device Hermitian eigensolver (N <= 64): |eig(a)| for Hermitian
+    input, otherwise the non-negative half of the spectrum of the dilation [[0, a], [a^H, 0]]
+    (zero-padded to a power of two, which only adds zero singular values)."""
+    a = _lib.c128(a)
+    r, c = a.shape
+    if r == c and np.array_equal(a, a.conj().T) and _pow2_at_least(r) <= 64:
+        p = _pow2_at_least(r)
+        h = np.zeros((p, p), dtype=np.complex128)
+        h[:r, :r] = a
+        return np.abs(_lib.eigh_batch(h[None], eigenvectors=False)[0])
+    if _pow2_at_least(r + c) <= 64:
+        p = _pow2_at_least(r + c)
+        h = np.zeros((p, p), dtype=np.complex128)
+        h[:r, r:r + c] = a
+        h[r:r + c, :r] = a.conj().T
+        lam = _lib.eigh_batch(h[None], eigenvectors=False)[0]
+        return np.sort(lam)[::-1][:min(r, c)].clip(min=0.0)
+    p = _pow2_at_least(c)
+    if p > 64:
+        raise ValueError("matrices beyond 64 columns are not supported by the device eigensolver")
+    g = np.zeros((p, p), dtype=np.complex128)
+    g[:c, :c] = a.conj().T @ a
+    return np.sqrt(np.maximum(_lib.eigh_batch(g[None], eigenvectors=False)[0], 0.0))
+
+
+def watrous_bounds(choi: np.ndarray) -> Tuple[float, float]:
+    """distance_measures.py:440-460: (nuclear norm, dim * nuclear norm) of a Choi-matrix difference."""
+    choi = np.asarray(choi)
+    if len(choi.shape) != 2:
+        raise ValueError("Watrous bounds only defined for matrices")
+    if not (_is_square(choi.shape[0]) and _is_square(choi.shape[1])):
+        raise ValueError("Choi matrix must have dimensions that are perfect squares")
+    nuclear_norm = float(np.sum(_singular_values(choi)))
+    return nuclear_norm, choi.shape[0] * nuclear_norm
+
+
+def diamond_norm_distance(choi0: np.ndarray, choi1: np.ndarray) -> float:
+    """distance_measures.py:378-437: Watrous' simplified SDP for the diamond norm of the difference
+    of two CPTP maps.  A convex program for a general-purpose solver, not a kernel (SURVEY.md 8a
+    row a29): formulated with cvxpy exactly when cvxpy is importable, ``ImportError`` otherwise --
+    the same behaviour as the reference on an installation without cvxpy.
+
+    maximise  Re tr(J^H W)   s.t.  W >= 0,  W <= 1 (x) rho,  rho >= 0,  tr rho = 1
+    with J the Hermitian part of choi0 - choi1; the distance is twice the optimum."""
+    import cvxpy as cvx
+    assert choi0.shape == choi1.shape
+    assert choi0.shape[0] == choi1.shape[1]
+    big = choi0.shape[0]
+    dim = int(np.sqrt(big))
+    delta = choi0 - choi1
+    delta = (delta + delta.conj().T) / 2
+    rho = cvx.Variable((dim, dim), hermitian=True)
+    w = cvx.Variable((big, big), hermitian=True)
+    constraints = [rho >> 0, cvx.trace(rho) == 1, w >> 0, cvx.kron(np.eye(dim), rho) - w >> 0]
+    problem = cvx.Problem(cvx.Maximize(cvx.real(cvx.trace(delta.conj().T @ w))), constraints)
+    problem.solve()
+    return problem.value * 2

@@ -1,0 +1,64 @@
+"""Small matrix helpers with the reference's names (forest/benchmarking/operator_tools/calculational.py).
+
+``sqrtm_psd`` goes through the device eigensolver (``fbx_eigh``); ``partial_trace`` for arbitrary
+subsystem lists is an index shuffle plus a trace and stays on the host (the two-subsystem partial
+trace the estimators need lives inside the kernels, csrc/fbx_choi.hpp ``partial_trace_out``).
+"""
+import numpy as np
+
+from .. import _lib
+
+__all__ = ["partial_trace", "outer_product", "inner_product", "sqrtm_psd"]
+
+
+def partial_trace(rho, keep, dims, optimize=False):
+    """calculational.py:5-35: trace out every subsystem whose index is not in ``keep``.
+
+    ``dims`` lists the subsystem dimensions in tensor order; the kept subsystems stay in their
+    original relative order."""
+    dims = [int(x) for x in np.asarray(dims).ravel()]
+    kept = set(int(k) for k in np.asarray(keep).ravel())
+    n = len(dims)
+    t = np.asarray(rho).reshape(dims + dims)
+    keep_axes = [i for i in range(n) if i in kept]
+    drop_axes = [i for i in range(n) if i not in kept]
+    # rows: kept then dropped; columns likewise; then sum the diagonal of the dropped part
+    t = np.transpose(t, keep_axes + drop_axes + [n + i for i in keep_axes] + [n + i for i in drop_axes])
+    nk = int(np.prod([dims[i] for i in keep_axes])) if keep_axes else 1
+    nd = int(np.prod([dims[i] for i in drop_axes])) if drop_axes else 1
+    t = t.reshape(nk, nd, nk, nd)
+    return np.einsum("ajbj->ab", t, optimize=optimize)
+
+
+def _check_kets(a, b):
+    rows1, cols1 = a.shape
+    rows2, cols2 = b.shape
+    if not (cols1 == cols2 == 1 and rows1 > 1 and rows2 > 1):
+        raise ValueError("The vectors do not have the correct dimensions.")
+
+
+def outer_product(bra1: np.ndarray, bra2: np.ndarray) -> np.ndarray:
+    """calculational.py:38-52: |bra1><bra2| for two (dim, 1) column vectors."""
+    _check_kets(bra1, bra2)
+    return bra1.reshape(-1, 1) * bra2.conj().reshape(1, -1)
+
+
+def inner_product(bra1: np.ndarray, bra2: np.ndarray) -> complex:
+    """calculational.py:55-72: <bra1|bra2> as a (1, 1) array, like the reference."""
+    _check_kets(bra1, bra2)
+    return bra1.conj().T @ bra2
+
+
+def sqrtm_psd_batch(matrices) -> np.ndarray:
+    """V sqrt(max(lambda, 0)) V^H for stacked Hermitian matrices [B, N, N], N in {2,...,64}."""
+    w, v = _lib.eigh_batch(matrices)
+    w = np.sqrt(np.maximum(w, 0))
+    return np.einsum("bik,bk,bjk->bij", v, w, v.conj())
+
+
+def sqrtm_psd(matrix: np.ndarray, check_finite: bool = True) -> np.ndarray:
+    """calculational.py:77-91."""
+    matrix = np.asarray(matrix)
+    if check_finite and not np.isfinite(matrix).all():
+        raise ValueError("array must not contain infs or NaNs")
+    return sqrtm_psd_batch(matrix[None])[0]

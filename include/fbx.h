@@ -195,9 +195,10 @@ int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, 
                              double* d_mean_out, double* d_var_out);
 
 /* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
- * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16}.  This is the
+ * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16, 32, 64}.  This is the
  * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators
- * (validate_operator.py:118-150) and proj_choi_to_unitary (project_superoperators.py:147-175).
+ * (validate_operator.py:118-150), proj_choi_to_unitary (project_superoperators.py:147-175),
+ * sqrtm_psd (calculational.py:77-91) and the spectral distance measures (distance_measures.py:153-195,440-460).
  * w_out[B][N]; v_out[B][N][N] holds the eigenvectors as columns (phases arbitrary), may be NULL. */
 int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out);
 

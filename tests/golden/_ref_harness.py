@@ -232,6 +232,7 @@ def load_reference():
     ns.tomography = importlib.import_module("forest.benchmarking.tomography")
     ns.operator_tools = importlib.import_module("forest.benchmarking.operator_tools")
     ns.calculational = importlib.import_module("forest.benchmarking.operator_tools.calculational")
+    ns.random_operators = importlib.import_module("forest.benchmarking.operator_tools.random_operators")
     ns.project_state_matrix = importlib.import_module(
         "forest.benchmarking.operator_tools.project_state_matrix")
     ns.distance_measures = importlib.import_module("forest.benchmarking.distance_measures")

@@ -167,8 +167,70 @@ def make_superops(n, batch):
     print("superops", n, "done")
 
 
+def make_extras():
+    """Rows a19 / a27 / a28-a29 extras: calculational helpers, seeded random operators (the draw
+    order is part of the contract), quantum Chernoff bound, Watrous bounds."""
+    RO = ref.random_operators
+    CALC = ref.calculational
+    out = {}
+    np.random.seed(1234)
+    out["ro_ginibre_3_2"] = RO.ginibre_matrix_complex(3, 2)
+    out["ro_haar_u4"] = RO.haar_rand_unitary(4)
+    out["ro_haar_state4"] = RO.haar_rand_state(4)
+    out["ro_ginibre_state_4_2"] = RO.ginibre_state_matrix(4, 2)
+    out["ro_bures4"] = RO.bures_measure_state_matrix(4)
+    out["ro_bcsz_2_2"] = RO.rand_map_with_BCSZ_dist(2, 2)
+    out["ro_bcsz_4_3"] = RO.rand_map_with_BCSZ_dist(4, 3)
+    rs = np.random.RandomState(7)
+    out["ro_rs_ginibre_2_3"] = RO.ginibre_matrix_complex(2, 3, rs)
+    out["ro_rs_haar_u3"] = RO.haar_rand_unitary(3, rs)
+    for k, (dims, perm) in enumerate([(2, [1, 0]), (2, [1, 2, 0]), ([2, 3, 5], [2, 0, 1]), (3, [0, 2, 1]),
+                                      ([2, 3, 2, 2], [2, 3, 1, 0])]):
+        out[f"perm{k}_dims"] = np.atleast_1d(dims)
+        out[f"perm{k}_perm"] = np.array(perm)
+        out[f"perm{k}_out"] = RO.permute_tensor_factors(dims, perm)
+    rs = np.random.RandomState(99)
+    m24 = rs.randn(24, 24) + 1j * rs.randn(24, 24)
+    out["pt_in"] = m24
+    for k, keep in enumerate([[0], [1], [2], [0, 2], [1, 2], [0, 1, 2]]):
+        out[f"pt{k}_keep"] = np.array(keep)
+        out[f"pt{k}_out"] = CALC.partial_trace(m24, keep, [2, 3, 4])
+    for N in (4, 16):
+        g = rs.randn(N, N) + 1j * rs.randn(N, N)
+        psd = g @ g.conj().T
+        out[f"psd{N}"] = psd
+        out[f"sqrtm{N}"] = CALC.sqrtm_psd(psd)
+    a, b = rs.randn(5, 1) + 1j * rs.randn(5, 1), rs.randn(5, 1) + 1j * rs.randn(5, 1)
+    out["ket_a"], out["ket_b"] = a, b
+    out["outer"], out["inner"] = CALC.outer_product(a, b), CALC.inner_product(a, b)
+    for d in (2, 4):
+        pairs, qcbs = [], []
+        for _ in range(3):
+            # real symmetric states: with this scipy the reference's objective turns complex for
+            # complex input and fractional_matrix_power rejects the complex exponent that follows
+            g1, g2 = rs.randn(d, d), rs.randn(d, d)
+            r1, r2 = g1 @ g1.T, g2 @ g2.T
+            r1, r2 = r1 / np.trace(r1).real, r2 / np.trace(r2).real
+            pairs.append((r1, r2))
+            qcbs.append([float(x) for x in DM.quantum_chernoff_bound(r1, r2)])
+        out[f"qcb{d}_rho"] = np.array([p[0] for p in pairs])
+        out[f"qcb{d}_sigma"] = np.array([p[1] for p in pairs])
+        out[f"qcb{d}"] = np.array(qcbs)
+    herm16 = rand_herm(rs, 16)
+    gen4 = rs.randn(4, 4) + 1j * rs.randn(4, 4)
+    gen16 = rs.randn(16, 16) + 1j * rs.randn(16, 16)
+    for name, x in (("herm16", herm16), ("gen4", gen4), ("gen16", gen16)):
+        out[f"wat_{name}"] = x
+        out[f"wat_{name}_out"] = np.array(DM.watrous_bounds(x))
+    np.savez_compressed(os.path.join(HERE, "extras.npz"), **out)
+    print("extras done")
+
+
 if __name__ == "__main__":
     np.random.seed(0)
+    if "--extras" in sys.argv:
+        make_extras()
+        sys.exit(0)
     if "--3q" in sys.argv:
         make_process_3q()
         make_superops(3, 1)
@@ -181,3 +243,4 @@ if __name__ == "__main__":
     make_state(2, 4)
     make_superops(1, 6)
     make_superops(2, 6)
+    make_extras()

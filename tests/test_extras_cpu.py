@@ -1,0 +1,91 @@
+"""Host-side mirrors (random_operators, calculational index helpers) and the oracle's spectral
+measures against outputs of the reference itself (tests/golden/extras.npz, make_goldens.py --extras)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(GOLD, "extras.npz"))
+
+
+def test_random_operators_follow_the_reference_draw_order(g):
+    from fbx.operator_tools import random_operators as ro
+    np.random.seed(1234)
+    assert np.abs(ro.ginibre_matrix_complex(3, 2) - g["ro_ginibre_3_2"]).max() == 0
+    assert np.abs(ro.haar_rand_unitary(4) - g["ro_haar_u4"]).max() < 1e-14
+    assert np.abs(ro.haar_rand_state(4) - g["ro_haar_state4"]).max() < 1e-14
+    assert np.abs(ro.ginibre_state_matrix(4, 2) - g["ro_ginibre_state_4_2"]).max() < 1e-14
+    assert np.abs(ro.bures_measure_state_matrix(4) - g["ro_bures4"]).max() < 1e-13
+    assert np.abs(ro.rand_map_with_BCSZ_dist(2, 2) - g["ro_bcsz_2_2"]).max() < 1e-12
+    assert np.abs(ro.rand_map_with_BCSZ_dist(4, 3) - g["ro_bcsz_4_3"]).max() < 1e-11
+    rs = np.random.RandomState(7)
+    assert np.abs(ro.ginibre_matrix_complex(2, 3, rs) - g["ro_rs_ginibre_2_3"]).max() == 0
+    assert np.abs(ro.haar_rand_unitary(3, rs) - g["ro_rs_haar_u3"]).max() < 1e-14
+    with pytest.raises(ValueError):
+        ro.ginibre_state_matrix(2, 3)
+
+
+def test_random_operator_properties():
+    from fbx.operator_tools import random_operators as ro
+    np.random.seed(5)
+    u = ro.haar_rand_unitary(8)
+    assert np.abs(u @ u.conj().T - np.eye(8)).max() < 1e-13
+    psi = ro.haar_rand_state(4)
+    assert psi.shape == (4, 1) and abs(np.vdot(psi, psi) - 1) < 1e-13
+    rho = ro.bures_measure_state_matrix(4)
+    assert abs(np.trace(rho) - 1) < 1e-13 and np.linalg.eigvalsh(rho).min() > -1e-14
+    choi = ro.rand_map_with_BCSZ_dist(4, 5)
+    pt = np.einsum("iaja->ij", choi.reshape(4, 4, 4, 4))      # trace preserving: Tr_out = identity
+    assert np.abs(pt - np.eye(4)).max() < 1e-12
+    assert np.linalg.eigvalsh(choi).min() > -1e-12
+    assert np.linalg.matrix_rank(choi, tol=1e-9) == 5
+
+
+def test_permute_tensor_factors(g):
+    from fbx.operator_tools import permute_tensor_factors
+    for k in range(5):
+        dims = g[f"perm{k}_dims"]
+        dims = int(dims[0]) if dims.size == 1 else [int(x) for x in dims]
+        got = permute_tensor_factors(dims, [int(x) for x in g[f"perm{k}_perm"]])
+        assert np.array_equal(got, g[f"perm{k}_out"])
+    # SWAP on two qubits exchanges the factors of a product operator
+    swap = permute_tensor_factors(2, [1, 0])
+    a, b = np.diag([1.0, 2.0]), np.array([[0.0, 1.0], [1.0, 0.0]])
+    assert np.allclose(swap @ np.kron(a, b) @ swap.T, np.kron(b, a))
+
+
+def test_partial_trace_outer_inner(g):
+    from fbx.operator_tools import calculational as calc
+    for k in range(6):
+        got = calc.partial_trace(g["pt_in"], [int(x) for x in g[f"pt{k}_keep"]], [2, 3, 4])
+        assert got.shape == g[f"pt{k}_out"].shape
+        assert np.abs(got - g[f"pt{k}_out"]).max() < 1e-13
+    assert np.abs(calc.outer_product(g["ket_a"], g["ket_b"]) - g["outer"]).max() < 1e-15
+    assert np.abs(calc.inner_product(g["ket_a"], g["ket_b"]) - g["inner"]).max() < 1e-14
+    with pytest.raises(ValueError):
+        calc.outer_product(np.ones((1, 3)), np.ones((3, 1)))
+
+
+def test_oracle_spectral_measures(g):
+    from fbx_oracle import measures as om
+    for d in (2, 4):
+        for b in range(3):
+            q, s = om.quantum_chernoff_bound(g[f"qcb{d}_rho"][b], g[f"qcb{d}_sigma"][b])
+            assert abs(q - g[f"qcb{d}"][b, 0]) < 1e-9
+    for name in ("herm16", "gen4", "gen16"):
+        got = om.watrous_bounds(g[f"wat_{name}"])
+        assert np.allclose(got, g[f"wat_{name}_out"], rtol=1e-12)
+
+
+def test_diamond_norm_needs_cvxpy_like_the_reference():
+    from fbx import distance_measures as dm
+    try:
+        import cvxpy  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            dm.diamond_norm_distance(np.eye(4), np.eye(4))

@@ -1,0 +1,95 @@
+"""Device eigensolver for 32 x 32 / 64 x 64, and the helpers that sit on it: sqrtm_psd, quantum
+Chernoff bound, Watrous bounds, choi2kraus for three qubits -- against reference outputs
+(tests/golden/extras.npz) and numpy."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(GOLD, "extras.npz"))
+
+
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32, 64])
+def test_eigh_all_sizes(gpu, N):
+    from fbx import _lib
+    rng = np.random.default_rng(N)
+    B = 5
+    a = rng.normal(size=(B, N, N)) + 1j * rng.normal(size=(B, N, N))
+    herm = a + a.conj().transpose(0, 2, 1)
+    low = np.tril(herm) + 1j * np.triu(rng.normal(size=(B, N, N)), 1)      # upper triangle is garbage
+    w, v = _lib.eigh_batch(low)
+    for b in range(B):
+        assert np.abs(w[b] - np.linalg.eigvalsh(herm[b])).max() < 1e-12 * N
+        assert np.abs(v[b].conj().T @ v[b] - np.eye(N)).max() < 1e-12
+        assert np.abs(herm[b] @ v[b] - v[b] * w[b]).max() < 1e-11 * N
+    assert (np.diff(w, axis=1) >= 0).all()
+    w_only = _lib.eigh_batch(low, eigenvectors=False)
+    assert np.array_equal(w_only, w)
+    degenerate = np.tile(np.eye(N)[None] * 3.0, (2, 1, 1))
+    wd, vd = _lib.eigh_batch(degenerate)
+    assert np.abs(wd - 3.0).max() == 0 and np.abs(vd - np.eye(N)).max() == 0
+
+
+def test_sqrtm_psd(gpu, g):
+    from fbx.operator_tools import calculational as calc
+    for N in (4, 16):
+        got = calc.sqrtm_psd(g[f"psd{N}"])
+        assert np.abs(got - g[f"sqrtm{N}"]).max() < 1e-11
+        assert np.abs(got @ got - g[f"psd{N}"]).max() < 1e-10
+    with pytest.raises(ValueError):
+        calc.sqrtm_psd(np.array([[np.nan, 0], [0, 1.0]]))
+
+
+def test_quantum_chernoff_bound(gpu, g):
+    from fbx import distance_measures as dm
+    for d in (2, 4):
+        for b in range(3):
+            q, s = dm.quantum_chernoff_bound(g[f"qcb{d}_rho"][b], g[f"qcb{d}_sigma"][b])
+            assert abs(q - g[f"qcb{d}"][b, 0]) < 1e-9
+            assert abs(s - g[f"qcb{d}"][b, 1]) < 1e-4          # flat minimum: argmin to optimiser tolerance
+    # reference known answers (tests/test_distance_measures.py:118-141)
+    rho = np.array([[1.0, 0.0], [0.0, 0.0]])
+    psi = np.array([[np.cos(np.pi / 4)], [np.sin(np.pi / 4)]])
+    assert np.allclose(dm.quantum_chernoff_bound(rho, psi @ psi.T)[0], 0.5)
+    G = np.array([[0.0, -1.0], [1.0, 0.0]])
+    r = np.diag([0.9, 0.1])
+    assert np.allclose(dm.quantum_chernoff_bound(r, G @ r @ G.T)[0], 0.6)
+    # complex states work too (the objective is real by construction)
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4)); a = a @ a.conj().T; a /= np.trace(a).real
+    q, s = dm.quantum_chernoff_bound(a, a)
+    assert abs(q - 1.0) < 1e-12
+
+
+def test_watrous_bounds(gpu, g):
+    from fbx import distance_measures as dm
+    for name in ("herm16", "gen4", "gen16"):
+        got = dm.watrous_bounds(g[f"wat_{name}"])
+        assert np.allclose(got, g[f"wat_{name}_out"], rtol=1e-11)
+    rng = np.random.default_rng(8)
+    x = rng.normal(size=(64, 64)) + 1j * rng.normal(size=(64, 64))       # A^H A route
+    assert np.isclose(dm.watrous_bounds(x)[0], np.linalg.svd(x, compute_uv=False).sum(), rtol=1e-9)
+    h = x + x.conj().T
+    assert np.isclose(dm.watrous_bounds(h)[0], np.abs(np.linalg.eigvalsh(h)).sum(), rtol=1e-11)
+    with pytest.raises(ValueError):
+        dm.watrous_bounds(np.ones((3, 3)))
+    with pytest.raises(ValueError):
+        dm.watrous_bounds(np.ones((4, 4, 4)))
+
+
+def test_choi2kraus_three_qubits_round_trip(gpu):
+    """superoperator_transformations.py:325-336 through the 64 x 64 device eigensolver; Kraus lists
+    are only defined up to phases, so parity is on the rebuilt Choi matrix, as in the reference's
+    own test (tests/test_superoperator_transformations.py:215-224)."""
+    from fbx.operator_tools import choi2kraus, kraus2choi
+    g3 = np.load(os.path.join(GOLD, "superops_3q.npz"))
+    choi = g3["kraus4_choi"][0]
+    ks = choi2kraus(choi)
+    assert len(ks) == 4 and ks[0].shape == (8, 8)
+    assert np.abs(kraus2choi(ks) - choi).max() < 1e-11
