@@ -126,3 +126,32 @@ def flatten_results(results, qubits, kind):
         _design_cache[d.key()] = d
         cached = d
     return cached, e, c
+
+
+# --------------------------------------------------------------------------------------------------
+# compact structure-of-arrays archive for the batched estimators: one design shared
+# by B experiments, label codes as in include/fbx.h
+# --------------------------------------------------------------------------------------------------
+def save_batch(fn, design: "Design", expectations, total_counts=None):
+    """Write (design, expectations[B, m], total_counts[B, m]) to a compressed ``.npz``."""
+    e = np.asarray(expectations, dtype=np.float64).reshape(-1, design.m)
+    arrays = dict(format=np.array("fbx-soa-1"), n_qubits=np.array(design.n_qubits),
+                  kind=np.array(design.kind), in_labels=design.in_labels, paulis=design.paulis,
+                  coefs=design.coefs, expectations=e)
+    if total_counts is not None:
+        arrays["total_counts"] = np.asarray(total_counts, dtype=np.float64).reshape(e.shape)
+    np.savez_compressed(fn, **arrays)
+    return fn
+
+
+def load_batch(fn):
+    """Inverse of :func:`save_batch`: ``(Design, expectations, total_counts or None)``; the design is
+    taken from the content-keyed cache when an identical one already lives on the device."""
+    with np.load(fn) as z:
+        if str(z["format"]) != "fbx-soa-1":
+            raise ValueError(f"{fn}: not an fbx structure-of-arrays archive")
+        d = Design(int(z["n_qubits"]), str(z["kind"]), z["in_labels"], z["paulis"], z["coefs"])
+        e = z["expectations"]
+        c = z["total_counts"] if "total_counts" in z.files else None
+    d = _design_cache.setdefault(d.key(), d)
+    return d, e, c

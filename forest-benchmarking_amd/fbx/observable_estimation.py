@@ -7,9 +7,10 @@ to what the estimators read: ``term[qubit]`` and ``.coefficient``).  The estimat
 duck-typed, so the reference's own objects work as well.
 """
 import ctypes as _C
+import json
 import re
 from dataclasses import dataclass
-from typing import List, Tuple, Union
+from typing import Dict, Iterable, List, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -158,6 +159,78 @@ class ExperimentResult:
     calibration_expectation: Union[float, complex] = None
     calibration_std_err: Union[float, complex] = None
     calibration_counts: int = None
+
+
+    def serializable(self):
+        """observable_estimation.py:721-733 (same keys, setting as its string form)."""
+        return {
+            'type': 'ExperimentResult',
+            'setting': str(self.setting),
+            'expectation': self.expectation,
+            'std_err': self.std_err,
+            'total_counts': self.total_counts,
+            'raw_expectation': self.raw_expectation,
+            'raw_std_err': self.raw_std_err,
+            'calibration_expectation': self.calibration_expectation,
+            'calibration_std_err': self.calibration_std_err,
+            'calibration_counts': self.calibration_counts,
+        }
+
+
+# ==================================================================================================
+# interchange (observable_estimation.py:356-389) and result bookkeeping (:1145-1173)
+# ==================================================================================================
+class OperatorEncoder(json.JSONEncoder):
+    def default(self, o):
+        if isinstance(o, ExperimentSetting):
+            return str(o)
+        if isinstance(o, ExperimentResult):
+            return o.serializable()
+        if isinstance(o, (np.integer,)):
+            return int(o)
+        if isinstance(o, (np.floating,)):
+            return float(o)
+        return super().default(o)
+
+
+def to_json(fn, obj):
+    """observable_estimation.py:367-373: same file layout as the reference (indent 2, settings as
+    ``'X+_0 * Z-_1→(1+0j)*X0Z1'`` strings), for ExperimentSetting / ExperimentResult objects and
+    lists of them."""
+    with open(fn, 'w') as f:
+        json.dump(obj, f, cls=OperatorEncoder, indent=2, ensure_ascii=False)
+    return fn
+
+
+def _result_object_hook(obj):
+    if obj.get('type') == 'ExperimentResult':
+        fields = {k: v for k, v in obj.items() if k != 'type'}
+        fields['setting'] = ExperimentSetting.from_str(fields['setting'])
+        return ExperimentResult(**fields)
+    return obj
+
+
+def read_json(fn):
+    """observable_estimation.py:384-389.  Unlike the reference (whose hook only rebuilds
+    ObservablesExperiment and leaves results as dicts) ExperimentResult records come back as
+    ExperimentResult objects, ready for the estimators; files written by the reference parse too."""
+    with open(fn) as f:
+        return json.load(f, object_hook=_result_object_hook)
+
+
+def get_results_by_qubit_groups(results: Iterable, qubit_groups: Sequence[Sequence[int]]) -> Dict[Tuple[int, ...], list]:
+    """observable_estimation.py:1145-1173: results whose observable acts inside a group, keyed by
+    the sorted group; order kept, a result may land in several overlapping groups.  One entry is
+    the natural unit of the batched estimators."""
+    groups = [tuple(sorted(g)) for g in qubit_groups]
+    out = {g: [] for g in groups}
+    sets = [set(g) for g in groups]
+    for res in results:
+        acts_on = set(res.setting.observable.get_qubits())
+        for g, gs in zip(groups, sets):
+            if acts_on <= gs:
+                out[g].append(res)
+    return out
 
 
 # ==================================================================================================

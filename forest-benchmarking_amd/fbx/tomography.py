@@ -317,3 +317,46 @@ def pgdb_process_estimate(results: List[ExperimentResult], qubits: List[int],
     """tomography.py:542-594 (projected gradient descent with backtracking)."""
     design, e, c = flatten_results(results, qubits, "process")
     return pgdb_process_estimate_batch(design, e, c, trace_preserving)[0]
+
+
+def estimate_by_qubit_groups(results, qubit_groups, kind="process", estimator="pgdb", **kwargs):
+    """Tomography of several qubit groups measured in one (merged) experiment: split the results
+    with ``get_results_by_qubit_groups`` (observable_estimation.py:1145-1173, the process notebook's
+    per-pair loop), keep for every group the settings that belong to its tomography (observable and,
+    for processes, the prepared state both inside the group), and run every set of groups that share
+    a design as ONE batched call.  Returns ``{sorted group tuple: estimate}``.
+
+    ``estimator``: 'pgdb' | 'linear_inv' for processes, 'mle' | 'linear_inv' for states; keyword
+    arguments go to the batched estimator."""
+    from .observable_estimation import get_results_by_qubit_groups
+    if kind not in ("process", "state"):
+        raise ValueError("kind must be 'process' or 'state'")
+    by_group = get_results_by_qubit_groups(results, qubit_groups)
+    batches = {}                                   # design key -> (design, [group], [e], [c])
+    for group, res in by_group.items():
+        res = [r for r in res if len(r.setting.observable.get_qubits()) > 0]
+        if not res:
+            raise ValueError(f"no results for qubit group {group}")
+        design, e, c = flatten_results(res, list(group), kind)
+        entry = batches.setdefault(design.key(), (design, [], [], []))
+        entry[1].append(group); entry[2].append(e); entry[3].append(c)
+    out = {}
+    for design, groups, es, cs in batches.values():
+        e, c = np.stack(es), np.stack(cs)
+        if kind == "process":
+            if estimator == "pgdb":
+                est = pgdb_process_estimate_batch(design, e, c, **kwargs)
+            elif estimator == "linear_inv":
+                est = linear_inv_process_estimate_batch(design, e)
+            else:
+                raise ValueError("process estimators: 'pgdb', 'linear_inv'")
+        else:
+            if estimator == "mle":
+                est = iterative_mle_state_estimate_batch(design, e, c, **kwargs)
+            elif estimator == "linear_inv":
+                est = linear_inv_state_estimate_batch(design, e)
+            else:
+                raise ValueError("state estimators: 'mle', 'linear_inv'")
+        for g, x in zip(groups, est):
+            out[g] = x
+    return out

@@ -194,6 +194,12 @@ int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, 
                              const uint8_t* d_obs_mask, const double* d_coefs, int beta_prior,
                              double* d_mean_out, double* d_var_out);
 
+/* estimate_dfe (direct_fidelity_estimation.py:224-307), batched: for each of B experiments with m
+ * settings on n_qubits, expect[B][m] and std_err[B][m] -> the direct fidelity estimate and its standard
+ * error; kind = FBX_KIND_STATE (state fidelity) or FBX_KIND_PROCESS (average gate fidelity). */
+int fbx_dfe_estimate(int n_qubits, int kind, int64_t B, int64_t m, const double* expect,
+                     const double* std_err, double* mean_out, double* err_out);
+
 /* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
  * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16, 32, 64}.  This is the
  * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators

@@ -24,3 +24,25 @@ def shots_to_obs_moments(bitarray, obs_mask, coeff=1.0, use_beta_dist_unbiased_p
 def ratio_variance(a, var_a, b, var_b):
     """observable_estimation.py:1052-1090."""
     return var_a / b ** 2 + (a ** 2 * var_b) / b ** 4
+
+
+def estimate_dfe(expectations, std_errs, n_qubits, kind):
+    """direct_fidelity_estimation.py:286-307 on plain arrays: (mean fidelity, standard error).
+
+    state:   F = 1/d + (1 - 1/d) mean(e)
+    process: average gate fidelity from the Choi-state fidelity p = 1/d^2 + (1 - 1/d^2) mean(e),
+             F = (d^2 p + d) / (d^2 + d)
+    The error bar is the root of the summed squared standard errors over m, times dF/dmean(e)."""
+    d = 2.0 ** n_qubits
+    e = np.asarray(expectations, dtype=float)
+    s = np.asarray(std_errs, dtype=float)
+    rms = np.sqrt(np.sum(s * s)) / e.size
+    which = kind.lower()
+    if which == "state":
+        slope = 1.0 - 1.0 / d
+        return 1.0 / d + slope * e.mean(), slope * rms
+    if which == "process":
+        slope = 1.0 - 1.0 / d ** 2
+        p = 1.0 / d ** 2 + slope * e.mean()
+        return (d * d * p + d) / (d * d + d), d / (d + 1.0) * slope * rms
+    raise ValueError("Kind can only be 'state' or 'process'.")

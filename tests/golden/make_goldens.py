@@ -222,6 +222,18 @@ def make_extras():
     for name, x in (("herm16", herm16), ("gen4", gen4), ("gen16", gen16)):
         out[f"wat_{name}"] = x
         out[f"wat_{name}_out"] = np.array(DM.watrous_bounds(x))
+    # direct fidelity estimate (direct_fidelity_estimation.py:224-307) on the reference's own records
+    import importlib
+    DFE = importlib.import_module("forest.benchmarking.direct_fidelity_estimation")
+    for n in (1, 2, 3):
+        qs, m = list(range(n)), 5 + 2 * n
+        e, se = rs.uniform(-1, 1, size=m), rs.uniform(0, 0.1, size=m)
+        res = [OE.ExperimentResult(
+            setting=OE.ExperimentSetting(OE.zeros_state(qs), ref.PauliTerm.from_list([("XYZ"[(k + q) % 3], q) for q in qs])),
+            expectation=float(e[k]), std_err=float(se[k]), total_counts=100) for k in range(m)]
+        out[f"dfe{n}_e"], out[f"dfe{n}_se"] = e, se
+        out[f"dfe{n}_state"] = np.array(DFE.estimate_dfe(res, "state"))
+        out[f"dfe{n}_process"] = np.array(DFE.estimate_dfe(res, "process"))
     np.savez_compressed(os.path.join(HERE, "extras.npz"), **out)
     print("extras done")
 

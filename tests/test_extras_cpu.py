@@ -89,3 +89,47 @@ def test_diamond_norm_needs_cvxpy_like_the_reference():
     except ImportError:
         with pytest.raises(ImportError):
             dm.diamond_norm_distance(np.eye(4), np.eye(4))
+
+
+def test_oracle_dfe_matches_reference(g):
+    from fbx_oracle import acquisition as oa
+    for n in (1, 2, 3):
+        for kind in ("state", "process"):
+            got = oa.estimate_dfe(g[f"dfe{n}_e"], g[f"dfe{n}_se"], n, kind)
+            assert np.allclose(got, g[f"dfe{n}_{kind}"], rtol=1e-14, atol=0)
+    with pytest.raises(ValueError):
+        oa.estimate_dfe([0.1], [0.1], 1, "gate")
+
+
+def test_results_by_qubit_groups_and_json_round_trip(tmp_path):
+    """observable_estimation.py:1145-1173 with the reference's own example
+    (tests/test_observable_estimation.py:1934-1965), and the JSON layout of :356-389, :721-733."""
+    from fbx import observable_estimation as oe
+    def res(ops, e):
+        st = oe.zeros_state(sorted(q for _, q in ops))
+        return oe.ExperimentResult(setting=oe.ExperimentSetting(st, oe.PauliTerm.from_list(ops)),
+                                   expectation=e, std_err=0.01, total_counts=40)
+    er1, er2, er3, er4 = res([("Z", 0)], 0.9), res([("Z", 1)], 0.8), res([("Z", 0), ("Z", 1)], 0.7), res([("X", 0), ("Z", 2)], 0.6)
+    by = oe.get_results_by_qubit_groups([er1, er2, er3, er4], [(0,), (1,), (2, 0)])
+    assert by == {(0,): [er1], (1,): [er2], (0, 2): [er1, er4]}
+    fn = oe.to_json(str(tmp_path / "results.json"), [er1, er3, er4])
+    import json
+    raw = json.load(open(fn))
+    assert raw[1]["type"] == "ExperimentResult" and raw[1]["setting"] == "Z+_0 * Z+_1→(1+0j)*Z0Z1"
+    assert set(raw[0]) == {"type", "setting", "expectation", "std_err", "total_counts", "raw_expectation",
+                           "raw_std_err", "calibration_expectation", "calibration_std_err", "calibration_counts"}
+    back = oe.read_json(fn)
+    assert back == [er1, er3, er4]
+    assert str(oe.ExperimentSetting.from_str("X+_0 * SIC2_1→(1+0j)*X0Y1")) == "X+_0 * SIC2_1→(1+0j)*X0Y1"
+
+
+def test_soa_archive_round_trip(tmp_path):
+    from fbx import design as fd
+    d = fd.process_design(1, "sic")
+    rng = np.random.default_rng(0)
+    e, c = rng.uniform(-1, 1, size=(3, d.m)), np.full((3, d.m), 500.0)
+    fn = fd.save_batch(str(tmp_path / "batch.npz"), d, e, c)
+    d2, e2, c2 = fd.load_batch(fn)
+    assert d2.key() == d.key() and np.array_equal(e2, e) and np.array_equal(c2, c)
+    fd.save_batch(fn, d, e)
+    assert fd.load_batch(fn)[2] is None

@@ -93,3 +93,47 @@ def test_choi2kraus_three_qubits_round_trip(gpu):
     ks = choi2kraus(choi)
     assert len(ks) == 4 and ks[0].shape == (8, 8)
     assert np.abs(kraus2choi(ks) - choi).max() < 1e-11
+
+
+def test_dfe_estimate(gpu, g):
+    from fbx import direct_fidelity_estimation as dfe
+    from fbx import observable_estimation as oe
+    for n in (1, 2, 3):
+        e, se = g[f"dfe{n}_e"], g[f"dfe{n}_se"]
+        for kind in ("state", "process"):
+            mean, err = dfe.estimate_dfe_batch(np.tile(e, (4, 1)), np.tile(se, (4, 1)), n, kind)
+            assert np.allclose(mean, g[f"dfe{n}_{kind}"][0], rtol=1e-14, atol=0)
+            assert np.allclose(err, g[f"dfe{n}_{kind}"][1], rtol=1e-14, atol=0)
+        qs = list(range(n))
+        res = [oe.ExperimentResult(setting=oe.ExperimentSetting(oe.zeros_state(qs), oe.PauliTerm.from_list(
+            [("XYZ"[(k + q) % 3], q) for q in qs])), expectation=float(e[k]), std_err=float(se[k]), total_counts=100)
+            for k in range(len(e))]
+        got = dfe.estimate_dfe(res, "process")
+        assert np.allclose(got, g[f"dfe{n}_process"], rtol=1e-14, atol=0)
+    big_e = np.random.default_rng(1).uniform(-1, 1, size=(1000, 4095))
+    mean, err = dfe.estimate_dfe_batch(big_e, np.full_like(big_e, 0.03), 6, "state")
+    assert np.allclose(mean, 1 / 64 + (63 / 64) * big_e.mean(axis=1), rtol=1e-13)
+    assert np.allclose(err, (63 / 64) * 0.03 / np.sqrt(4095), rtol=1e-13)
+    with pytest.raises(ValueError):
+        dfe.estimate_dfe_batch(big_e[:1], big_e[:1], 2, "gate")
+
+
+def test_estimate_by_qubit_groups_batches_pairs(gpu):
+    """Two disjoint qubit pairs measured in one merged experiment: one batched PGDB call, results
+    identical to the per-pair calls (the process notebook's loop over get_results_by_qubit_groups)."""
+    from fbx import synthetic, tomography
+    from fbx import observable_estimation as oe
+    design, us, e, c = synthetic.process_batch(2, "sic", 2)
+    results = []
+    for b, pair in enumerate([(0, 1), (4, 5)]):
+        for k, s in enumerate(tomography.generate_process_tomography_settings(list(pair), "sic")):
+            results.append(oe.ExperimentResult(setting=s, expectation=float(e[b, k]), std_err=0.0,
+                                               total_counts=int(c[b, k])))
+    got = tomography.estimate_by_qubit_groups(results, [(0, 1), (5, 4)], kind="process")
+    assert set(got) == {(0, 1), (4, 5)}
+    want01 = tomography.pgdb_process_estimate([r for r in results[:design.m]], [0, 1])
+    assert np.array_equal(got[(0, 1)], want01)
+    want45 = tomography.pgdb_process_estimate([r for r in results[design.m:]], [4, 5])
+    assert np.array_equal(got[(4, 5)], want45)
+    lin = tomography.estimate_by_qubit_groups(results, [(0, 1)], kind="process", estimator="linear_inv")
+    assert np.abs(lin[(0, 1)] - tomography.linear_inv_process_estimate(results[:design.m], [0, 1])).max() == 0
