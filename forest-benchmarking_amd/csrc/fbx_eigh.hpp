@@ -257,6 +257,8 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
         wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
     }
     const int dI = I * NB + I, dJ = J * NB + J;            // lanes owning the pivot blocks
+    const int src_lane = (lane & 63) - J + I;              // lane (I, I): same row, NB | 64 keeps rows inside a wave
+    (void)dI;
     if (act && init_identity) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -282,8 +284,10 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
+#ifdef FBX_JACOBI_TWO_CHAINS
             const double aI = Ms[0 * LS + dI].re, dI_ = Ms[3 * LS + dI].re;
             const cplx bI = Ms[1 * LS + dI];
+#endif
             const double aJ = Ms[0 * LS + dJ].re, dJ_ = Ms[3 * LS + dJ].re;
             const cplx bJ = Ms[1 * LS + dJ];
             cplx m00 = Ms[0 * LS + me], m01 = Ms[1 * LS + me];
@@ -291,8 +295,15 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             cplx v0p = Vs[0 * LS + me], v0q = Vs[1 * LS + me];
             cplx v1p = Vs[2 * LS + me], v1q = Vs[3 * LS + me];
             __syncthreads();            // everything read before anyone overwrites it
-            const JRot rI = jacobi_rotation(aI, dI_, bI.re, bI.im);
             const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
+#ifdef FBX_JACOBI_TWO_CHAINS
+            const JRot rI = jacobi_rotation(aI, dI_, bI.re, bI.im);
+#else
+            // the row rotation (pair I) is the column rotation of the lane (I, I) of this block row,
+            // which sits in the same wavefront: fetch it instead of computing a second chain
+            JRot rI;
+            rI.c = __shfl(rJ.c, src_lane); rI.sr = __shfl(rJ.sr, src_lane); rI.si = __shfl(rJ.si, src_lane);
+#endif
             jacobi_apply_m(rI.c, rI.sr, rI.si, rJ.c, rJ.sr, rJ.si, m00, m01, m10, m11);
             jacobi_apply_v(rJ.c, rJ.sr, rJ.si, v0p, v0q, v1p, v1q);
             if (I == J) {   // the annihilated pair: exact zeros, real diagonal

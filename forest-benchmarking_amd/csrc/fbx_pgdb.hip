@@ -299,7 +299,7 @@ __global__ void debug_log_kernel(const double* x, double* out, long long n) {
     if (i < n) out[i] = fast_log_pos(x[i]);
 }
 
-static long long* g_phase_out = nullptr;   // diagnostics: set by fbx_debug_set_phase_buffer
+long long* g_phase_out = nullptr;          // diagnostics: set by fbx_debug_set_phase_buffer (also read by fbx_pgdb3.hip)
 
 template <int NQ, int MAXJ>
 static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,

@@ -11,8 +11,11 @@
 //
 // Reference: tomography.py:542-633, operator_tools/project_superoperators.py:19-144.
 #include "fbx_choi.hpp"
+#include <cstdlib>
 
 namespace fbx {
+
+extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics)
 
 namespace p3 {
 constexpr int NQ = 3, d = 8, D = 64, NB = 32, NT = 1024, LD = 64, LDs = d + 1;
@@ -26,6 +29,7 @@ struct Lds {
     double* Rt;      // [4096] Pauli coefficients, TRANSPOSED: Rt[j * 64 + i] = R[i][j]
     // overlay on Rt (alive only while R is dead):
     cplx* pt; cplx* pts; cplx* ptV; double* lam; double* red;
+    PhaseClock* pc;  // diagnostics (-DFBX_PHASE_TIMERS)
     __device__ void carve(char* p) {
         Ms = (cplx*)p; Vs = Ms + D * D; Mw = Vs; T = (double*)p;
         Rt = (double*)(p + 2 * sizeof(cplx) * D * D);
@@ -98,14 +102,19 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
     __syncthreads();
     sys_store<D>(L.Ms, t, h);
     __syncthreads();
+    PH_STOP(*L.pc, 2);
     if (warm) rotate_into_basis(L, Tg, t);
+    PH_STOP(*L.pc, 6);
     sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, !warm, L.red);
+    PH_STOP(*L.pc, 0);
     if (t < D) {
         const double l = L.Ms[sys_index<D>(t, t)].re;
         L.lam[t] = l < 0.0 ? 0.0 : l;
     }
     __syncthreads();
-    return reconstruct_blk<D>(L.Vs, L.lam, t);
+    const Blk out = reconstruct_blk<D>(L.Vs, L.lam, t);
+    PH_STOP(*L.pc, 1);
+    return out;
 }
 
 // ---- partial trace over the output space into L.pt (calculational.py:5-35); stages x through Mw
@@ -282,10 +291,11 @@ __global__ void __launch_bounds__(1024)
 pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
              int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out,
              int* __restrict__ iters_out, int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-             double* __restrict__ cost_out, cplx* __restrict__ scratch) {
+             double* __restrict__ cost_out, cplx* __restrict__ scratch, long long* __restrict__ phase_out, int* __restrict__ sweeps_out) {
     using namespace p3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds L; L.carve(smem);
+    PhaseClock pc; pc.reset(); L.pc = &pc;
     const int t = threadIdx.x;
     const long long item = blockIdx.x;
     const int m = des.m, S = des.S;
@@ -347,12 +357,16 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
     double old_cost = 0.0, new_cost = 0.0;
     bool have_cost = false;
 
+    PH_START(pc);
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
         choi_to_pauli(est, L, t);
+        PH_STOP(pc, 3);
         predict_table(des, L, t);
         load_probs(pep, pem);
+        PH_STOP(pc, 7);
         if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }
+        PH_STOP(pc, 5);
 
         // ---- gradient (tomography.py:617-633): W[i][s] = sum over the settings of state s.
         // Threads own CONTIGUOUS runs of the state-grouped settings, so the identity row W[0][s]
@@ -410,16 +424,21 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         }
         __syncthreads();
         gradient_coefficients(des, L, W, t);
+        PH_STOP(pc, 4);
         const Blk grad = pauli_to_choi(L, t);
+        PH_STOP(pc, 3);
 
         const Blk x = blk_axpy(est, -inv_mu, grad);
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch ? scratch + (size_t)blockIdx.x * D * D : nullptr);
         const Blk upd = blk_sub(proj, est);
+        PH_STOP(pc, 2);
 
         choi_to_pauli(upd, L, t);
+        PH_STOP(pc, 3);
         predict_table(des, L, t);
         load_probs(pup, pum);
+        PH_STOP(pc, 7);
 
         double ipr, ipi;
         blk_dotc(upd, grad, ipr, ipi);
@@ -435,6 +454,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         }
         est = blk_axpy(est, alpha, upd);
         ++iters;
+        PH_STOP(pc, 5);
         if (mode == FBX_MODE_CONVERGE) {
             if (old_cost - new_cost < STOP) break;
             if (max_iters > 0 && iters >= max_iters) break;
@@ -450,11 +470,15 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
             o[0] = est.re[e]; o[1] = est.im[e];
         }
     }
+#ifdef FBX_PHASE_TIMERS
+    if (t == 0 && phase_out) for (int i = 0; i < FBX_NPHASE; ++i) phase_out[item * FBX_NPHASE + i] = pc.acc[i];
+#endif
     if (t == 0) {
         if (iters_out) iters_out[item] = iters;
         if (dykstra_out) dykstra_out[item] = dyk;
         if (backtracks_out) backtracks_out[item] = backtracks;
         if (cost_out) cost_out[item] = have_cost ? new_cost : 0.0;
+        if (sweeps_out) sweeps_out[item] = sweeps;      // FBX_DEBUG_SWEEPS: overrides the backtrack count
     }
 }
 
@@ -478,7 +502,9 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), des->dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
-                           dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch);
+                           dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch,
+                           g_phase_out ? g_phase_out + b0 * 8 : nullptr,
+                           (getenv("FBX_DEBUG_SWEEPS") && bt) ? bt + b0 : nullptr);
     }
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(stream());
