@@ -241,11 +241,92 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 // the wave must call; (N/2)^2 of them work.  Returns the number of sweeps.
 //
 // Every lane derives the two rotations it needs from the pivot blocks in LDS.
+// Single-wavefront version with the eigenvector update software-pipelined one round behind the
+// matrix update: v <- v R_J of round r does not feed the next pivots, so it is issued inside the
+// dependent rsqrt chain of round r + 1, where the wave would otherwise idle.  LDS instructions of
+// one wavefront execute in program order, so no barrier or wait separates the rounds.
+#ifndef FBX_JACOBI_NO_PIPELINE
+template <int N>
+__device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity) {
+    constexpr int NB = N / 2, LS = NB * NB;
+    static_assert(LS == 64, "every lane of the wavefront owns one 2x2 block");
+    const int I = lane / NB, J = lane % NB;
+    const int me = lane;
+    int wm[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
+        wm[e] = ((sa & 1) * 2 + (sb & 1)) * LS + (sa >> 1) * NB + (sb >> 1);
+        wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
+    }
+    const int dJ = J * NB + J;
+    const int src_lane = (lane & 63) - J + I;
+    // The eigenvector block is kept one seat permutation BEHIND the matrix: every round first
+    // finishes the pending update (rotate, write to the seats, read back), so the registers start
+    // with the columns pulled back through the permutation -- V[row][seat(col)] -- and the first
+    // pending rotation is the identity.
+    cplx v0p, v0q, v1p, v1q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cplx v;
+        if (init_identity) {
+            v.re = (2 * I + (e >> 1) == jacobi_seat<N>(2 * J + (e & 1))) ? 1.0 : 0.0; v.im = 0.0;
+        } else v = Vs[wv[e]];
+        if (e == 0) v0p = v; else if (e == 1) v0q = v; else if (e == 2) v1p = v; else v1q = v;
+    }
+    double pc = 1.0, psr = 0.0, psi = 0.0;          // rotation whose eigenvector update is still pending
+    int sweep = 0;
+    for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
+        {
+            double o2 = 0.0, n2 = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const cplx v = Ms[e * LS + me];
+                const double a2 = v.re * v.re + v.im * v.im;
+                n2 += a2;
+                if (!(I == J && (e == 0 || e == 3))) o2 += a2;
+            }
+            o2 = uniform(wave_sum(o2));
+            n2 = uniform(wave_sum(n2));
+            if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
+        }
+        for (int r = 0; r < N - 1; ++r) {
+            const double aJ = Ms[0 * LS + dJ].re, dJ_ = Ms[3 * LS + dJ].re;
+            const cplx bJ = Ms[1 * LS + dJ];
+            cplx m00 = Ms[0 * LS + me], m01 = Ms[1 * LS + me];
+            cplx m10 = Ms[2 * LS + me], m11 = Ms[3 * LS + me];
+            // pending eigenvector update of the previous round (identity the very first time), written
+            // to its seats and read back as this round's block -- independent of the chain below
+            jacobi_apply_v(pc, psr, psi, v0p, v0q, v1p, v1q);
+            Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
+            v0p = Vs[0 * LS + me]; v0q = Vs[1 * LS + me]; v1p = Vs[2 * LS + me]; v1q = Vs[3 * LS + me];
+            const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
+            JRot rI;
+            rI.c = __shfl(rJ.c, src_lane); rI.sr = __shfl(rJ.sr, src_lane); rI.si = __shfl(rJ.si, src_lane);
+            jacobi_apply_m(rI.c, rI.sr, rI.si, rJ.c, rJ.sr, rJ.si, m00, m01, m10, m11);
+            if (I == J) {   // the annihilated pair: exact zeros, real diagonal (see jacobi_eigh_simple)
+                m01.re = m01.im = 0.0; m10.re = m10.im = 0.0;
+                m00.im = 0.0; m11.im = 0.0;
+            }
+            Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;
+            pc = rJ.c; psr = rJ.sr; psi = rJ.si;
+        }
+    }
+    jacobi_apply_v(pc, psr, psi, v0p, v0q, v1p, v1q);      // flush the last pending update
+    Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
+    __syncthreads();
+    return sweep;
+}
+#endif
+
 template <int N, int NT = 64>
 __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true,
                                   double* red = nullptr) {
     constexpr int NB = N / 2, LS = NB * NB;
     static_assert(LS <= NT, "one lane per 2x2 block");
+#ifndef FBX_JACOBI_NO_PIPELINE
+    if constexpr (NT <= 64 && N == 16) { (void)red; return jacobi_eigh_wave<N>(Ms, Vs, lane, init_identity); }
+#endif
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
     const int me = act ? lane : 0;
@@ -294,7 +375,10 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             cplx m10 = Ms[2 * LS + me], m11 = Ms[3 * LS + me];
             cplx v0p = Vs[0 * LS + me], v0q = Vs[1 * LS + me];
             cplx v1p = Vs[2 * LS + me], v1q = Vs[3 * LS + me];
-            __syncthreads();            // everything read before anyone overwrites it
+            // everything read before anyone overwrites it.  A single wavefront needs no barrier and no
+            // wait here or after the writes: its LDS instructions execute in program order, so the
+            // reads above see the previous round and the next round's reads see the writes below.
+            if constexpr (NT > 64) __syncthreads();
             const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
 #ifdef FBX_JACOBI_TWO_CHAINS
             const JRot rI = jacobi_rotation(aI, dI_, bI.re, bI.im);
@@ -316,8 +400,9 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
                 Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;
                 Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
             }
-            __syncthreads();
+            if constexpr (NT > 64) __syncthreads();
         }
+        if constexpr (NT <= 64) __syncthreads();
     }
     return sweep;
 }
