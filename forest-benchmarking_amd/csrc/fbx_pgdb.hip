@@ -252,13 +252,67 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         double ipr, ipi;
         blk_dotc(upd, grad, ipr, ipi);
         ipr = uniform(wave_sum(ipr));
+#ifndef FBX_NO_SMALL_STEP
+        // Small steps: cost(alpha) = cost(0) - sum n log1p(alpha pu / pe), and cost(0) is old_cost.
+        // Once alpha |pu / pe| < 2^-9 for every outcome (and nothing sits at the clip), log1p is a
+        // degree-6 polynomial to < 1e-17 relative -- 8 instructions per outcome instead of ~40.  The
+        // long halving runs of stalled iterations live here.
+        double rp[MAXJ], rm[MAXJ];
+        double rmax = 0.0;
+        uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const double ap = pep[j], am = pem[j];
+            const bool fp = ap < 2.0 * PGDB_EPS, fm = am < 2.0 * PGDB_EPS;
+            double ip = __builtin_amdgcn_rcp(ap), im = __builtin_amdgcn_rcp(am);
+            ip = fma(fma(-ap, ip, 1.0), ip, ip); im = fma(fma(-am, im, 1.0), im, im);
+            rp[j] = fp ? 0.0 : pup[j] * ip; rm[j] = fm ? 0.0 : pum[j] * im;
+            rmax = fmax(rmax, fmax(fabs(rp[j]), fabs(rm[j])));
+            if (__ballot(fp)) near_clip |= 1u << (2 * j);
+            if (__ballot(fm)) near_clip |= 2u << (2 * j);
+        }
+        rmax = uniform(wave_max(rmax));
+        const bool small_ok = rmax == rmax;
+        auto log1p_small = [](double x) -> double {
+            double q = fma(x, -1.0 / 6.0, 0.2);
+            q = fma(x, q, -0.25);
+            q = fma(x, q, 1.0 / 3.0);
+            q = fma(x, q, -0.5);
+            q = fma(x, q, 1.0);
+            return x * q;
+        };
+        auto clipped_log = [](double p) -> double { return fast_log_pos(p < PGDB_EPS ? PGDB_EPS : p); };
+        auto cost_step = [&](double alpha) -> double {
+            if (!(small_ok && alpha * rmax < 0x1p-9)) return cost_at(alpha);
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j)
+                acc += npl[j] * log1p_small(alpha * rp[j]) + nmi[j] * log1p_small(alpha * rm[j]);
+            if (near_clip) {                 // the few outcomes at the clip: exact difference of clipped logs
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {
+                    if (near_clip & (1u << (2 * j))) {
+                        const double dl = clipped_log(fma(alpha, pup[j], pep[j])) - clipped_log(pep[j]);
+                        acc += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * dl : 0.0;
+                    }
+                    if (near_clip & (2u << (2 * j))) {
+                        const double dl = clipped_log(fma(alpha, pum[j], pem[j])) - clipped_log(pem[j]);
+                        acc += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * dl : 0.0;
+                    }
+                }
+            }
+            return old_cost - uniform(wave_sum(acc));
+        };
+#else
+        auto cost_step = [&](double alpha) -> double { return cost_at(alpha); };
+#endif
         double alpha = 1.0;
-        new_cost = cost_at(alpha);
+        new_cost = cost_step(alpha);
         double change = PGDB_GAMMA * alpha * ipr;
         while (new_cost > old_cost + change) {
             alpha *= 0.5;
             change *= 0.5;
-            new_cost = cost_at(alpha);
+            new_cost = cost_step(alpha);
             ++backtracks;
             if (alpha < PGDB_ALPHA_MIN) break;
         }
