@@ -328,6 +328,14 @@ static int launch_convert3(int from, int to, int64_t B, const double* in, int K,
     return FBX_OK;
 }
 
+// results of the sweep are written once and never re-read by the kernel: stream them past the caches
+typedef double fbx_d2v __attribute__((ext_vector_type(2)));
+#ifdef FBX_SWEEP_PLAIN_STORES
+#define FBX_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define FBX_STREAM_STORE(ptr, val) __builtin_nontemporal_store(fbx_d2v{(val).x, (val).y}, reinterpret_cast<fbx_d2v*>(ptr))
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // fused Kraus sweep (BASELINE config 3)
 // ---------------------------------------------------------------------------------------------
@@ -403,6 +411,37 @@ __device__ __forceinline__ void pauli_stage(cplx* M, int lane, int pbit, int qbi
     M[addr(i00)] = oi; M[addr(i11)] = oz; M[addr(i01)] = ox; M[addr(i10)] = oy;
 }
 
+// the same stage on two independent matrices at once: all eight loads are in flight before the first
+// butterfly, so the two transforms hide each other's LDS latency
+__device__ __forceinline__ void pauli_stage_pair(cplx* M0, int p0, int q0, double y0, cplx* M1, int p1, int q1,
+                                                 double y1, int lane) {
+    auto addr = [](int idx) { return (idx >> 4) * 17 + (idx & 15); };
+    int ix[2][4];
+    const int pb[2] = {p0, p1}, qb[2] = {q0, q1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int lo = pb[k] < qb[k] ? pb[k] : qb[k], hi = pb[k] < qb[k] ? qb[k] : pb[k];
+        const int base = insert_zero_bits(lane, lo, hi);
+        ix[k][0] = addr(base); ix[k][1] = addr(base | (1 << pb[k]) | (1 << qb[k]));
+        ix[k][2] = addr(base | (1 << qb[k])); ix[k][3] = addr(base | (1 << pb[k]));
+    }
+    cplx c[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c[0][e] = M0[ix[0][e]]; c[1][e] = M1[ix[1][e]]; }
+    const double ys[2] = {y0, y1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        cplx oi, oz, ox, oy;
+        oi.re = c[k][0].re + c[k][1].re; oi.im = c[k][0].im + c[k][1].im;
+        oz.re = c[k][0].re - c[k][1].re; oz.im = c[k][0].im - c[k][1].im;
+        ox.re = c[k][2].re + c[k][3].re; ox.im = c[k][2].im + c[k][3].im;
+        const double dr = c[k][2].re - c[k][3].re, di = c[k][2].im - c[k][3].im;
+        oy.re = -ys[k] * di; oy.im = ys[k] * dr;
+        cplx* M = k == 0 ? M0 : M1;
+        M[ix[k][0]] = oi; M[ix[k][1]] = oz; M[ix[k][2]] = ox; M[ix[k][3]] = oy;
+    }
+}
+
 __global__ void __launch_bounds__(64)
 sweep2q_kernel(long long B, int K, const double* __restrict__ kraus, const double* __restrict__ ptm_ref,
                double* __restrict__ choi_out, double* __restrict__ ptm_out, double* __restrict__ chi_out,
@@ -420,17 +459,41 @@ sweep2q_kernel(long long B, int K, const double* __restrict__ kraus, const doubl
         ref[r].re = ref[r].im = 0.0;
         if (ptm_ref) { ref[r].re = ptm_ref[2 * (lane + 64 * r)]; ref[r].im = ptm_ref[2 * (lane + 64 * r) + 1]; }
     }
+    // One wavefront per workgroup: its LDS instructions execute in program order, so the stages
+    // below need no barrier and no wait -- only a compiler fence that keeps LDS values out of
+    // registers across a stage boundary.  The next item's Kraus operators are fetched from HBM
+    // while the current item is transformed.
+#define FBX_WAVE_FENCE() asm volatile("" ::: "memory")
+    const int n_ld = (K * D + 63) / 64;              // 16-byte loads per lane and item (K <= 16: at most 4)
+    double2 nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        nxt[u].x = nxt[u].y = 0.0;
+        const int idx = lane + 64 * u;
+        if (u < n_ld && idx < K * D && (long long)blockIdx.x < B)
+            nxt[u] = *reinterpret_cast<const double2*>(kraus + (blockIdx.x * (long long)K * D + idx) * 2);
+    }
     for (long long item = blockIdx.x; item < B; item += gridDim.x) {
-        // ---- Kraus operators: coalesced 16-byte loads, stored as vec(K_t)[c*4 + r] = K_t[r][c]
-        const double* kp = kraus + item * (long long)K * D * 2;
-        __syncthreads();
-        for (int idx = lane; idx < K * D; idx += 64) {
-            const double2 v = *reinterpret_cast<const double2*>(kp + 2 * idx);
-            const int t = idx >> 4, rr = (idx >> 2) & 3, cc = idx & 3;
-            cplx c; c.re = v.x; c.im = v.y;
-            kb[t * D + cc * 4 + rr] = c;
+        // ---- Kraus operators, stored as vec(K_t)[c*4 + r] = K_t[r][c]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = lane + 64 * u;
+            if (u < n_ld && idx < K * D) {
+                const int t = idx >> 4, rr = (idx >> 2) & 3, cc = idx & 3;
+                cplx c; c.re = nxt[u].x; c.im = nxt[u].y;
+                kb[t * D + cc * 4 + rr] = c;
+            }
         }
-        __syncthreads();
+        {
+            const long long nitem = item + gridDim.x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = lane + 64 * u;
+                if (u < n_ld && idx < K * D && nitem < B)
+                    nxt[u] = *reinterpret_cast<const double2*>(kraus + (nitem * (long long)K * D + idx) * 2);
+            }
+        }
+        FBX_WAVE_FENCE();
         // ---- kraus2choi: C[row][col] = sum_t vK_t[row] conj(vK_t[col]); lane owns rows q + 4 r
         cplx acc[4];
 #pragma unroll
@@ -450,21 +513,18 @@ sweep2q_kernel(long long B, int K, const double* __restrict__ kraus, const doubl
             W[(q + 4 * r) * LD + col] = acc[r];
             if (choi_out) {
                 double2 v; v.x = acc[r].re; v.y = acc[r].im;
-                *reinterpret_cast<double2*>(choi_out + (item * D * D + lane + 64 * r) * 2) = v;
+                FBX_STREAM_STORE(reinterpret_cast<double2*>(choi_out + (item * D * D + lane + 64 * r) * 2), v);
             }
         }
-        __syncthreads();
-        // ---- Pauli-Liouville: sites pair (row bit, col bit); element index = row * 16 + col, so the
-        // row bits are index bits 7..4 (a1 a0 b1 b0) and the col bits 3..0
-        pauli_stage(A, lane, 7, 3, -1.0); __syncthreads();     // input qubit 0:  P_j^T  -> -i
-        pauli_stage(A, lane, 6, 2, -1.0); __syncthreads();     // input qubit 1
-        pauli_stage(A, lane, 5, 1, +1.0); __syncthreads();     // output qubit 0: P_i    -> +i
-        pauli_stage(A, lane, 4, 0, +1.0); __syncthreads();     // output qubit 1
-        // ---- chi: sites pair (a bit, b bit) of the same index; rows carry vec(P_k)^H, columns vec(P_l)
-        pauli_stage(W, lane, 7, 5, -1.0); __syncthreads();
-        pauli_stage(W, lane, 6, 4, -1.0); __syncthreads();
-        pauli_stage(W, lane, 3, 1, +1.0); __syncthreads();
-        pauli_stage(W, lane, 2, 0, +1.0); __syncthreads();
+        FBX_WAVE_FENCE();
+        // ---- Pauli-Liouville (A): sites pair (row bit, col bit); element index = row * 16 + col, so
+        // the row bits are index bits 7..4 (a1 a0 b1 b0) and the col bits 3..0; -i for the input
+        // qubits (P_j^T), +i for the output qubits (P_i).
+        // ---- chi (W): sites pair (a bit, b bit) of the same index; rows carry vec(P_k)^H, columns vec(P_l)
+        pauli_stage_pair(A, 7, 3, -1.0, W, 7, 5, -1.0, lane); FBX_WAVE_FENCE();
+        pauli_stage_pair(A, 6, 2, -1.0, W, 6, 4, -1.0, lane); FBX_WAVE_FENCE();
+        pauli_stage_pair(A, 5, 1, +1.0, W, 3, 1, +1.0, lane); FBX_WAVE_FENCE();
+        pauli_stage_pair(A, 4, 0, +1.0, W, 2, 0, +1.0, lane); FBX_WAVE_FENCE();
         // ---- gather to matrix order, scale, store; process fidelity on the fly
         double fr = 0.0;
 #pragma unroll
@@ -475,21 +535,23 @@ sweep2q_kernel(long long B, int K, const double* __restrict__ kraus, const doubl
                 const int cl = ((j >> 2) & 1) << 3 | (j & 1) << 2 | ((i >> 2) & 1) << 1 | (i & 1);
                 cplx v = A[row * LD + cl]; v.re *= 0.25; v.im *= 0.25;
                 fr += ref[r].re * v.re + ref[r].im * v.im;
-                if (ptm_out) { double2 o; o.x = v.re; o.y = v.im; *reinterpret_cast<double2*>(ptm_out + (item * D * D + idx) * 2) = o; }
+                if (ptm_out) { double2 o; o.x = v.re; o.y = v.im; FBX_STREAM_STORE(reinterpret_cast<double2*>(ptm_out + (item * D * D + idx) * 2), o); }
             }
             if (chi_out) {   // chi[k][l]: k = 8 a1 + 4 b1 + 2 a0 + b0 over the row bits (a1 a0 b1 b0)
                 const int row = ((i >> 3) & 1) << 3 | ((i >> 1) & 1) << 2 | ((i >> 2) & 1) << 1 | (i & 1);
                 const int cl = ((j >> 3) & 1) << 3 | ((j >> 1) & 1) << 2 | ((j >> 2) & 1) << 1 | (j & 1);
                 cplx v = W[row * LD + cl]; v.re *= 0.0625; v.im *= 0.0625;
                 double2 o; o.x = v.re; o.y = v.im;
-                *reinterpret_cast<double2*>(chi_out + (item * D * D + idx) * 2) = o;
+                FBX_STREAM_STORE(reinterpret_cast<double2*>(chi_out + (item * D * D + idx) * 2), o);
             }
         }
         if (fid_out) {
             fr = wave_sum(fr);
             if (lane == 0) fid_out[item] = (4.0 * (fr / 16.0) + 1.0) / 5.0;
         }
+        FBX_WAVE_FENCE();
     }
+#undef FBX_WAVE_FENCE
 }
 
 template <int NQ>
