@@ -147,17 +147,32 @@ def linear_inv_process_estimate(design: Design, expectations) -> np.ndarray:
     return unvec(rho) + np.eye(dim ** 2) / dim
 
 
-def design_matrix_A(design: Design) -> np.ndarray:
-    """The data-independent half of tomography.py:494-539: A in C^{2m x D^2}."""
+def design_matrix_A(design: Design, sparse: bool = False):
+    """The data-independent half of tomography.py:494-539: A in C^{2m x D^2}.
+
+    ``sparse=True`` returns the same matrix as scipy CSR (built in row chunks) -- the dense form of
+    the 3-qubit Pauli design is 27 216 x 4096 complex (1.8 GB), 24 % of it non-zero."""
     dim = design.dim
     eye = np.eye(dim)
-    rows = []
-    for k in range(design.m):
+
+    def rows_of(k):
         rho_in = state_matrix(design.in_labels[k])
         op = pauli_matrix(design.paulis[k], design.coefs[k])
-        rows.append(vec(np.kron(rho_in, ((eye + op) / 2).T)).T[0])
-        rows.append(vec(np.kron(rho_in, ((eye - op) / 2).T)).T[0])
-    return np.asarray(rows) / dim ** 2
+        return (vec(np.kron(rho_in, ((eye + op) / 2).T)).T[0], vec(np.kron(rho_in, ((eye - op) / 2).T)).T[0])
+
+    if not sparse:
+        rows = []
+        for k in range(design.m):
+            rows.extend(rows_of(k))
+        return np.asarray(rows) / dim ** 2
+    import scipy.sparse as sp
+    chunks, chunk = [], []
+    for k in range(design.m):
+        chunk.extend(rows_of(k))
+        if len(chunk) >= 1024 or k == design.m - 1:
+            chunks.append(sp.csr_matrix(np.asarray(chunk) / dim ** 2))
+            chunk = []
+    return sp.vstack(chunks, format="csr")
 
 
 def counts_vector(expectations, total_counts) -> np.ndarray:

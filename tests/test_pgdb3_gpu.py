@@ -100,3 +100,22 @@ def test_linear_inversion_3q_matches_reference_golden_and_oracle(gpu):
     d = od.Design(3, "process", design.in_labels, design.paulis, design.coefs)
     want = oe.linear_inv_process_estimate(d, g["expectations"][0])
     assert np.abs(got[0] - want).max() < 1e-9
+
+
+def test_pauli_in_basis_3q_matches_oracle(gpu):
+    """Config 4 stretch: 3 qubits with the Pauli in-basis (13 608 settings, 216 input states, the
+    14-settings-per-thread instantiation) against the oracle with a sparse design matrix."""
+    from fbx import synthetic, tomography
+    from fbx_oracle import design as od, estimators as oe
+    design, us, e, c = synthetic.process_batch(3, "pauli", 1, first_item=2)
+    assert design.m == 13608
+    d = od.Design(3, "process", design.in_labels, design.paulis, design.coefs)
+    A = oe.design_matrix_A(d, sparse=True)
+    got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=2, return_stats=True)
+    want, ws = oe.pgdb_process_estimate(d, e[0], c[0], A=A, mode="fixed", max_iters=2, return_stats=True)
+    assert np.abs(got[0] - want).max() < 1e-11
+    assert st["dykstra"][0] == ws["dykstra"] and st["backtracks"][0] == ws["backtracks"]
+    assert abs(st["cost"][0] - ws["cost"]) < 1e-11
+    lin = tomography.linear_inv_process_estimate_batch(design, e)
+    pt = np.einsum("iojo->ij", lin[0].reshape(8, 8, 8, 8))
+    assert np.abs(lin[0] - lin[0].conj().T).max() < 1e-12 and np.abs(pt - np.eye(8)).max() < 1e-9
