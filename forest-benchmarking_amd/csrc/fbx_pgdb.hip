@@ -145,7 +145,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         }
     };
     // negative log-likelihood at est + alpha * update (tomography.py:597-614)
-    auto cost_at = [&](double alpha) -> double {
+    auto cost_at = [&](double alpha) __attribute__((always_inline)) -> double {
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
@@ -257,23 +257,24 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         // Once alpha |pu / pe| < 2^-9 for every outcome (and nothing sits at the clip), log1p is a
         // degree-6 polynomial to < 1e-17 relative -- 8 instructions per outcome instead of ~40.  The
         // long halving runs of stalled iterations live here.
-        double rp[MAXJ], rm[MAXJ];
+        // (the ratios are recomputed per evaluation -- three instructions -- rather than kept: the
+        // kernel sits at the 512-register limit and 2 MAXJ more doubles went to scratch)
+        auto ratio = [](double pu, double pe) __attribute__((always_inline)) -> double {
+            double ip = __builtin_amdgcn_rcp(pe);
+            ip = fma(fma(-pe, ip, 1.0), ip, ip);
+            return pe < 2.0 * PGDB_EPS ? 0.0 : pu * ip;
+        };
         double rmax = 0.0;
         uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const double ap = pep[j], am = pem[j];
-            const bool fp = ap < 2.0 * PGDB_EPS, fm = am < 2.0 * PGDB_EPS;
-            double ip = __builtin_amdgcn_rcp(ap), im = __builtin_amdgcn_rcp(am);
-            ip = fma(fma(-ap, ip, 1.0), ip, ip); im = fma(fma(-am, im, 1.0), im, im);
-            rp[j] = fp ? 0.0 : pup[j] * ip; rm[j] = fm ? 0.0 : pum[j] * im;
-            rmax = fmax(rmax, fmax(fabs(rp[j]), fabs(rm[j])));
-            if (__ballot(fp)) near_clip |= 1u << (2 * j);
-            if (__ballot(fm)) near_clip |= 2u << (2 * j);
+            rmax = fmax(rmax, fmax(fabs(ratio(pup[j], pep[j])), fabs(ratio(pum[j], pem[j]))));
+            if (__ballot(pep[j] < 2.0 * PGDB_EPS)) near_clip |= 1u << (2 * j);
+            if (__ballot(pem[j] < 2.0 * PGDB_EPS)) near_clip |= 2u << (2 * j);
         }
         rmax = uniform(wave_max(rmax));
         const bool small_ok = rmax == rmax;
-        auto log1p_small = [](double x) -> double {
+        auto log1p_small = [](double x) __attribute__((always_inline)) -> double {
             double q = fma(x, -1.0 / 6.0, 0.2);
             q = fma(x, q, -0.25);
             q = fma(x, q, 1.0 / 3.0);
@@ -281,13 +282,13 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             q = fma(x, q, 1.0);
             return x * q;
         };
-        auto clipped_log = [](double p) -> double { return fast_log_pos(p < PGDB_EPS ? PGDB_EPS : p); };
-        auto cost_step = [&](double alpha) -> double {
+        auto clipped_log = [](double p) __attribute__((always_inline)) -> double { return fast_log_pos(p < PGDB_EPS ? PGDB_EPS : p); };
+        auto cost_step = [&](double alpha) __attribute__((always_inline)) -> double {
             if (!(small_ok && alpha * rmax < 0x1p-9)) return cost_at(alpha);
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j)
-                acc += npl[j] * log1p_small(alpha * rp[j]) + nmi[j] * log1p_small(alpha * rm[j]);
+                acc += npl[j] * log1p_small(alpha * ratio(pup[j], pep[j])) + nmi[j] * log1p_small(alpha * ratio(pum[j], pem[j]));
             if (near_clip) {                 // the few outcomes at the clip: exact difference of clipped logs
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) {
