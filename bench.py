@@ -71,6 +71,45 @@ def cpu_baseline(design, e, c, n_items, iters):
                       f"numpy oracle with the design matrix hoisted, {dt:.1f} s"}
 
 
+_POOL_WORKER = r"""
+import os, sys, time
+os.environ["OMP_NUM_THREADS"] = "1"; os.environ["OPENBLAS_NUM_THREADS"] = "1"; os.environ["MKL_NUM_THREADS"] = "1"
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from fbx_oracle import design as od, estimators as oe
+z = np.load(sys.argv[2]); lo, hi, iters = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+d = od.Design(int(z["n"]), "process", z["in_labels"], z["paulis"], z["coefs"])
+A = oe.design_matrix_A(d)
+t0 = time.perf_counter()
+for b in range(lo, hi):
+    oe.pgdb_process_estimate(d, z["e"][b], z["c"][b], mode="fixed", max_iters=iters, A=A)
+print(time.perf_counter() - t0)
+"""
+
+
+def cpu_baseline_pool(design, e, c, iters, per_core=1, max_cores=64):
+    """The fair multi-core variant of SURVEY.md 8d: one single-threaded oracle process per host core
+    (separate interpreters -- nothing is forked from the process that owns the GPU), `per_core`
+    items each, design matrix hoisted once per process and left out of the timed region."""
+    import subprocess, tempfile
+    cores = max(1, min(os.cpu_count() or 1, max_cores, e.shape[0] // per_core))
+    n_items = cores * per_core
+    with tempfile.TemporaryDirectory() as tmp:
+        fn = os.path.join(tmp, "sample.npz")
+        np.savez(fn, n=design.n_qubits, in_labels=design.in_labels, paulis=design.paulis, coefs=design.coefs,
+                 e=e[:n_items], c=c[:n_items])
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-c", _POOL_WORKER, os.path.join(ROOT, "oracle"), fn,
+                                   str(k * per_core), str((k + 1) * per_core), str(iters)],
+                                  stdout=subprocess.PIPE, text=True) for k in range(cores)]
+        inner = [float(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+        wall = time.perf_counter() - t0
+    busy = max(inner)                      # slowest worker's reconstruction time, start-up excluded
+    return {"value": n_items / busy, "unit": "reconstructions/s", "cores": cores, "kind": "port",
+            "sample": f"{n_items} items of the bench batch, {per_core} per single-threaded oracle process, "
+                      f"fixed {iters} iterations, slowest worker {busy:.1f} s (wall incl. start-up {wall:.1f} s)"}
+
+
 def _profiled(key):
     """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -270,19 +309,22 @@ def main():
                        "mean_dykstra_iters": float(dyk.mean()),
                        "mean_backtracks": float(bt.mean()),
                        "mean_outer_iters": float(iters.mean())},
-            "roofline": {"bound": "fp64", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS,
                          "traffic": traffic,
                          "kernel": "pgdb_kernel<2,9>", "kernel_ms": 1e3 * kernel_s,
                          "note": "PGDB is fp64-compute bound (SURVEY.md 8d): achieved = "
                                  "0.77 GFLOP algorithmic (dense-A formulation) x batch / HIP-event "
-                                 "kernel time; peak = MI355X fp64 vector = fp64 MFMA dense peak",
+                                 "kernel time; peak = dense fp64 MFMA peak of MI355X, which equals its fp64 "
+                                 "vector peak -- the kernel's flops are VALU FMAs (no GEMM with K >= 16 "
+                                 "on the 2-qubit path)",
                          "hbm": {"achieved": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9 / HBM_PEAK_GBS}},
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(design, e, c, min(args.cpu_sample, B), args.iters)
+            line["cpu_baseline_multicore"] = cpu_baseline_pool(design, e, c, args.iters)
         print(json.dumps(line), flush=True)
 
     if dist is not None:
