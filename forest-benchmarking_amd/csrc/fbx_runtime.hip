@@ -167,39 +167,40 @@ static void bloch_of_state(int code, double r[4]) {
     r[3] = (r00 - r11).real();
 }
 
-// Cyclic Jacobi eigensolver for a small real symmetric matrix (host side, design constants only).
-static void host_sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::vector<double>& v) {
+// One-sided (Hestenes) Jacobi SVD of a real rows x n matrix `a` (row-major; destroyed): on return
+// the columns of a V are mutually orthogonal, w[e] = squared norm of column e (= sigma_e^2) and v
+// holds V (n x n, row-major).  Unlike an eigendecomposition of the Gram matrix this keeps zero
+// singular values at (eps sigma_max)^2, so rank-deficient blocks are cut off like scipy's pinv does.
+static void host_onesided_svd(std::vector<double>& a, int rows, int n, std::vector<double>& w, std::vector<double>& v) {
     v.assign((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, nrm = 0.0;
-        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
-            nrm += a[(size_t)i * n + j] * a[(size_t)i * n + j];
-            if (i != j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
-        }
-        if (off <= 1e-30 * nrm) break;
+        bool rotated = false;
         for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
-            const double apq = a[(size_t)p * n + q];
-            if (std::fabs(apq) < 1e-300) continue;
-            const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            double al = 0.0, be = 0.0, ga = 0.0;
+            for (int k = 0; k < rows; ++k) {
+                const double x = a[(size_t)k * n + p], y = a[(size_t)k * n + q];
+                al += x * x; be += y * y; ga += x * y;
+            }
+            if (ga == 0.0 || ga * ga <= 1e-30 * al * be) continue;
+            rotated = true;
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(zeta * zeta + 1.0));
             const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-            for (int k = 0; k < n; ++k) {
-                const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
-                a[(size_t)k * n + p] = c * akp - sn * akq; a[(size_t)k * n + q] = sn * akp + c * akq;
+            for (int k = 0; k < rows; ++k) {
+                const double x = a[(size_t)k * n + p], y = a[(size_t)k * n + q];
+                a[(size_t)k * n + p] = c * x - sn * y; a[(size_t)k * n + q] = sn * x + c * y;
             }
             for (int k = 0; k < n; ++k) {
-                const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
-                a[(size_t)p * n + k] = c * apk - sn * aqk; a[(size_t)q * n + k] = sn * apk + c * aqk;
-            }
-            for (int k = 0; k < n; ++k) {
-                const double vkp = v[(size_t)k * n + p], vkq = v[(size_t)k * n + q];
-                v[(size_t)k * n + p] = c * vkp - sn * vkq; v[(size_t)k * n + q] = sn * vkp + c * vkq;
+                const double x = v[(size_t)k * n + p], y = v[(size_t)k * n + q];
+                v[(size_t)k * n + p] = c * x - sn * y; v[(size_t)k * n + q] = sn * x + c * y;
             }
         }
+        if (!rotated) break;
     }
-    w.resize(n);
-    for (int i = 0; i < n; ++i) w[i] = a[(size_t)i * n + i];
+    w.assign(n, 0.0);
+    for (int e = 0; e < n; ++e)
+        for (int k = 0; k < rows; ++k) w[e] += a[(size_t)k * n + e] * a[(size_t)k * n + e];
 }
 
 int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
@@ -330,16 +331,12 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
             auto it = cache.find(sig);
             if (it != cache.end()) { alias[i] = it->second; continue; }
             cache[sig] = i; alias[i] = i;
-            std::vector<double> gram((size_t)D * D, 0.0);
+            std::vector<double> abar((size_t)(g1 - g0) * D, 0.0);
             for (int g = g0; g < g1; ++g) {
                 const int k = porder[g]; const double ck = coefs ? coefs[k] : 1.0;
-                for (int a = 0; a < D; ++a) {
-                    const double ra = ck * des->C_host[(size_t)a * S + sidx[k]];
-                    if (ra == 0.0) continue;
-                    for (int b = 0; b < D; ++b) gram[(size_t)a * D + b] += ra * ck * des->C_host[(size_t)b * S + sidx[k]];
-                }
+                for (int a = 0; a < D; ++a) abar[(size_t)(g - g0) * D + a] = ck * des->C_host[(size_t)a * S + sidx[k]];
             }
-            host_sym_eig(gram, D, blocks[i].w, blocks[i].v);
+            host_onesided_svd(abar, g1 - g0, D, blocks[i].w, blocks[i].v);
             for (double l : blocks[i].w) smax2 = std::max(smax2, l);
         }
         // scipy.linalg.pinv cut-off: singular values <= max(M, N) * eps * sigma_max are dropped
@@ -349,7 +346,7 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
             const int g0 = pptr[i], g1 = pptr[i + 1];
             if (g0 == g1) continue;
             const Block& bl = blocks[alias[i]];
-            // G^+ = V diag(1/lambda) V^T ; pinv(Abar) = G^+ Abar^T  ->  column of setting k
+            // w = sigma^2: (Abar^T Abar)^+ = V diag(1/sigma^2) V^T ; pinv(Abar) = that times Abar^T -> column of setting k
             std::vector<double> gp((size_t)D * D, 0.0);
             for (int e = 0; e < D; ++e) {
                 if (!(bl.w[e] > cut2)) continue;
