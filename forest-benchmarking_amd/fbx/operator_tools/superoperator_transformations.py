@@ -86,8 +86,21 @@ def kraus2chi(kraus_ops):
 
 
 def kraus2superop(kraus_ops):
-    """superoperator_transformations.py:100-145 (square Kraus operators)."""
-    return convert_batch("kraus", "superop", _kraus_stack(kraus_ops))[0]
+    """superoperator_transformations.py:100-145.  Non-square Kraus operators (M x N, measurement
+    theory / error correction; the reference returns an M^2 x N^2 matrix) are zero-padded to the
+    enclosing 2^n x 2^n square, converted on the device, and the rows / columns that belong to the
+    padding are dropped -- sum conj(K) (x) K has no contribution from zero entries."""
+    ks = _kraus_stack(kraus_ops)
+    rows, cols = ks.shape[-2:]
+    if rows == cols:
+        return convert_batch("kraus", "superop", ks)[0]
+    n = 2
+    while n < max(rows, cols):
+        n *= 2
+    padded = np.zeros(ks.shape[:-2] + (n, n), dtype=np.complex128)
+    padded[..., :rows, :cols] = ks
+    full = convert_batch("kraus", "superop", padded)[0].reshape(n, n, n, n)
+    return np.ascontiguousarray(full[:rows, :rows, :cols, :cols]).reshape(rows * rows, cols * cols)
 
 
 def kraus2pauli_liouville(kraus_ops):
