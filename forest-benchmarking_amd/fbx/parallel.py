@@ -46,3 +46,26 @@ def run_sharded(fn: Callable[..., np.ndarray], arrays: Sequence[np.ndarray], ran
     if is_complex:
         full = full.view(np.complex128)
     return full[:n], (lo, hi)
+
+
+def reduce_summary(sums: Sequence[float], maxima: Sequence[float] = (), dist=None):
+    """Whole-job summary scalars: element-wise SUM of ``sums`` (e.g. sum of
+    fidelities, of iteration counts, number of items that hit the cap) and MAX of ``maxima`` (e.g.
+    most halvings, slowest shard) over all ranks -- two all-reduces on vectors of a few doubles,
+    the only other collective next to the optional all-gather.  Returns two numpy arrays; without an
+    initialised ``dist`` the inputs are returned unchanged."""
+    s = np.asarray(list(sums), dtype=np.float64)
+    m = np.asarray(list(maxima), dtype=np.float64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return s, m
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    if s.size:
+        t = torch.from_numpy(s.copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        s = t.cpu().numpy()
+    if m.size:
+        t = torch.from_numpy(m.copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        m = t.cpu().numpy()
+    return s, m

@@ -25,7 +25,7 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fbx import synthetic
-    from fbx.parallel import run_sharded, shard_bounds
+    from fbx.parallel import reduce_summary, run_sharded, shard_bounds
     from fbx_oracle import design as od, estimators as oe
     design, _, e, c = synthetic.process_batch(1, "sic", 7)          # 7 items: ragged split 4 + 3
     o = od.process_design(1, "sic")
@@ -39,6 +39,10 @@ def _worker(rank, world, port, out_dir):
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == world
+    # whole-job summary: sum of the local item counts and traces, max of the local block length
+    local = full[lo:hi]
+    sums, maxima = reduce_summary([hi - lo, float(np.trace(local, axis1=1, axis2=2).real.sum())], [hi - lo], dist)
+    assert sums[0] == 7 and abs(sums[1] - np.trace(full, axis1=1, axis2=2).real.sum()) < 1e-12 and maxima[0] == 4
     np.save(os.path.join(out_dir, f"full_{rank}.npy"), full)
     dist.barrier()
     dist.destroy_process_group()
