@@ -158,28 +158,41 @@ __device__ Blk proj_tni_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps)
 // ---- Dykstra: project_superoperators.py:87-144.  Stops on the Birgin-Raydan functional
 // < 1e-4 (no iteration cap in the reference; `max_iter` is a safety net that is never the
 // binding constraint in practice).  Returns the last TP / TNI iterate.
-// `vfirst` (optional, D*D cplx in the Jacobi layout) carries the eigenvectors of the FIRST projection
-// of the previous call: successive PGDB iterations project nearby matrices, so they warm-start
-// that first eigendecomposition as well (`first_valid` says whether the buffer holds a basis).
+// `store` (optional) keeps, in HBM / L2, the eigenvector basis of EVERY Dykstra iteration of the
+// previous call for the same item: successive PGDB iterations project nearby matrices along nearly
+// the same Dykstra trajectory, so iteration j of this call starts its eigendecomposition from basis
+// j of the previous call when the caller says the outer step was small (`use_prev`; the first
+// projection, which has no basis of its own run to start from, always does).  A basis is only an
+// initial guess -- every decomposition still runs to the same off-norm tolerance.
+struct BasisStore {
+    cplx* g;          // [cap][D * D] in the Jacobi layout, private to the item
+    int cap;          // slots
+    int nprev;        // slots that hold a basis of the previous call
+    bool use_prev;    // outer step small: prefer the previous call's basis over the previous iteration's
+};
+
 template <int NQ>
 __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ>& L, int lane,
                                  int& iters, int& sweeps, int max_iter = 100000,
-                                 cplx* vfirst = nullptr, bool first_valid = false) {
+                                 BasisStore* store = nullptr) {
     constexpr int DD = ChoiLds<NQ>::D * ChoiLds<NQ>::D;
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
-    for (int it = 0; it < max_iter; ++it) {
+    int it = 0;
+    for (; it < max_iter; ++it) {
         ++iters;
         const Blk pre_cp = blk_sub(last_state, old_cp);
         bool warm = FBX_WARM_START && it > 0;
-        if (FBX_WARM_START && it == 0 && vfirst && first_valid) {
+        if (FBX_WARM_START && store && it < store->nprev && (it == 0 || store->use_prev)) {
             __syncthreads();
-            for (int idx = lane; idx < DD; idx += 64) L.Vs[idx] = vfirst[idx];
+            const cplx* src = store->g + (size_t)it * DD;
+            for (int idx = lane; idx < DD; idx += 64) L.Vs[idx] = src[idx];
             warm = true;
         }
         const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm);
-        if (FBX_WARM_START && it == 0 && vfirst) {
-            for (int idx = lane; idx < DD; idx += 64) vfirst[idx] = L.Vs[idx];
+        if (FBX_WARM_START && store && it < store->cap) {
+            cplx* dst = store->g + (size_t)it * DD;
+            for (int idx = lane; idx < DD; idx += 64) dst[idx] = L.Vs[idx];
         }
         const Blk new_cp = blk_sub(cp, pre_cp);
         const Blk pre_tp = blk_sub(cp, old_tp);
@@ -195,9 +208,10 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         i1r = wave_sum(i1r); i1i = wave_sum(i1i); i2r = wave_sum(i2r); i2i = wave_sum(i2i);
         const double crit = uniform(s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i)
                                     + 2.0 * sqrt(i2r * i2r + i2i * i2i));
-        if (crit < 1e-4) break;
+        if (crit < 1e-4) { ++it; break; }
         old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
     }
+    if (store) store->nprev = it < store->cap ? it : store->cap;
     return new_state;
 }
 

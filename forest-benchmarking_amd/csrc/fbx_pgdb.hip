@@ -32,7 +32,6 @@ struct PgdbLds {
     double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
     double* Tupd;   // [S*D]  same for the update direction; aliased as W[D][S] in the gradient
     double* Cl;     // [D*S]  Bloch coefficients of the input states
-    cplx* Vfirst;   // [D*D]  eigenvectors of the first projection of the previous outer iteration
     double* hs;     // [m] (eta+ + eta-)/2 ; aliases the Jacobi work matrices
     double* hd;     // [m] coef * (eta+ - eta-)/2
     static size_t bytes(int S, int m) {
@@ -41,7 +40,7 @@ struct PgdbLds {
         size_t h = sizeof(double) * 2 * (size_t)m;
         size_t jac = sizeof(cplx) * (D * ChoiLds<NQ>::LD + 2 * D * D);
         size_t extra = h > jac ? h - jac : 0;     // h aliases Mw..Vw, spill past them if longer
-        return choi + extra + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + sizeof(cplx) * D * D + 64;
+        return choi + extra + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + 64;
     }
     __device__ void carve(char* p, int S, int m) {
         constexpr int D = ChoiLds<NQ>::D;
@@ -61,8 +60,6 @@ struct PgdbLds {
         Test = (double*)p; p += sizeof(double) * S * D;
         Tupd = (double*)p; p += sizeof(double) * S * D;
         Cl = (double*)p; p += sizeof(double) * D * S;
-        p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-        Vfirst = (cplx*)p;
     }
 };
 
@@ -86,7 +83,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             double* __restrict__ choi_out, int* __restrict__ iters_out,
             int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
             double* __restrict__ cost_out, int* __restrict__ sweeps_out,
-            long long* __restrict__ phase_out) {
+            long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
@@ -169,6 +166,11 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     __syncthreads();
 
     int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
+    // eigenvector bases of the previous outer iteration's Dykstra run (fbx_choi.hpp BasisStore)
+    BasisStore basis;
+    basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
+    basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false;
+    double outer_step = 1.0;                       // alpha * ||update||_F of the previous outer iteration
     PhaseClock pc; pc.reset(); L.choi.pc = &pc;
     PH_START(pc);
     double old_cost = 0.0, new_cost = 0.0;
@@ -227,13 +229,16 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 
         // ---- projected step (tomography.py:572)
         const Blk x = blk_axpy(est, -inv_mu, grad);
-        // the cross-iteration basis is restarted every 16 iterations to bound the accumulated
-        // loss of unitarity (~1e-16 per rotation)
+        // the cross-iteration bases are dropped every 16 iterations to bound the accumulated loss of
+        // unitarity (~1e-16 per rotation); below a step of 1e-3 the previous run's trajectory is closer
+        // to this one than consecutive Dykstra iterates are to each other (those stop at ~1e-2)
+        if ((iters & 15) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
+        basis.use_prev = outer_step < 1e-3;
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
 #ifdef FBX_NO_VFIRST
-                                               nullptr, false);
+                                               nullptr);
 #else
-                                               L.Vfirst, (iters & 15) != 0 && !FBX_DBG_NOVALID);
+                                               basis.g ? &basis : nullptr);
 #endif
         const Blk upd = blk_sub(proj, est);
         PH_STOP(pc, 2);
@@ -319,6 +324,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         }
         PH_STOP(pc, 5);
         est = blk_axpy(est, alpha, upd);            // tomography.py:588
+        outer_step = alpha * sqrt(uniform(wave_sum(blk_norm2(upd))));
         ++iters;
         if (mode == FBX_MODE_CONVERGE) {
             if (old_cost - new_cost < PGDB_STOP) break;          // tomography.py:589
@@ -354,6 +360,10 @@ __global__ void debug_log_kernel(const double* x, double* out, long long n) {
     if (i < n) out[i] = fast_log_pos(x[i]);
 }
 
+static cplx* g_basis = nullptr;            // Dykstra eigenvector bases of the items in flight (see launch_pgdb)
+static size_t g_basis_bytes = 0;
+constexpr int BASIS_CAP = 32;              // Dykstra iterations per projection that get a stored basis
+
 long long* g_phase_out = nullptr;          // diagnostics: set by fbx_debug_set_phase_buffer (also read by fbx_pgdb3.hip)
 
 template <int NQ, int MAXJ>
@@ -367,9 +377,28 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     }
     auto kern = pgdb_kernel<NQ, MAXJ>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream(), des->dev, (long long)B, e, c, tp,
-                       mode, max_iters, choi, it, dy, getenv("FBX_DEBUG_SWEEPS") ? nullptr : bt, cost,
-                       getenv("FBX_DEBUG_SWEEPS") ? bt : (int*)nullptr, g_phase_out);
+    // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each), kept by the
+    // library between calls (grow-only); larger batches go in chunks that reuse it
+    constexpr int D = 1 << (2 * NQ);
+    constexpr int64_t CHUNK = 8192;
+    const int64_t in_flight = B < CHUNK ? B : CHUNK;
+    const size_t need = sizeof(cplx) * D * D * BASIS_CAP * (size_t)in_flight;
+    if (need > g_basis_bytes) {
+        if (g_basis) (void)hipFree(g_basis);
+        g_basis = nullptr; g_basis_bytes = 0;
+        FBX_HIP(hipMalloc((void**)&g_basis, need));
+        g_basis_bytes = need;
+    }
+    const bool dbg = getenv("FBX_DEBUG_SWEEPS") != nullptr;
+    const size_t m = des->dev.m;
+    for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
+        const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, stream(), des->dev, (long long)nb,
+                           e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2,
+                           it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, (!dbg && bt) ? bt + b0 : nullptr,
+                           cost ? cost + b0 : nullptr, (dbg && bt) ? bt + b0 : (int*)nullptr,
+                           g_phase_out ? g_phase_out + b0 * 8 : nullptr, g_basis, BASIS_CAP);
+    }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
 }
