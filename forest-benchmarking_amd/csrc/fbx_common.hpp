@@ -92,6 +92,22 @@ struct PhaseClock { __device__ void reset() {} };
 
 struct __attribute__((aligned(16))) cplx { double re, im; };
 
+// Wavefront reductions on the VALU: four DPP butterfly steps inside each row of 16 lanes (quad
+// swaps, half-row and row mirrors -- no LDS crossbar round trips as with ds_bpermute), then the four
+// row results through v_readlane.  Every lane gets the same value (already wave-uniform); the
+// summation order is fixed.
+template <int CTRL>
+__device__ __forceinline__ double dpp_permute(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+#ifdef FBX_SHUFFLE_REDUCTIONS
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -102,6 +118,22 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
+#else
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_permute<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_permute<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_permute<0x141>(v);         // row_half_mirror
+    v += dpp_permute<0x140>(v);         // row_mirror: every lane holds the sum of its row of 16
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_permute<0xB1>(v));
+    v = fmax(v, dpp_permute<0x4E>(v));
+    v = fmax(v, dpp_permute<0x141>(v));
+    v = fmax(v, dpp_permute<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+#endif
 // sum over all NT threads of the workgroup (every thread receives the same total, summed in one
 // fixed order); `red` is NT/64 doubles of LDS scratch, unused for single-wave workgroups
 template <int NT>

@@ -14,6 +14,12 @@
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
 #include "fbx_choi.hpp"
 #include <cstdlib>
+#ifndef FBX_BASIS_RESET_MASK
+#define FBX_BASIS_RESET_MASK 15
+#endif
+#ifndef FBX_BASIS_STEP
+#define FBX_BASIS_STEP 1e-3
+#endif
 #ifndef FBX_DBG_NOVALID
 #define FBX_DBG_NOVALID 0
 #endif
@@ -232,8 +238,8 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         // the cross-iteration bases are dropped every 16 iterations to bound the accumulated loss of
         // unitarity (~1e-16 per rotation); below a step of 1e-3 the previous run's trajectory is closer
         // to this one than consecutive Dykstra iterates are to each other (those stop at ~1e-2)
-        if ((iters & 15) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
-        basis.use_prev = outer_step < 1e-3;
+        if ((iters & FBX_BASIS_RESET_MASK) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
+        basis.use_prev = outer_step < FBX_BASIS_STEP;
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
 #ifdef FBX_NO_VFIRST
                                                nullptr);
