@@ -178,6 +178,9 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
     constexpr int DD = ChoiLds<NQ>::D * ChoiLds<NQ>::D;
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
+    constexpr int PF = (DD + 63) / 64;         // 16-byte loads per lane for one basis
+    cplx pf[PF];                               // basis of the NEXT iteration, fetched while this one finishes
+    bool have_pf = false;
     int it = 0;
     for (; it < max_iter; ++it) {
         ++iters;
@@ -186,19 +189,40 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         if (FBX_WARM_START && store && it < store->nprev && (it == 0 || store->use_prev)) {
             __syncthreads();
             const cplx* src = store->g + (size_t)it * DD;
-            for (int idx = lane; idx < DD; idx += 64) L.Vs[idx] = src[idx];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < DD) L.Vs[idx] = have_pf ? pf[u] : src[idx];
+            }
             warm = true;
         }
         const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm);
+        have_pf = false;
         if (FBX_WARM_START && store && it < store->cap) {
+            // loads of the next basis first, stores of this one behind them: vector memory returns in
+            // issue order, so consuming the loads next iteration never waits for the stores
+            if (store->use_prev && it + 1 < store->nprev) {      // overlaps the TP projection and the stop test
+                const cplx* nxt = store->g + (size_t)(it + 1) * DD;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int idx = lane + 64 * u;
+                    if (idx < DD) pf[u] = nxt[idx];
+                }
+                have_pf = true;
+            }
             cplx* dst = store->g + (size_t)it * DD;
-            for (int idx = lane; idx < DD; idx += 64) dst[idx] = L.Vs[idx];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < DD) dst[idx] = L.Vs[idx];
+            }
         }
         const Blk new_cp = blk_sub(cp, pre_cp);
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = trace_preserving ? proj_tp_blk<NQ>(pre_tp, L, lane)
                                      : proj_tni_blk<NQ>(pre_tp, L, lane, sweeps);
         const Blk new_tp = blk_sub(new_state, pre_tp);
+        PH_STOP(*L.pc, 6);
         double s1 = blk_norm2(blk_sub(new_cp, old_cp));
         double s2 = blk_norm2(blk_sub(new_tp, old_tp));
         double i1r, i1i, i2r, i2i;
@@ -206,8 +230,11 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         blk_dotc(old_cp, blk_sub(cp, last_cp), i2r, i2i);
         s1 = wave_sum(s1); s2 = wave_sum(s2);
         i1r = wave_sum(i1r); i1i = wave_sum(i1i); i2r = wave_sum(i2r); i2i = wave_sum(i2i);
-        const double crit = uniform(s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i)
-                                    + 2.0 * sqrt(i2r * i2r + i2i * i2i));
+        // |z| = |z|^2 rsqrt(|z|^2): the IEEE sqrt expansion is ~40 instructions, twice per iteration
+        const double a1 = i1r * i1r + i1i * i1i, a2 = i2r * i2r + i2i * i2i;
+        const double m1 = a1 > 1e-300 ? a1 * fast_rsqrt(a1) : 0.0, m2 = a2 > 1e-300 ? a2 * fast_rsqrt(a2) : 0.0;
+        const double crit = uniform(s1 + s2 + 2.0 * m1 + 2.0 * m2);
+        PH_STOP(*L.pc, 7);
         if (crit < 1e-4) { ++it; break; }
         old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
     }

@@ -285,6 +285,16 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         }
         rmax = uniform(wave_max(rmax));
         const bool small_ok = rmax == rmax;
+        double clip_base = 0.0;
+        if (near_clip) {
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                if (near_clip & (1u << (2 * j)))
+                    clip_base += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * fast_log_pos(pep[j] < PGDB_EPS ? PGDB_EPS : pep[j]) : 0.0;
+                if (near_clip & (2u << (2 * j)))
+                    clip_base += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * fast_log_pos(pem[j] < PGDB_EPS ? PGDB_EPS : pem[j]) : 0.0;
+            }
+        }
         auto log1p_small = [](double x) __attribute__((always_inline)) -> double {
             double q = fma(x, -1.0 / 6.0, 0.2);
             q = fma(x, q, -0.25);
@@ -303,15 +313,12 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             if (near_clip) {                 // the few outcomes at the clip: exact difference of clipped logs
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) {
-                    if (near_clip & (1u << (2 * j))) {
-                        const double dl = clipped_log(fma(alpha, pup[j], pep[j])) - clipped_log(pep[j]);
-                        acc += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * dl : 0.0;
-                    }
-                    if (near_clip & (2u << (2 * j))) {
-                        const double dl = clipped_log(fma(alpha, pum[j], pem[j])) - clipped_log(pem[j]);
-                        acc += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * dl : 0.0;
-                    }
+                    if (near_clip & (1u << (2 * j)))
+                        acc += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * clipped_log(fma(alpha, pup[j], pep[j])) : 0.0;
+                    if (near_clip & (2u << (2 * j)))
+                        acc += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * clipped_log(fma(alpha, pum[j], pem[j])) : 0.0;
                 }
+                acc -= clip_base;            // this lane's sum of n log(clip(pe)) over those outcomes
             }
             return old_cost - uniform(wave_sum(acc));
         };

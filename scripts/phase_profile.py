@@ -19,11 +19,11 @@ for rep in range(2):
     choi, st = tomography.pgdb_process_estimate_batch(design, e, c, mode=mode, max_iters=100 if mode == 'fixed' else 0, return_stats=True)
     dt = time.time() - t
 ph = buf.to_array(np.int64, (B, 8))
-names = ['jacobi', 'reconstruct', 'dykstra-other', 'transforms', 'gradient', 'linesearch', '-', '-']
+names = ['jacobi', 'reconstruct', 'hermitize+wait', 'transforms', 'gradient', 'linesearch', 'store+TP-proj', 'stop-test']
 tot = ph.sum(1)
 print('B', B, mode, 'time %.1f ms' % (1e3 * dt), 'recon/s %.0f' % (B / dt))
 print('cycles/item mean %.3e max %.3e' % (tot.mean(), tot.max()))
-for i, n in enumerate(names[:6]):
+for i, n in enumerate(names):
     print('  %-14s mean %.3e (%.1f%%)  max-item share %.3e' % (n, ph[:, i].mean(), 100 * ph[:, i].sum() / tot.sum(), ph[tot.argmax(), i]))
 print('per eigh jacobi cycles %.0f ; dykstra iters mean %.1f max %d; backtracks mean %.1f max %d' % (
     ph[:, 0].sum() / st['dykstra'].sum(), st['dykstra'].mean(), st['dykstra'].max(), st['backtracks'].mean(), st['backtracks'].max()))
