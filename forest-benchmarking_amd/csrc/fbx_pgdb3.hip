@@ -171,15 +171,32 @@ __device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project
 }
 
 // ---- Dykstra (project_superoperators.py:87-144)
-__device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, int& sweeps, cplx* Tg) {
+__device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, int& sweeps, cplx* Tg,
+                             BasisStore* store = nullptr) {
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
-    for (int it = 0; it < 100000; ++it) {
+    int it = 0;
+    for (; it < 100000; ++it) {
         ++iters;
         const Blk pre_cp = blk_sub(last_state, old_cp);
-        // consecutive Dykstra iterates are close: start from the previous eigenvectors (cold again
-        // at the first projection of every call, which also bounds the loss of unitarity)
-        const Blk cp = proj_cp(pre_cp, L, t, sweeps, it > 0 && Tg != nullptr, Tg);
+        // consecutive Dykstra iterates are close: start from the previous eigenvectors; when the
+        // outer step was small, from the basis the previous call found at the same Dykstra
+        // iteration (BasisStore, fbx_choi.hpp) -- the first projection always, it has no other
+        bool warm = it > 0 && Tg != nullptr;
+        if (store && Tg && it < store->nprev && (it == 0 || store->use_prev)) {
+            __syncthreads();
+            const cplx* src = store->g + (size_t)it * D * D;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) L.Vs[e * NT + t] = src[e * NT + t];
+            __syncthreads();
+            warm = true;
+        }
+        const Blk cp = proj_cp(pre_cp, L, t, sweeps, warm, Tg);
+        if (store && it < store->cap) {
+            cplx* dst = store->g + (size_t)it * D * D;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e * NT + t] = L.Vs[e * NT + t];
+        }
         const Blk new_cp = blk_sub(cp, pre_cp);
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = tp ? proj_tp(pre_tp, L, t) : proj_tni(pre_tp, L, t, sweeps);
@@ -191,9 +208,10 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         s1 = bsum(s1, L); s2 = bsum(s2, L);
         i1r = bsum(i1r, L); i1i = bsum(i1i, L); i2r = bsum(i2r, L); i2i = bsum(i2i, L);
         const double crit = s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
-        if (crit < 1e-4) break;
+        if (crit < 1e-4) { ++it; break; }
         old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
     }
+    if (store) store->nprev = it < store->cap ? it : store->cap;
     return new_state;
 }
 
@@ -291,7 +309,8 @@ __global__ void __launch_bounds__(1024)
 pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
              int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out,
              int* __restrict__ iters_out, int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-             double* __restrict__ cost_out, cplx* __restrict__ scratch, long long* __restrict__ phase_out, int* __restrict__ sweeps_out) {
+             double* __restrict__ cost_out, cplx* __restrict__ scratch, long long* __restrict__ phase_out, int* __restrict__ sweeps_out,
+             cplx* __restrict__ basis_scratch, int basis_cap) {
     using namespace p3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds L; L.carve(smem);
@@ -356,6 +375,10 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
     int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
     double old_cost = 0.0, new_cost = 0.0;
     bool have_cost = false;
+    BasisStore basis;
+    basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
+    basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false;
+    double outer_step = 1.0;
 
     PH_START(pc);
     while (true) {
@@ -429,8 +452,11 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         PH_STOP(pc, 3);
 
         const Blk x = blk_axpy(est, -inv_mu, grad);
+        if ((iters & 15) == 0) basis.nprev = 0;       // bounds the accumulated loss of unitarity
+        basis.use_prev = outer_step < 1e-3;
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
-                                       scratch ? scratch + (size_t)blockIdx.x * D * D : nullptr);
+                                       scratch ? scratch + (size_t)blockIdx.x * D * D : nullptr,
+                                       basis.g ? &basis : nullptr);
         const Blk upd = blk_sub(proj, est);
         PH_STOP(pc, 2);
 
@@ -453,6 +479,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
             if (alpha < ALPHA_MIN) break;
         }
         est = blk_axpy(est, alpha, upd);
+        outer_step = alpha * sqrt(bsum(blk_norm2(upd), L));
         ++iters;
         PH_STOP(pc, 5);
         if (mode == FBX_MODE_CONVERGE) {
@@ -495,8 +522,10 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     // 64 KiB of L2-resident scratch per workgroup for the warm-start product; batches are processed
     // in chunks so the scratch stays bounded (512 workgroups = 32 MiB)
     constexpr int64_t CHUNK = 512;
+    constexpr int BASIS_CAP = 24;            // Dykstra iterations per projection with a stored basis (64 KiB each)
     cplx* scratch = nullptr;
-    FBX_HIP(hipMalloc((void**)&scratch, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK)));
+    FBX_HIP(hipMalloc((void**)&scratch, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK) * (1 + BASIS_CAP)));
+    cplx* basis = scratch + (size_t)p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK);
     const size_t m = des->dev.m, DD = (size_t)p3::D * p3::D;
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
@@ -504,7 +533,7 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
                            dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch,
                            g_phase_out ? g_phase_out + b0 * 8 : nullptr,
-                           (getenv("FBX_DEBUG_SWEEPS") && bt) ? bt + b0 : nullptr);
+                           (getenv("FBX_DEBUG_SWEEPS") && bt) ? bt + b0 : nullptr, basis, BASIS_CAP);
     }
     hipError_t le = hipGetLastError();
     hipError_t se = hipStreamSynchronize(stream());
