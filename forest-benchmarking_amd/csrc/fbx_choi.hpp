@@ -318,7 +318,7 @@ __device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
     for (int idx = lane; idx < D * D; idx += 64) {
         int row, col;
         pauli_coeff_position<NQ>(idx / D, idx % D, row, col);
-        Rb[idx] = Mw[row * LD + col].re / d;
+        Rb[(idx % D) * D + idx / D] = Mw[row * LD + col].re / d;     // transposed: Rb[j * D + i] = R[i][j]
     }
 }
 
@@ -330,7 +330,7 @@ __device__ Blk pauli_real_to_choi_blk(const double* Rb, cplx* Mw, int lane) {
     for (int idx = lane; idx < D * D; idx += 64) {
         int row, col;
         pauli_coeff_position<NQ>(idx / D, idx % D, row, col);
-        cplx v; v.re = Rb[idx] * d; v.im = 0.0;     // E = d * F^{-1}(R)
+        cplx v; v.re = Rb[(idx % D) * D + idx / D] * d; v.im = 0.0;     // E = d * F^{-1}(R); Rb[j * D + i] = R[i][j]
         Mw[row * LD + col] = v;
     }
     __syncthreads();

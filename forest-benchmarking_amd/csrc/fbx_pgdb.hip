@@ -34,10 +34,10 @@ constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
 template <int NQ>
 struct PgdbLds {
     ChoiLds<NQ> choi;
-    double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time)
+    double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time), TRANSPOSED: Rb[j * D + i] = R[i][j]
     double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
     double* Tupd;   // [S*D]  same for the update direction; aliased as W[D][S] in the gradient
-    double* Cl;     // [D*S]  Bloch coefficients of the input states
+    double* Cl;     // [S*D]  Bloch coefficients of the input states, one state per row: Cl[s * D + j] = C[j][s]
     double* hs;     // [m] (eta+ + eta-)/2 ; aliases the Jacobi work matrices
     double* hd;     // [m] coef * (eta+ - eta-)/2
     static size_t bytes(int S, int m) {
@@ -69,16 +69,28 @@ struct PgdbLds {
     }
 };
 
-// T[s][i] = sum_j R[i][j] * C[j][s]
+// T[s][i] = sum_j R[i][j] * C[j][s].  Lane (i = lane % D, q = lane / D) keeps row i of R in registers
+// (Rb is transposed, so the D loads are conflict-free across i) and walks the states s = q, q + 64/D,
+// ...: per state D/2 broadcast 16-byte loads of the state's Bloch vector (Ct is [S][D]) and D FMAs, all
+// straight-line code -- the D x S loop over (s, i) pairs with two 8-byte loads per FMA it replaces
+// took 16k cycles per call for the 36-state design.
 template <int NQ>
-__device__ void predict_table(const double* Rb, const double* Cl, double* T, int S, int lane) {
-    constexpr int D = ChoiLds<NQ>::D;
-    for (int idx = lane; idx < S * D; idx += 64) {
-        const int s = idx / D, i = idx % D;
-        double acc = 0.0;
-#pragma unroll 4
-        for (int j = 0; j < D; ++j) acc += Rb[i * D + j] * Cl[j * S + s];
-        T[idx] = acc;
+__device__ void predict_table(const double* Rb, const double* Ct, double* T, int S, int lane) {
+    constexpr int D = ChoiLds<NQ>::D, STEP = 64 / D;
+    const int i = lane % D, q = lane / D;
+    double r[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) r[j] = Rb[j * D + i];
+    for (int s = q; s < S; s += STEP) {
+        const double2* c2 = reinterpret_cast<const double2*>(Ct + (size_t)s * D);
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) {
+            const double2 c = c2[j];
+            acc0 = fma(r[2 * j], c.x, acc0);
+            acc1 = fma(r[2 * j + 1], c.y, acc1);
+        }
+        T[s * D + i] = acc0 + acc1;
     }
 }
 
@@ -98,7 +110,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     PgdbLds<NQ> L;
     L.carve(smem, S, m);
 
-    for (int idx = lane; idx < D * S; idx += 64) L.Cl[idx] = des.C[idx];
+    for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
 
     // ---- data: n+-[k] = counts * (1 +- e)/2 / grand_total   (tomography.py:528-538)
     double npl[MAXJ], nmi[MAXJ];
@@ -190,13 +202,20 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         __syncthreads();
         choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
         __syncthreads();
+        PH_STOP(pc, 3);
         predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
         __syncthreads();
-        PH_STOP(pc, 3);
+        PH_STOP(pc, 7);
         load_probs(L.Test, pep, pem);
         if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }   // tomography.py:565
 
-        // ---- gradient (tomography.py:617-633): eta = n / clip(p); W_s = sum eta Pi
+        // ---- gradient (tomography.py:617-633): eta = n / clip(p); per input state s the weights of the
+        // Pauli components, Wt[s][0] = sum (eta+ + eta-)/2 and Wt[s][p] = coef (eta+ - eta-)/2, added
+        // straight from the registers of the lanes that own the settings (LDS fp64 atomics; one
+        // wavefront per item, so the order of the additions is the same in every run)
+        double* Wt = L.Tupd;                        // [S][D]
+        for (int idx = lane; idx < D * S; idx += 64) Wt[idx] = 0.0;
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
@@ -205,29 +224,30 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 const double pm = pem[j] < PGDB_EPS ? PGDB_EPS : pem[j];
                 const double ep = npl[j] / pp, em = nmi[j] / pm;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
-                L.hs[g] = 0.5 * (ep + em);
-                L.hd[g] = cf * 0.5 * (ep - em);
+                const int st = spw[j] >> 16, p = spw[j] & 0xffff;
+                atomicAdd(&Wt[st * D], 0.5 * (ep + em));
+                atomicAdd(&Wt[st * D + p], cf * 0.5 * (ep - em));
             }
         }
-        double* W = L.Tupd;                         // [D][S]
-        for (int idx = lane; idx < D * S; idx += 64) W[idx] = 0.0;
         __syncthreads();
-        for (int s = lane; s < S; s += 64) {        // one lane owns one input state: no atomics
-            double w0 = 0.0;
-            for (int g = des.sptr[s]; g < des.sptr[s + 1]; ++g) {
-                const int p = des.sp[g] & 0xffff;
-                w0 += L.hs[g];
-                W[p * S + s] += L.hd[g];
+        // R-coefficients of the gradient: Rg_ij = -(1/d^2) sum_s W[i][s] C[j][s].  Lane (i = lane % D,
+        // jq = lane / D) owns the outputs j = JB jq .. JB jq + JB - 1: per state one conflict-free load of
+        // Wt[s][i] and JB broadcast coefficients of the state's Bloch vector.
+        {
+            constexpr int JB = (D * D + 63) / 64;
+            const int i = lane % D, j0 = (lane / D) * JB;
+            if (j0 < D) {
+                double acc[JB];
+#pragma unroll
+                for (int r = 0; r < JB; ++r) acc[r] = 0.0;
+                for (int st = 0; st < S; ++st) {
+                    const double w = Wt[st * D + i];
+#pragma unroll
+                    for (int r = 0; r < JB; ++r) acc[r] = fma(w, L.Cl[st * D + j0 + r], acc[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < JB; ++r) L.Rb[(j0 + r) * D + i] = -acc[r] / (double)(d * d);
             }
-            W[s] += w0;                              // row i = 0 (identity component)
-        }
-        __syncthreads();
-        // R-coefficients of the gradient: Rg_ij = -(1/d^2) sum_s W[i][s] C[j][s]
-        for (int idx = lane; idx < D * D; idx += 64) {
-            const int i = idx / D, j = idx % D;
-            double acc = 0.0;
-            for (int s = 0; s < S; ++s) acc += W[i * S + s] * L.Cl[j * S + s];
-            L.Rb[idx] = -acc / (double)(d * d);
         }
         __syncthreads();
         const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, L.choi.Mw, lane);

@@ -668,7 +668,7 @@ linv_process_kernel(DesignDev des, long long B, const double* __restrict__ expec
         double acc = 0.0;
         for (int g = des.pptr[i]; g < des.pptr[i + 1]; ++g)
             acc += expect[item * des.m + des.porder[g]] * des.pinvT[(size_t)g * D + j];
-        Rb[idx] = acc + ((idx == 0) ? 1.0 : 0.0);
+        Rb[j * D + i] = acc + ((idx == 0) ? 1.0 : 0.0);      // transposed, as pauli_real_to_choi_blk reads it
     }
     __syncthreads();
     const Blk c = pauli_real_to_choi_blk<NQ>(Rb, Mw, lane);
