@@ -472,9 +472,15 @@ __device__ __forceinline__ Blk reconstruct_blk(const cplx* Vs, const double* lam
     Blk out = blk_zero();
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
-    for (int k = 0; k < N; ++k) {
-        const double l = uniform(lam[k]);
-        if (l == 0.0) continue;
+    // lane k of every wavefront keeps lam[k]; the non-zero ones are walked through a ballot mask and
+    // v_readlane, so the loop has no LDS load + branch on its critical path
+    const int wl = lane & 63;
+    const double mine = wl < N ? lam[wl] : 0.0;
+    unsigned long long todo = __ballot(mine != 0.0);
+    while (todo) {
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const double l = readlane_f64(mine, k);
         const int kb = k >> 1, ke = k & 1;
         const cplx r0 = Vs[(0 + ke) * LS + I * NB + kb], r1 = Vs[(2 + ke) * LS + I * NB + kb];
         const cplx c0 = Vs[(0 + ke) * LS + J * NB + kb], c1 = Vs[(2 + ke) * LS + J * NB + kb];
