@@ -305,15 +305,47 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         }
         rmax = uniform(wave_max(rmax));
         const bool small_ok = rmax == rmax;
+        // The near-clip outcomes are few and scattered over lanes and slots: they are compacted into
+        // one entry per lane (through LDS -- the Jacobi work area is idle during the line search), so
+        // an evaluation costs one clipped log per lane instead of one per flagged slot and sign.
+        constexpr int CL_MAX = 64;
+        double clip_pe = 1.0, clip_pu = 0.0, clip_n = 0.0;       // this lane's entry of the compact list
+        bool clip_listed = false;
         double clip_base = 0.0;
         if (near_clip) {
+            double* cl = (double*)L.choi.Ms;                     // [3][CL_MAX]
+            int n_clip = 0;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            __syncthreads();
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j) {
-                if (near_clip & (1u << (2 * j)))
-                    clip_base += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * fast_log_pos(pep[j] < PGDB_EPS ? PGDB_EPS : pep[j]) : 0.0;
-                if (near_clip & (2u << (2 * j)))
-                    clip_base += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * fast_log_pos(pem[j] < PGDB_EPS ? PGDB_EPS : pem[j]) : 0.0;
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg) {
+                    if (near_clip & ((1u + sg) << (2 * j))) {
+                        const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? nmi[j] : npl[j];
+                        const bool f = pe < 2.0 * PGDB_EPS;
+                        const unsigned long long mk = __ballot(f);
+                        const int pos = n_clip + __popcll(mk & below);
+                        if (f && pos < CL_MAX) { cl[pos] = pe; cl[CL_MAX + pos] = pu; cl[2 * CL_MAX + pos] = nn; }
+                        n_clip += __popcll(mk);
+                    }
+                }
             }
+            __syncthreads();
+            clip_listed = n_clip <= CL_MAX;
+            if (clip_listed) {
+                if (lane < n_clip) { clip_pe = cl[lane]; clip_pu = cl[CL_MAX + lane]; clip_n = cl[2 * CL_MAX + lane]; }
+                clip_base = clip_n * fast_log_pos(clip_pe < PGDB_EPS ? PGDB_EPS : clip_pe);
+            } else {
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {
+                    if (near_clip & (1u << (2 * j)))
+                        clip_base += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * fast_log_pos(pep[j] < PGDB_EPS ? PGDB_EPS : pep[j]) : 0.0;
+                    if (near_clip & (2u << (2 * j)))
+                        clip_base += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * fast_log_pos(pem[j] < PGDB_EPS ? PGDB_EPS : pem[j]) : 0.0;
+                }
+            }
+            __syncthreads();
         }
         auto log1p_small = [](double x) __attribute__((always_inline)) -> double {
             double q = fma(x, -1.0 / 6.0, 0.2);
@@ -331,12 +363,16 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             for (int j = 0; j < MAXJ; ++j)
                 acc += npl[j] * log1p_small(alpha * ratio(pup[j], pep[j])) + nmi[j] * log1p_small(alpha * ratio(pum[j], pem[j]));
             if (near_clip) {                 // the few outcomes at the clip: exact difference of clipped logs
+                if (clip_listed) {
+                    acc += clip_n * clipped_log(fma(alpha, clip_pu, clip_pe));
+                } else {
 #pragma unroll
-                for (int j = 0; j < MAXJ; ++j) {
-                    if (near_clip & (1u << (2 * j)))
-                        acc += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * clipped_log(fma(alpha, pup[j], pep[j])) : 0.0;
-                    if (near_clip & (2u << (2 * j)))
-                        acc += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * clipped_log(fma(alpha, pum[j], pem[j])) : 0.0;
+                    for (int j = 0; j < MAXJ; ++j) {
+                        if (near_clip & (1u << (2 * j)))
+                            acc += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * clipped_log(fma(alpha, pup[j], pep[j])) : 0.0;
+                        if (near_clip & (2u << (2 * j)))
+                            acc += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * clipped_log(fma(alpha, pum[j], pem[j])) : 0.0;
+                    }
                 }
                 acc -= clip_base;            // this lane's sum of n log(clip(pe)) over those outcomes
             }
