@@ -293,15 +293,21 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         auto ratio = [](double pu, double pe) __attribute__((always_inline)) -> double {
             double ip = __builtin_amdgcn_rcp(pe);
             ip = fma(fma(-pe, ip, 1.0), ip, ip);
-            return pe < 2.0 * PGDB_EPS ? 0.0 : pu * ip;
+            return (pe < 2.0 * PGDB_EPS || fabs(pu) > pe) ? 0.0 : pu * ip;
+        };
+        // outcomes evaluated exactly instead (compact list below): at the clip, or moving by more than
+        // their own size over a full step -- with those out, |pu / pe| <= 1 and the polynomial takes over
+        // from alpha = 2^-9 on whatever the design
+        auto exact = [](double pu, double pe) __attribute__((always_inline)) -> bool {
+            return pe < 2.0 * PGDB_EPS || fabs(pu) > pe;
         };
         double rmax = 0.0;
         uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             rmax = fmax(rmax, fmax(fabs(ratio(pup[j], pep[j])), fabs(ratio(pum[j], pem[j]))));
-            if (__ballot(pep[j] < 2.0 * PGDB_EPS)) near_clip |= 1u << (2 * j);
-            if (__ballot(pem[j] < 2.0 * PGDB_EPS)) near_clip |= 2u << (2 * j);
+            if (__ballot(exact(pup[j], pep[j]))) near_clip |= 1u << (2 * j);
+            if (__ballot(exact(pum[j], pem[j]))) near_clip |= 2u << (2 * j);
         }
         rmax = uniform(wave_max(rmax));
         const bool small_ok = rmax == rmax;
@@ -323,7 +329,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 for (int sg = 0; sg < 2; ++sg) {
                     if (near_clip & ((1u + sg) << (2 * j))) {
                         const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? nmi[j] : npl[j];
-                        const bool f = pe < 2.0 * PGDB_EPS;
+                        const bool f = exact(pu, pe);
                         const unsigned long long mk = __ballot(f);
                         const int pos = n_clip + __popcll(mk & below);
                         if (f && pos < CL_MAX) { cl[pos] = pe; cl[CL_MAX + pos] = pu; cl[2 * CL_MAX + pos] = nn; }
@@ -336,15 +342,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             if (clip_listed) {
                 if (lane < n_clip) { clip_pe = cl[lane]; clip_pu = cl[CL_MAX + lane]; clip_n = cl[2 * CL_MAX + lane]; }
                 clip_base = clip_n * fast_log_pos(clip_pe < PGDB_EPS ? PGDB_EPS : clip_pe);
-            } else {
-#pragma unroll
-                for (int j = 0; j < MAXJ; ++j) {
-                    if (near_clip & (1u << (2 * j)))
-                        clip_base += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * fast_log_pos(pep[j] < PGDB_EPS ? PGDB_EPS : pep[j]) : 0.0;
-                    if (near_clip & (2u << (2 * j)))
-                        clip_base += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * fast_log_pos(pem[j] < PGDB_EPS ? PGDB_EPS : pem[j]) : 0.0;
-                }
-            }
+            }                                                    // more than CL_MAX of them: full evaluations only
             __syncthreads();
         }
         auto log1p_small = [](double x) __attribute__((always_inline)) -> double {
@@ -357,25 +355,13 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         };
         auto clipped_log = [](double p) __attribute__((always_inline)) -> double { return fast_log_pos(p < PGDB_EPS ? PGDB_EPS : p); };
         auto cost_step = [&](double alpha) __attribute__((always_inline)) -> double {
-            if (!(small_ok && alpha * rmax < 0x1p-9)) return cost_at(alpha);
+            if (!(small_ok && (near_clip == 0u || clip_listed) && alpha * rmax < 0x1p-9)) return cost_at(alpha);
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j)
                 acc += npl[j] * log1p_small(alpha * ratio(pup[j], pep[j])) + nmi[j] * log1p_small(alpha * ratio(pum[j], pem[j]));
-            if (near_clip) {                 // the few outcomes at the clip: exact difference of clipped logs
-                if (clip_listed) {
-                    acc += clip_n * clipped_log(fma(alpha, clip_pu, clip_pe));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < MAXJ; ++j) {
-                        if (near_clip & (1u << (2 * j)))
-                            acc += (pep[j] < 2.0 * PGDB_EPS) ? npl[j] * clipped_log(fma(alpha, pup[j], pep[j])) : 0.0;
-                        if (near_clip & (2u << (2 * j)))
-                            acc += (pem[j] < 2.0 * PGDB_EPS) ? nmi[j] * clipped_log(fma(alpha, pum[j], pem[j])) : 0.0;
-                    }
-                }
-                acc -= clip_base;            // this lane's sum of n log(clip(pe)) over those outcomes
-            }
+            if (near_clip)                   // the listed outcomes: exact difference of clipped logs
+                acc += clip_n * clipped_log(fma(alpha, clip_pu, clip_pe)) - clip_base;
             return old_cost - uniform(wave_sum(acc));
         };
 #else
