@@ -186,7 +186,10 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         ++iters;
         const Blk pre_cp = blk_sub(last_state, old_cp);
         bool warm = FBX_WARM_START && it > 0;
+        bool from_slot = false;
+        const int sweeps_before = sweeps;
         if (FBX_WARM_START && store && it < store->nprev && (it == 0 || store->use_prev)) {
+            from_slot = true;
             __syncthreads();
             const cplx* src = store->g + (size_t)it * DD;
 #pragma unroll
@@ -213,11 +216,13 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
             // every basis is written back (4 KB per decomposition, ~2 GB per 1024-item launch = 1 % of
             // the HBM bandwidth): writing only the slots the next call is predicted to use measured
             // 2 % slower, the first small step then finds part of its trajectory without a basis
-            cplx* dst = store->g + (size_t)it * DD;
+            if (!(from_slot && sweeps == sweeps_before)) {       // no sweep on the slot's own basis: nothing changed
+                cplx* dst = store->g + (size_t)it * DD;
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int idx = lane + 64 * u;
-                if (idx < DD) dst[idx] = L.Vs[idx];
+                for (int u = 0; u < PF; ++u) {
+                    const int idx = lane + 64 * u;
+                    if (idx < DD) dst[idx] = L.Vs[idx];
+                }
             }
         }
         const Blk new_cp = blk_sub(cp, pre_cp);
