@@ -51,16 +51,16 @@ struct ChoiLds {
 template <int NQ>
 __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, bool warm = false) {
     constexpr int D = ChoiLds<NQ>::D;
-    __syncthreads();                       // previous readers of Ms / Vs are done
+    FBX_WAVE_SYNC();                       // previous readers of Ms / Vs are done
     sys_store<D>(L.Ms, lane, x);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     const Blk xa = sys_load_adjoint<D>(L.Ms, lane);
     Blk h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (x.re[e] + xa.re[e]); h.im[e] = 0.5 * (x.im[e] + xa.im[e]); }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     sys_store<D>(L.Ms, lane, h);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     PH_STOP(*L.pc, 2);
     // warm start: the eigenvectors of the previous projection (still in Vs) nearly diagonalise
     // this matrix, because consecutive Dykstra iterates are close
@@ -71,7 +71,7 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
         const double l = L.Ms[sys_index<D>(lane, lane)].re;
         L.lam[lane] = l < 0.0 ? 0.0 : l;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     const Blk out = reconstruct_blk<D>(L.Vs, L.lam, lane);
     PH_STOP(*L.pc, 1);
     return out;
@@ -82,9 +82,9 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
 template <int NQ>
 __device__ void partial_trace_out(const Blk& x, ChoiLds<NQ>& L, int lane) {
     constexpr int d = ChoiLds<NQ>::d, D = ChoiLds<NQ>::D, LD = ChoiLds<NQ>::LD, LDs = ChoiLds<NQ>::LDs;
-    __syncthreads();
+    FBX_WAVE_SYNC();
     blk_store<D, LD>(L.Mw, lane, x);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     if (lane < d * d) {
         const int i = lane / d, ip = lane % d;
         cplx s; s.re = 0.0; s.im = 0.0;
@@ -95,7 +95,7 @@ __device__ void partial_trace_out(const Blk& x, ChoiLds<NQ>& L, int lane) {
         }
         L.pt[i * LDs + ip] = s;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
 }
 
 // subtract kron(corr / d, I_d) where corr (d x d) is in L.pt
@@ -123,7 +123,7 @@ __device__ Blk proj_tp_blk(const Blk& x, ChoiLds<NQ>& L, int lane) {
     constexpr int d = ChoiLds<NQ>::d, LDs = ChoiLds<NQ>::LDs;
     partial_trace_out<NQ>(x, L, lane);
     if (lane < d) L.pt[lane * LDs + lane].re -= 1.0;       // pt - I
-    __syncthreads();
+    FBX_WAVE_SYNC();
     return subtract_kron_pt<NQ>(x, L, lane);
 }
 
@@ -139,19 +139,19 @@ __device__ Blk proj_tni_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps)
     Blk h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (ptb.re[e] + pta.re[e]); h.im[e] = 0.5 * (ptb.im[e] + pta.im[e]); }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     sys_store<d>(L.pts, lane, h);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     sweeps += jacobi_eigh_lds<d>(L.pts, L.ptV, L.rec, lane);
     if (lane < d) {
         const double l = L.pts[sys_index<d>(lane, lane)].re;
         L.lam[lane] = l > 1.0 ? 1.0 : l;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     const Blk proj = reconstruct_blk<d>(L.ptV, L.lam, lane);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     blk_store<d, LDs>(L.pt, lane, blk_sub(ptb, proj));      // pt - projection
-    __syncthreads();
+    FBX_WAVE_SYNC();
     return subtract_kron_pt<NQ>(x, L, lane);
 }
 
@@ -164,6 +164,8 @@ __device__ Blk proj_tni_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps)
 // j of the previous call when the caller says the outer step was small (`use_prev`; the first
 // projection, which has no basis of its own run to start from, always does).  A basis is only an
 // initial guess -- every decomposition still runs to the same off-norm tolerance.
+typedef double fbx_v2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) fbx_v2d* fbx_global_cplx_ptr;   // HBM: global_load / global_store, not flat_*
 struct BasisStore {
     cplx* g;          // [cap][D * D] in the Jacobi layout, private to the item
     int cap;          // slots
@@ -190,12 +192,19 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         const int sweeps_before = sweeps;
         if (FBX_WARM_START && store && it < store->nprev && (it == 0 || store->use_prev)) {
             from_slot = true;
-            __syncthreads();
-            const cplx* src = store->g + (size_t)it * DD;
+            FBX_WAVE_SYNC();
+            if (!have_pf) {                                       // nothing in flight (first iteration): fetch now
+                const fbx_global_cplx_ptr src = (fbx_global_cplx_ptr)(store->g + (size_t)it * DD);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int idx = lane + 64 * u;
+                    if (idx < DD) { const fbx_v2d w = src[idx]; pf[u].re = w.x; pf[u].im = w.y; }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int idx = lane + 64 * u;
-                if (idx < DD) L.Vs[idx] = have_pf ? pf[u] : src[idx];
+                if (idx < DD) L.Vs[idx] = pf[u];
             }
             warm = true;
         }
@@ -205,11 +214,11 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
             // loads of the next basis first, stores of this one behind them: vector memory returns in
             // issue order, so consuming the loads next iteration never waits for the stores
             if (store->use_prev && it + 1 < store->nprev) {      // overlaps the TP projection and the stop test
-                const cplx* nxt = store->g + (size_t)(it + 1) * DD;
+                const fbx_global_cplx_ptr nxt = (fbx_global_cplx_ptr)(store->g + (size_t)(it + 1) * DD);
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int idx = lane + 64 * u;
-                    if (idx < DD) pf[u] = nxt[idx];
+                    if (idx < DD) { const fbx_v2d w = nxt[idx]; pf[u].re = w.x; pf[u].im = w.y; }
                 }
                 have_pf = true;
             }
@@ -217,11 +226,11 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
             // the HBM bandwidth): writing only the slots the next call is predicted to use measured
             // 2 % slower, the first small step then finds part of its trajectory without a basis
             if (!(from_slot && sweeps == sweeps_before)) {       // no sweep on the slot's own basis: nothing changed
-                cplx* dst = store->g + (size_t)it * DD;
+                fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * DD);
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int idx = lane + 64 * u;
-                    if (idx < DD) dst[idx] = L.Vs[idx];
+                    if (idx < DD) { const cplx w = L.Vs[idx]; dst[idx] = fbx_v2d{w.re, w.im}; }
                 }
             }
         }
@@ -313,12 +322,12 @@ __device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
 #pragma unroll
     for (int t = NQ - 1; t >= 0; --t) {            // input-qubit sites: row bit NQ + t, col bit NQ + t
         pauli_site_stage<NQ, false>(Mw, lane, 2 * NQ + NQ + t, NQ + t, -1.0);
-        __syncthreads();
+        FBX_WAVE_SYNC();
     }
 #pragma unroll
     for (int t = NQ - 1; t >= 0; --t) {            // output-qubit sites
         pauli_site_stage<NQ, false>(Mw, lane, 2 * NQ + t, t, +1.0);
-        __syncthreads();
+        FBX_WAVE_SYNC();
     }
     for (int idx = lane; idx < D * D; idx += 64) {
         int row, col;
@@ -331,26 +340,26 @@ __device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
 template <int NQ>
 __device__ Blk pauli_real_to_choi_blk(const double* Rb, cplx* Mw, int lane) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    __syncthreads();
+    FBX_WAVE_SYNC();
     for (int idx = lane; idx < D * D; idx += 64) {
         int row, col;
         pauli_coeff_position<NQ>(idx / D, idx % D, row, col);
         cplx v; v.re = Rb[(idx % D) * D + idx / D] * d; v.im = 0.0;     // E = d * F^{-1}(R); Rb[j * D + i] = R[i][j]
         Mw[row * LD + col] = v;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         pauli_site_stage<NQ, true>(Mw, lane, 2 * NQ + t, t, +1.0);
-        __syncthreads();
+        FBX_WAVE_SYNC();
     }
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         pauli_site_stage<NQ, true>(Mw, lane, 2 * NQ + NQ + t, NQ + t, -1.0);
-        __syncthreads();
+        FBX_WAVE_SYNC();
     }
     const Blk out = blk_load<D, LD>(Mw, lane);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     return out;
 }
 

@@ -92,6 +92,17 @@ struct PhaseClock { __device__ void reset() {} };
 
 struct __attribute__((aligned(16))) cplx { double re, im; };
 
+// Phase separator for code that runs as ONE wavefront per workgroup.  The LDS instructions of a
+// wavefront execute in program order, so a write phase followed by a read phase needs neither
+// s_barrier nor a wait -- only that the compiler keeps the order and does not carry LDS values in
+// registers across the boundary.  __syncthreads() would add `s_waitcnt vmcnt(0) lgkmcnt(0)`: every
+// outstanding LDS access AND every outstanding HBM load / store (the basis prefetch) completed first.
+#ifdef FBX_WAVE_SYNC_IS_BARRIER
+#define FBX_WAVE_SYNC() __syncthreads()
+#else
+#define FBX_WAVE_SYNC() asm volatile("" ::: "memory")
+#endif
+
 // Wavefront reductions on the VALU: four DPP butterfly steps inside each row of 16 lanes (quad
 // swaps, half-row and row mirrors -- no LDS crossbar round trips as with ds_bpermute), then the four
 // row results through v_readlane.  Every lane gets the same value (already wave-uniform); the

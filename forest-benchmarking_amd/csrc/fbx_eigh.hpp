@@ -314,7 +314,7 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
     }
     jacobi_apply_v(pc, psr, psi, v0p, v0q, v1p, v1q);      // flush the last pending update
     Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
-    __syncthreads();
+    FBX_WAVE_SYNC();
     return sweep;
 }
 #endif
@@ -347,7 +347,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             Vs[e * LS + me] = v;
         }
     }
-    __syncthreads();
+    if constexpr (NT > 64) __syncthreads(); else FBX_WAVE_SYNC();
     int sweep = 0;
     for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
         {
@@ -402,7 +402,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             }
             if constexpr (NT > 64) __syncthreads();
         }
-        if constexpr (NT <= 64) __syncthreads();
+        if constexpr (NT <= 64) FBX_WAVE_SYNC();
     }
     return sweep;
 }
@@ -433,7 +433,7 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) Ts[e * LS + me] = t[e];
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
 #pragma unroll
     for (int e = 0; e < 4; ++e) { t[e].re = 0.0; t[e].im = 0.0; }
     for (int kb = 0; kb < NB; ++kb) {
@@ -448,13 +448,13 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
             t[3].re += u1.re * w1.re + u1.im * w1.im; t[3].im += u1.re * w1.im - u1.im * w1.re;
         }
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     if (act) {
         if (I == J) { t[0].im = 0.0; t[3].im = 0.0; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) Ms[e * LS + me] = t[e];
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
 }
 
 template <int N, int NT = 64>

@@ -36,32 +36,22 @@ struct PgdbLds {
     ChoiLds<NQ> choi;
     double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time), TRANSPOSED: Rb[j * D + i] = R[i][j]
     double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
-    double* Tupd;   // [S*D]  same for the update direction; aliased as W[D][S] in the gradient
+    double* Tupd;   // [S*D]  same for the update direction; reused as Wt[S][D] in the gradient
     double* Cl;     // [S*D]  Bloch coefficients of the input states, one state per row: Cl[s * D + j] = C[j][s]
-    double* hs;     // [m] (eta+ + eta-)/2 ; aliases the Jacobi work matrices
-    double* hd;     // [m] coef * (eta+ - eta-)/2
-    static size_t bytes(int S, int m) {
+    static size_t bytes(int S, int /*m*/) {
         constexpr int D = ChoiLds<NQ>::D;
-        size_t choi = ChoiLds<NQ>::bytes();
-        size_t h = sizeof(double) * 2 * (size_t)m;
-        size_t jac = sizeof(cplx) * (D * ChoiLds<NQ>::LD + 2 * D * D);
-        size_t extra = h > jac ? h - jac : 0;     // h aliases Mw..Vw, spill past them if longer
-        return choi + extra + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + 64;
+        return ((ChoiLds<NQ>::bytes() + 15) & ~(size_t)15) + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + 64;
     }
-    __device__ void carve(char* p, int S, int m) {
+    // every pointer is a plain offset from the start of the dynamic LDS segment (no conditional
+    // layout), so the compiler keeps them in the LDS address space (ds_* instead of flat_*)
+    __device__ void carve(char* p, int S, int /*m*/) {
         constexpr int D = ChoiLds<NQ>::D;
-        char* base = p;
-        size_t h = sizeof(double) * 2 * (size_t)m;
-        size_t jac = sizeof(cplx) * (D * ChoiLds<NQ>::LD + 2 * D * D);
-        if (h > jac) {            // put the h arrays first, Jacobi matrices inside them
-            hs = (double*)p; hd = hs + m;
-            choi.carve(p);
-            p = base + (h > ChoiLds<NQ>::bytes() ? h : ChoiLds<NQ>::bytes());
-        } else {
-            choi.carve(p);
-            hs = (double*)choi.Mw; hd = hs + m;
-        }
-        p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        char* q = p;
+        choi.carve(q);
+        // (rounding the POINTER up through an integer cast would turn everything behind it into
+        // generic-address-space pointers: flat_load / flat_store instead of ds_read / ds_write)
+        constexpr size_t aligned = (ChoiLds<NQ>::bytes() + 15) & ~(size_t)15;
+        p += aligned;
         Rb = (double*)p; p += sizeof(double) * D * D;
         Test = (double*)p; p += sizeof(double) * S * D;
         Tupd = (double*)p; p += sizeof(double) * S * D;
@@ -181,7 +171,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         const int I = lane / NB, J = lane % NB;
         if (I == J) { est.re[0] = 1.0 / d; est.re[3] = 1.0 / d; }
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
 
     int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
     // eigenvector bases of the previous outer iteration's Dykstra run (fbx_choi.hpp BasisStore)
@@ -197,14 +187,14 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
         // ---- prediction table of the current estimate
-        __syncthreads();
+        FBX_WAVE_SYNC();
         blk_store<D, LD>(L.choi.Mw, lane, est);
-        __syncthreads();
+        FBX_WAVE_SYNC();
         choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
-        __syncthreads();
+        FBX_WAVE_SYNC();
         PH_STOP(pc, 3);
         predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
-        __syncthreads();
+        FBX_WAVE_SYNC();
         PH_STOP(pc, 7);
         load_probs(L.Test, pep, pem);
         if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }   // tomography.py:565
@@ -215,7 +205,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         // wavefront per item, so the order of the additions is the same in every run)
         double* Wt = L.Tupd;                        // [S][D]
         for (int idx = lane; idx < D * S; idx += 64) Wt[idx] = 0.0;
-        __syncthreads();
+        FBX_WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
@@ -229,7 +219,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 atomicAdd(&Wt[st * D + p], cf * 0.5 * (ep - em));
             }
         }
-        __syncthreads();
+        FBX_WAVE_SYNC();
         // R-coefficients of the gradient: Rg_ij = -(1/d^2) sum_s W[i][s] C[j][s].  Lane (i = lane % D,
         // jq = lane / D) owns the outputs j = JB jq .. JB jq + JB - 1: per state one conflict-free load of
         // Wt[s][i] and JB broadcast coefficients of the state's Bloch vector.
@@ -249,7 +239,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 for (int r = 0; r < JB; ++r) L.Rb[(j0 + r) * D + i] = -acc[r] / (double)(d * d);
             }
         }
-        __syncthreads();
+        FBX_WAVE_SYNC();
         const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, L.choi.Mw, lane);
         PH_STOP(pc, 4);
 
@@ -270,13 +260,13 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         PH_STOP(pc, 2);
 
         // ---- prediction table of the update direction
-        __syncthreads();
+        FBX_WAVE_SYNC();
         blk_store<D, LD>(L.choi.Mw, lane, upd);
-        __syncthreads();
+        FBX_WAVE_SYNC();
         choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
-        __syncthreads();
+        FBX_WAVE_SYNC();
         predict_table<NQ>(L.Rb, L.Cl, L.Tupd, S, lane);
-        __syncthreads();
+        FBX_WAVE_SYNC();
         load_probs(L.Tupd, pup, pum);
         PH_STOP(pc, 3);
         // ---- backtracking line search (tomography.py:575-585)
@@ -322,7 +312,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             double* cl = (double*)L.choi.Ms;                     // [3][CL_MAX]
             int n_clip = 0;
             const unsigned long long below = (1ull << lane) - 1ull;
-            __syncthreads();
+            FBX_WAVE_SYNC();
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j) {
 #pragma unroll
@@ -337,13 +327,13 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                     }
                 }
             }
-            __syncthreads();
+            FBX_WAVE_SYNC();
             clip_listed = n_clip <= CL_MAX;
             if (clip_listed) {
                 if (lane < n_clip) { clip_pe = cl[lane]; clip_pu = cl[CL_MAX + lane]; clip_n = cl[2 * CL_MAX + lane]; }
                 clip_base = clip_n * fast_log_pos(clip_pe < PGDB_EPS ? PGDB_EPS : clip_pe);
             }                                                    // more than CL_MAX of them: full evaluations only
-            __syncthreads();
+            FBX_WAVE_SYNC();
         }
         auto log1p_small = [](double x) __attribute__((always_inline)) -> double {
             double q = fma(x, -1.0 / 6.0, 0.2);

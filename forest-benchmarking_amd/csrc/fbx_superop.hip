@@ -183,7 +183,7 @@ convert_kernel(int from, int to, long long B, const double* __restrict__ in, int
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* p = smem;
     ChoiLds<NQ> L; L.carve(p);
-    p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    p = smem + ((ChoiLds<NQ>::bytes() + 15) & ~(size_t)15);      // (no pointer -> integer -> pointer: keeps the LDS address space)
     cplx* A = (cplx*)p; p += sizeof(cplx) * D * LD;
     cplx* Bm = (cplx*)p; p += sizeof(cplx) * D * LD;
     cplx* kb = (cplx*)p;
