@@ -185,17 +185,17 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         bool warm = it > 0 && Tg != nullptr;
         if (store && Tg && it < store->nprev && (it == 0 || store->use_prev)) {
             __syncthreads();
-            const cplx* src = store->g + (size_t)it * D * D;
+            const fbx_global_cplx_ptr src = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) L.Vs[e * NT + t] = src[e * NT + t];
+            for (int e = 0; e < 4; ++e) { const fbx_v2d w = src[e * NT + t]; cplx v; v.re = w.x; v.im = w.y; L.Vs[e * NT + t] = v; }
             __syncthreads();
             warm = true;
         }
         const Blk cp = proj_cp(pre_cp, L, t, sweeps, warm, Tg);
         if (store && it < store->cap) {
-            cplx* dst = store->g + (size_t)it * D * D;
+            fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[e * NT + t] = L.Vs[e * NT + t];
+            for (int e = 0; e < 4; ++e) { const cplx v = L.Vs[e * NT + t]; dst[e * NT + t] = fbx_v2d{v.re, v.im}; }
         }
         const Blk new_cp = blk_sub(cp, pre_cp);
         const Blk pre_tp = blk_sub(cp, old_tp);
