@@ -278,8 +278,6 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         // Once alpha |pu / pe| < 2^-9 for every outcome (and nothing sits at the clip), log1p is a
         // degree-6 polynomial to < 1e-17 relative -- 8 instructions per outcome instead of ~40.  The
         // long halving runs of stalled iterations live here.
-        // (the ratios are recomputed per evaluation -- three instructions -- rather than kept: the
-        // kernel sits at the 512-register limit and 2 MAXJ more doubles went to scratch)
         auto ratio = [](double pu, double pe) __attribute__((always_inline)) -> double {
             double ip = __builtin_amdgcn_rcp(pe);
             ip = fma(fma(-pe, ip, 1.0), ip, ip);
@@ -292,10 +290,12 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             return pe < 2.0 * PGDB_EPS || fabs(pu) > pe;
         };
         double rmax = 0.0;
+        double rp[MAXJ], rm[MAXJ];           // pu / pe per outcome (0 for the listed ones), kept for the evaluations
         uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            rmax = fmax(rmax, fmax(fabs(ratio(pup[j], pep[j])), fabs(ratio(pum[j], pem[j]))));
+            rp[j] = ratio(pup[j], pep[j]); rm[j] = ratio(pum[j], pem[j]);
+            rmax = fmax(rmax, fmax(fabs(rp[j]), fabs(rm[j])));
             if (__ballot(exact(pup[j], pep[j]))) near_clip |= 1u << (2 * j);
             if (__ballot(exact(pum[j], pem[j]))) near_clip |= 2u << (2 * j);
         }
@@ -349,7 +349,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j)
-                acc += npl[j] * log1p_small(alpha * ratio(pup[j], pep[j])) + nmi[j] * log1p_small(alpha * ratio(pum[j], pem[j]));
+                acc += npl[j] * log1p_small(alpha * rp[j]) + nmi[j] * log1p_small(alpha * rm[j]);
             if (near_clip)                   // the listed outcomes: exact difference of clipped logs
                 acc += clip_n * clipped_log(fma(alpha, clip_pu, clip_pe)) - clip_base;
             return old_cost - uniform(wave_sum(acc));
