@@ -46,10 +46,11 @@ struct Lds {
 __device__ __forceinline__ double bsum(double v, Lds& L) { return block_sum<NT>(v, L.red); }
 
 // ---- warm start: Ms <- V^H Ms V for the eigenvectors V of the previous projection (still in Vs).
-// LDS is full, so the intermediate product T = Ms V goes through a 64 KiB L2-resident scratch of
-// this workgroup (`Tg`, element-major); agent-scope fences around the barrier make the other
-// waves' stores visible past the per-CU L1.
+// LDS is full, but the intermediate product T = Ms V can take the place of Ms itself once every
+// thread holds its block of it (a first version sent T through an L2 scratch: 1 MB of L2 reads per
+// decomposition).  `Tg` only says that warm starts are enabled.
 __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
+    (void)Tg;
     const int I = t / NB, J = t % NB;
     cplx acc[4];
 #pragma unroll
@@ -65,18 +66,18 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
             acc[3].re += h1.re * v1.re - h1.im * v1.im; acc[3].im += h1.re * v1.im + h1.im * v1.re;
         }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) Tg[e * NT + t] = acc[e];
-    __threadfence();
+    // T = Ms V replaces Ms in place: H is dead once every thread has its block of the product
     __syncthreads();
-    __threadfence();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) L.Ms[e * NT + t] = acc[e];
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[e].re = 0.0; acc[e].im = 0.0; }
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int ke = 0; ke < 2; ++ke) {
             const cplx u0 = L.Vs[(ke * 2 + 0) * NT + kb * NB + I], u1 = L.Vs[(ke * 2 + 1) * NT + kb * NB + I];
-            const cplx w0 = Tg[(ke * 2 + 0) * NT + kb * NB + J], w1 = Tg[(ke * 2 + 1) * NT + kb * NB + J];
+            const cplx w0 = L.Ms[(ke * 2 + 0) * NT + kb * NB + J], w1 = L.Ms[(ke * 2 + 1) * NT + kb * NB + J];
             acc[0].re += u0.re * w0.re + u0.im * w0.im; acc[0].im += u0.re * w0.im - u0.im * w0.re;
             acc[1].re += u0.re * w1.re + u0.im * w1.im; acc[1].im += u0.re * w1.im - u0.im * w1.re;
             acc[2].re += u1.re * w0.re + u1.im * w0.im; acc[2].im += u1.re * w0.im - u1.im * w0.re;
