@@ -139,3 +139,18 @@ def test_state_estimators_on_ragged_designs(gpu):
             assert np.abs(lin[b] - oe.linear_inv_state_estimate(od_, e[b, keep])).max() < 1e-10
             want = oe.iterative_mle_state_estimate(od_, e[b, keep], c[b, keep], maxiter=200)
             assert np.abs(mle[b] - want).max() < 1e-9
+
+
+def test_batches_beyond_one_launch_chunk(gpu):
+    """More than 8192 items go through several launches that share the basis-store workspace."""
+    from fbx import synthetic, tomography
+    design, us, e, c = synthetic.process_batch(1, "sic", 7)
+    B = 8192 + 300
+    reps = -(-B // 7)
+    eb, cb = np.tile(e, (reps, 1))[:B], np.tile(c, (reps, 1))[:B]
+    got, st = tomography.pgdb_process_estimate_batch(design, eb, cb, return_stats=True)
+    ref, rst = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True)
+    idx = np.arange(B) % 7
+    assert np.array_equal(got, ref[idx])
+    assert np.array_equal(st["iterations"], rst["iterations"][idx]) and np.array_equal(st["dykstra"], rst["dykstra"][idx])
+    assert np.array_equal(st["cost"], rst["cost"][idx])
