@@ -154,3 +154,19 @@ def test_batches_beyond_one_launch_chunk(gpu):
     assert np.array_equal(got, ref[idx])
     assert np.array_equal(st["iterations"], rst["iterations"][idx]) and np.array_equal(st["dykstra"], rst["dykstra"][idx])
     assert np.array_equal(st["cost"], rst["cost"][idx])
+
+
+def test_design_with_more_than_576_settings(gpu):
+    """2-qubit designs between 577 and 1024 settings use the 16-settings-per-lane instantiation."""
+    from fbx import synthetic
+    from fbx.design import Design
+    full, us, e, c = synthetic.process_batch(2, "pauli", 2)
+    rng = np.random.default_rng(12)
+    extra = rng.choice(full.m, size=200, replace=False)
+    idx = np.concatenate([np.arange(full.m), extra])
+    d = Design(2, "process", full.in_labels[idx], full.paulis[idx])
+    e2 = np.concatenate([e, np.clip(e[:, extra] + rng.normal(0, 0.03, size=(2, 200)), -1, 1)], axis=1)
+    c2 = np.concatenate([c, c[:, extra]], axis=1)
+    assert d.m == 740
+    _check(d, e2, c2, mode="fixed", max_iters=8)
+    _check(d, e2, c2)
