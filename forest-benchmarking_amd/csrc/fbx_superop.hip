@@ -745,22 +745,34 @@ int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect, 
     return io.sync();
 }
 
-int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K, double* out) {
+static int convert_check(int from_rep, int to_rep, int n_qubits, int64_t B, const void* in, int K, const void* out) {
     FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_convert: n_qubits must be 1..3");
     FBX_REQUIRE(from_rep >= FBX_REP_KRAUS && from_rep <= FBX_REP_CHI, "fbx_convert: bad source representation");
     FBX_REQUIRE(to_rep >= FBX_REP_CHOI && to_rep <= FBX_REP_CHI, "fbx_convert: bad target representation (Kraus output is not offered)");
     FBX_REQUIRE(from_rep != to_rep, "fbx_convert: source and target representation are the same");
     FBX_REQUIRE(B >= 0 && (B == 0 || (in && out)), "fbx_convert: bad batch / NULL buffer");
     FBX_REQUIRE(from_rep != FBX_REP_KRAUS || K >= 1, "fbx_convert: need K >= 1 Kraus operators");
+    return FBX_OK;
+}
+
+int fbx_convert_dev(int from_rep, int to_rep, int n_qubits, int64_t B, const double* d_in, int K, double* d_out) {
+    FBX_TRY(convert_check(from_rep, to_rep, n_qubits, B, d_in, K, d_out));
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    if (n_qubits == 3) return launch_convert3(from_rep, to_rep, B, d_in, K, d_out);
+    if (n_qubits == 1) return launch_convert<1>(from_rep, to_rep, B, d_in, K, d_out);
+    return launch_convert<2>(from_rep, to_rep, B, d_in, K, d_out);
+}
+
+int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K, double* out) {
+    FBX_TRY(convert_check(from_rep, to_rep, n_qubits, B, in, K, out));
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const size_t d = (size_t)1 << n_qubits, D = d * d;
     const size_t n_in = (from_rep == FBX_REP_KRAUS ? (size_t)K * D : D * D) * 2 * B, n_out = D * D * 2 * B;
     HostIO io; double *d_in, *d_out;
     FBX_TRY(io.in(in, n_in, &d_in)); FBX_TRY(io.out(n_out, &d_out));
-    if (n_qubits == 3) FBX_TRY(launch_convert3(from_rep, to_rep, B, d_in, K, d_out));
-    else if (n_qubits == 1) FBX_TRY(launch_convert<1>(from_rep, to_rep, B, d_in, K, d_out));
-    else FBX_TRY(launch_convert<2>(from_rep, to_rep, B, d_in, K, d_out));
+    FBX_TRY(fbx_convert_dev(from_rep, to_rep, n_qubits, B, d_in, K, d_out));
     FBX_TRY(io.back(out, d_out, n_out));
     return io.sync();
 }
@@ -797,25 +809,35 @@ int fbx_kraus_sweep(int n_qubits, int64_t B, int K, const double* kraus, const d
     return io.sync();
 }
 
-int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, double* out, int32_t* iters_out) {
+int fbx_proj_choi_dev(int proj_kind, int n_qubits, int64_t B, const double* d_choi, double* d_out, int32_t* d_iters_out) {
     FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_proj_choi: n_qubits must be 1..3");
     FBX_REQUIRE(proj_kind >= FBX_PROJ_CP && proj_kind <= FBX_PROJ_PHYSICAL_TNI, "fbx_proj_choi: bad projection kind");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_choi && d_out)), "fbx_proj_choi: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    if (n_qubits == 3) {
+        FBX_TRY(proj_choi3_launch(proj_kind, B, d_choi, d_out, d_iters_out));
+    } else if (n_qubits == 1) {
+        const size_t lds = ChoiLds<1>::bytes() + 64;
+        hipLaunchKernelGGL(proj_choi_kernel<1>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_choi, d_out, d_iters_out);
+    } else {
+        const size_t lds = ChoiLds<2>::bytes() + 64;
+        hipLaunchKernelGGL(proj_choi_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_choi, d_out, d_iters_out);
+    }
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, double* out, int32_t* iters_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_proj_choi: n_qubits must be 1..3");
     FBX_REQUIRE(B >= 0 && (B == 0 || (choi && out)), "fbx_proj_choi: bad batch / NULL buffer");
+    FBX_REQUIRE(proj_kind >= FBX_PROJ_CP && proj_kind <= FBX_PROJ_PHYSICAL_TNI, "fbx_proj_choi: bad projection kind");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const size_t d = (size_t)1 << n_qubits, D = d * d, nm = D * D * 2 * B;
     HostIO io; double *d_in, *d_out; int32_t* d_it;
     FBX_TRY(io.in(choi, nm, &d_in)); FBX_TRY(io.out(nm, &d_out)); FBX_TRY(io.out((size_t)B, &d_it));
-    if (n_qubits == 3) {
-        FBX_TRY(proj_choi3_launch(proj_kind, B, d_in, d_out, d_it));
-    } else if (n_qubits == 1) {
-        const size_t lds = ChoiLds<1>::bytes() + 64;
-        hipLaunchKernelGGL(proj_choi_kernel<1>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_in, d_out, d_it);
-    } else {
-        const size_t lds = ChoiLds<2>::bytes() + 64;
-        hipLaunchKernelGGL(proj_choi_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_in, d_out, d_it);
-    }
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_proj_choi_dev(proj_kind, n_qubits, B, d_in, d_out, d_it));
     FBX_TRY(io.back(out, d_out, nm)); FBX_TRY(io.back(iters_out, d_it, (size_t)B));
     return io.sync();
 }
@@ -835,6 +857,17 @@ int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rh
     return io.sync();
 }
 
+int fbx_process_fidelity_dev(int n_qubits, int64_t B, const double* d_ptm0, const double* d_ptm1, double* d_fe_out, double* d_fp_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_process_fidelity: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_ptm0 && d_ptm1)), "fbx_process_fidelity: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const unsigned grid = (unsigned)(B < 8192 ? B : 8192);
+    hipLaunchKernelGGL(process_fidelity_kernel, dim3(grid), dim3(64), 0, stream(), 1 << n_qubits, (long long)B, d_ptm0, d_ptm1, d_fe_out, d_fp_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 int fbx_process_fidelity(int n_qubits, int64_t B, const double* ptm0, const double* ptm1, double* fe_out, double* fp_out) {
     FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_process_fidelity: n_qubits must be 1..3");
     FBX_REQUIRE(B >= 0 && (B == 0 || (ptm0 && ptm1)), "fbx_process_fidelity: bad batch / NULL buffer");
@@ -844,9 +877,7 @@ int fbx_process_fidelity(int n_qubits, int64_t B, const double* ptm0, const doub
     HostIO io; double *da, *db, *dfe, *dfp;
     FBX_TRY(io.in(ptm0, nm, &da)); FBX_TRY(io.in(ptm1, nm, &db));
     FBX_TRY(io.out((size_t)B, &dfe)); FBX_TRY(io.out((size_t)B, &dfp));
-    const unsigned grid = (unsigned)(B < 8192 ? B : 8192);
-    hipLaunchKernelGGL(process_fidelity_kernel, dim3(grid), dim3(64), 0, stream(), (int)d, (long long)B, da, db, dfe, dfp);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_process_fidelity_dev(n_qubits, B, da, db, dfe, dfp));
     FBX_TRY(io.back(fe_out, dfe, (size_t)B)); FBX_TRY(io.back(fp_out, dfp, (size_t)B));
     return io.sync();
 }

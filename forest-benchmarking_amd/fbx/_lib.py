@@ -72,6 +72,9 @@ PROTOTYPES = {
     "fbx_shots_to_moments": [C.c_int, _i64, _i64, _u8p, _u8p, _dp, C.c_int, _dp, _dp],
     "fbx_shots_to_moments_dev": [C.c_int, _i64, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp],
     "fbx_dfe_estimate": [C.c_int, C.c_int, _i64, _i64, _dp, _dp, _dp, _dp],
+    "fbx_convert_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
+    "fbx_proj_choi_dev": [C.c_int, C.c_int, _i64, _vp, _vp, _vp],
+    "fbx_process_fidelity_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp],
 }
 
 

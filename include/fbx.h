@@ -145,6 +145,9 @@ int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* 
  * are only defined up to phase, superoperator_transformations.py:325-336). */
 int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K,
                 double* out);
+/* same with device pointers (buffers from fbx_malloc): the batch stays resident in HBM */
+int fbx_convert_dev(int from_rep, int to_rep, int n_qubits, int64_t B, const double* d_in, int K,
+                    double* d_out);
 
 /* Fused conversion sweep of BASELINE config 3: kraus2choi -> choi2pauli_liouville ->
  * choi2chi -> process_fidelity(ptm_ref, ptm) (superoperator_transformations.py:159,364,339;
@@ -160,6 +163,9 @@ int fbx_kraus_sweep_dev(int n_qubits, int64_t B, int K, const double* d_kraus,
 int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, double* out,
                   int32_t* iters_out);
 
+int fbx_proj_choi_dev(int proj_kind, int n_qubits, int64_t B, const double* d_choi, double* d_out,
+                      int32_t* d_iters_out);
+
 /* project_state_matrix_to_physical (operator_tools/project_state_matrix.py:6-52). */
 int fbx_proj_state_physical(int n_qubits, int64_t B, const double* rho, double* out);
 
@@ -171,6 +177,8 @@ int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rh
  * NULL. */
 int fbx_process_fidelity(int n_qubits, int64_t B, const double* ptm0, const double* ptm1,
                          double* fe_out, double* fp_out);
+int fbx_process_fidelity_dev(int n_qubits, int64_t B, const double* d_ptm0, const double* d_ptm1,
+                             double* d_fe_out, double* d_fp_out);
 
 /* State measures (distance_measures.py:14-114, :198): purity tr(rho^2), fidelity
  * (tr sqrt(sqrt(rho) sigma sqrt(rho)))^2, trace_distance = 0.5 * induced 1-norm,
