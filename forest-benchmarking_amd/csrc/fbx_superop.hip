@@ -554,12 +554,179 @@ sweep2q_kernel(long long B, int K, const double* __restrict__ kraus, const doubl
 #undef FBX_WAVE_FENCE
 }
 
+// ---------------------------------------------------------------------------------------------
+// sweep2q_pair_kernel: the same pipeline with HALF the LDS traffic (the kernel above is LDS-bandwidth
+// bound: ~100 KB per item).  A wavefront takes TWO Kraus sets; 16 lanes own one 16 x 16 matrix (A ->
+// Pauli-Liouville and W -> chi of each item), 16 elements per lane, so that TWO butterfly stages run in
+// registers per pass and one LDS transpose separates the two passes.  The passes are ordered so that the
+// final registers of a lane are one column (PTM) / one column (chi) of the output in matrix order: the
+// results go from registers to HBM in 256-byte runs, no gather through LDS.  The process fidelity uses
+// tr(R_ref^H R) = tr(E_ref^H E) (the Pauli transform is unitary up to the factor d), so it is reduced from
+// the Choi accumulators against the Choi form of the reference, before any transform.
+// Element index = row * 16 + col (8 bits); lane-group roles: (lane >> 5) = item of the pair,
+// (lane >> 4) & 1 = 0: A, 1: W; within the group, 4 index bits come from the lane and 4 from the register.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int dep4(int v, int b3, int b2, int b1, int b0) {
+    return (((v >> 3) & 1) << b3) | (((v >> 2) & 1) << b2) | (((v >> 1) & 1) << b1) | ((v & 1) << b0);
+}
+__device__ __forceinline__ constexpr int padded(int idx) { return idx + (idx >> 4); }     // (idx >> 4) * 17 + (idx & 15)
+
+// two sites on the 16 registers of a lane: register index r = (p1 q1 p2 q2)
+__device__ __forceinline__ void two_sites(cplx (&x)[16], double y1, double y2) {
+    auto site = [](cplx& c00, cplx& c11, cplx& c01, cplx& c10, double ys) {
+        cplx oi, oz, ox, oy;
+        oi.re = c00.re + c11.re; oi.im = c00.im + c11.im;
+        oz.re = c00.re - c11.re; oz.im = c00.im - c11.im;
+        ox.re = c01.re + c10.re; ox.im = c01.im + c10.im;
+        const double dr = c01.re - c10.re, di = c01.im - c10.im;
+        oy.re = -ys * di; oy.im = ys * dr;
+        c00 = oi; c11 = oz; c01 = ox; c10 = oy;
+    };
+#pragma unroll
+    for (int cd = 0; cd < 4; ++cd) site(x[cd], x[12 | cd], x[4 | cd], x[8 | cd], y1);            // p1 = bit 3, q1 = bit 2
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) site(x[ab << 2], x[(ab << 2) | 3], x[(ab << 2) | 1], x[(ab << 2) | 2], y2);   // p2 = bit 1, q2 = bit 0
+}
+
+__global__ void __launch_bounds__(64)
+sweep2q_pair_kernel(long long B, int K, const double* __restrict__ kraus, const double* __restrict__ choi_ref,
+                    double* __restrict__ choi_out, double* __restrict__ ptm_out, double* __restrict__ chi_out,
+                    double* __restrict__ fid_out) {
+    constexpr int D = 16, MAT = 16 * 17;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* bufA = (cplx*)smem;              // [2][MAT] Choi of the item, then the A transpose
+    cplx* bufW = bufA + 2 * MAT;           // [2][MAT] W transpose
+    cplx* kbs = bufW + 2 * MAT;            // [2][K * 16] vec of the Kraus operators
+    const int lane = threadIdx.x;
+    const int h = lane >> 5, u = lane & 31, w = (lane >> 4) & 1, l = lane & 15;
+    const int col = u & 15, row0 = (u >> 4) * 8;           // kraus2choi: this lane owns C[row0 .. row0 + 7][col]
+    // LDS addresses of the 16 registers in the two passes (additive: lane part + register part, no carries)
+    const int la1 = padded(w ? dep4(l, 7, 6, 5, 4) : dep4(l, 5, 4, 1, 0));
+    const int la2 = padded(w ? dep4(l, 3, 2, 1, 0) : dep4(l, 7, 6, 3, 2));
+    const int jcol = ((l >> 3) & 1) << 3 | ((l >> 1) & 1) << 2 | ((l >> 2) & 1) << 1 | (l & 1);   // output column of this lane
+    cplx* mine = (w ? bufW : bufA) + h * MAT;              // where this lane's matrix is transposed
+    const cplx* src = bufA + h * MAT;                      // the item's Choi matrix
+    cplx* kb = kbs + h * K * D;
+    // reference in Choi form, in the kraus2choi layout
+    cplx ref[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        ref[rr].re = ref[rr].im = 0.0;
+        if (choi_ref) { const double* q = choi_ref + 2 * ((row0 + rr) * D + col); ref[rr].re = q[0]; ref[rr].im = q[1]; }
+    }
+#define FBX_WAVE_FENCE() asm volatile("" ::: "memory")
+    const int n_ld = (K * D + 31) / 32;                    // 16-byte loads per lane and item (K <= 16: at most 8)
+    const long long n_pairs = (B + 1) / 2;
+    double2 nxt[8];
+    auto fetch = [&](long long pair) {
+        const long long item = 2 * pair + h;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+            const int idx = u + 32 * t8;
+            if (t8 < n_ld && idx < K * D && item < B)
+                nxt[t8] = *reinterpret_cast<const double2*>(kraus + (item * (long long)K * D + idx) * 2);
+        }
+    };
+#pragma unroll
+    for (int t8 = 0; t8 < 8; ++t8) nxt[t8].x = nxt[t8].y = 0.0;
+    if ((long long)blockIdx.x < n_pairs) fetch(blockIdx.x);
+    for (long long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        const long long item = 2 * pair + h;
+        const bool live = item < B;
+        // ---- Kraus operators -> LDS as vec(K_t)[c * 4 + r] = K_t[r][c]; next pair's operators from HBM meanwhile
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+            const int idx = u + 32 * t8;
+            if (t8 < n_ld && idx < K * D) {
+                const int t = idx >> 4, rr = (idx >> 2) & 3, cc = idx & 3;
+                cplx c; c.re = nxt[t8].x; c.im = nxt[t8].y;
+                kb[t * D + cc * 4 + rr] = c;
+            }
+        }
+        if (pair + gridDim.x < n_pairs) fetch(pair + gridDim.x);
+        FBX_WAVE_FENCE();
+        // ---- kraus2choi: C[row][col] = sum_t vK_t[row] conj(vK_t[col])
+        cplx acc[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr].re = acc[rr].im = 0.0;
+        for (int t = 0; t < K; ++t) {
+            const cplx b = kb[t * D + col];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const cplx a = kb[t * D + row0 + rr];
+                acc[rr].re += a.re * b.re + a.im * b.im;
+                acc[rr].im += a.im * b.re - a.re * b.im;
+            }
+        }
+        double fr = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            bufA[h * MAT + (row0 + rr) * 17 + col] = acc[rr];
+            fr += ref[rr].re * acc[rr].re + ref[rr].im * acc[rr].im;
+            if (choi_out && live) {
+                double2 v; v.x = acc[rr].re; v.y = acc[rr].im;
+                FBX_STREAM_STORE(reinterpret_cast<double2*>(choi_out + (item * D * D + (row0 + rr) * D + col) * 2), v);
+            }
+        }
+        if (fid_out) {                                     // sum over the 32 lanes of the item
+            fr += dpp_permute<0xB1>(fr); fr += dpp_permute<0x4E>(fr);
+            fr += dpp_permute<0x141>(fr); fr += dpp_permute<0x140>(fr);
+            const double tot = readlane_f64(fr, 0) + readlane_f64(fr, 16), tot1 = readlane_f64(fr, 32) + readlane_f64(fr, 48);
+            if (u == 0 && live) fid_out[item] = (4.0 * ((h ? tot1 : tot) / 16.0) + 1.0) / 5.0;
+        }
+        FBX_WAVE_FENCE();
+        // ---- pass 1: A sites (7,3),(6,2) [-i: input qubits]; W sites (3,1),(2,0) [+i]
+        cplx x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            x[r] = src[la1 + (w ? padded(dep4(r, 3, 1, 2, 0)) : padded(dep4(r, 7, 3, 6, 2)))];
+        two_sites(x, w ? +1.0 : -1.0, w ? +1.0 : -1.0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mine[la1 + (w ? padded(dep4(r, 3, 1, 2, 0)) : padded(dep4(r, 7, 3, 6, 2)))] = x[r];
+        FBX_WAVE_FENCE();
+        // ---- pass 2: A sites (5,1),(4,0) [+i: output qubits]; W sites (7,5),(6,4) [-i]
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            x[r] = mine[la2 + (w ? padded(dep4(r, 7, 5, 6, 4)) : padded(dep4(r, 5, 1, 4, 0)))];
+        two_sites(x, w ? -1.0 : +1.0, w ? -1.0 : +1.0);
+        // ---- register r = output row i, lane = output column jcol: 256-byte runs straight to HBM
+        double* dst = w ? chi_out : ptm_out;
+        const double scale = w ? 0.0625 : 0.25;
+        if (dst && live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double2 o; o.x = x[r].re * scale; o.y = x[r].im * scale;
+                FBX_STREAM_STORE(reinterpret_cast<double2*>(dst + (item * D * D + r * D + jcol) * 2), o);
+            }
+        }
+        FBX_WAVE_FENCE();
+    }
+#undef FBX_WAVE_FENCE
+}
+
 template <int NQ>
 static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi,
                         double* ptm, double* chi, double* fid) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
     const size_t lds = sizeof(cplx) * (4 * D * LD + (size_t)K * D);
     if (lds > 160 * 1024) { set_error("fbx_kraus_sweep: too many Kraus operators"); return FBX_ERR_UNSUPPORTED; }
+    if (NQ == 2 && K <= 16 && !getenv("FBX_SWEEP_GENERIC") && !getenv("FBX_SWEEP_SINGLE")) {
+        // reference in Choi form for the on-the-fly fidelity (one 16 x 16 conversion per call)
+        static double* choi_ref = nullptr;
+        if (ptm_ref) {
+            if (!choi_ref) FBX_HIP(hipMalloc((void**)&choi_ref, sizeof(cplx) * 256));
+            { const int rc = launch_convert<2>(FBX_REP_PAULI_LIOUVILLE, FBX_REP_CHOI, 1, ptm_ref, 0, choi_ref); if (rc) return rc; }
+        }
+        const size_t ldsp = sizeof(cplx) * (4 * 16 * 17 + 2 * (size_t)K * 16);
+        const long long n_pairs = (B + 1) / 2;
+        const long long cap = getenv("FBX_SWEEP_GRID") ? atoll(getenv("FBX_SWEEP_GRID")) : 256 * 16;   // 8 resident per CU, the rest queued
+        const unsigned gridp = (unsigned)(n_pairs < cap ? n_pairs : cap);
+        hipLaunchKernelGGL(sweep2q_pair_kernel, dim3(gridp), dim3(64), ldsp, stream(), (long long)B, K, kraus,
+                           ptm_ref ? choi_ref : (const double*)nullptr, choi, ptm, chi, fid);
+        FBX_HIP(hipGetLastError());
+        return FBX_OK;
+    }
     if (NQ == 2 && K <= 16 && !getenv("FBX_SWEEP_GENERIC")) {
         const size_t lds2 = sizeof(cplx) * (2 * 16 * 17 + (size_t)K * 16);
         const unsigned grid2 = (unsigned)(B < 256 * 16 ? B : 256 * 16);
