@@ -194,7 +194,7 @@ def run_sweep(args, rank, world, dist, torch):
                            "items_per_gpu": B, "parallelism": f"shard{world}"},
                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": gbs / HBM_PEAK_GBS, "traffic": _profiled("sweep_kernel_hbm_bytes_per_launch"),
-                             "kernel": "sweep2q_kernel",
+                             "kernel": "sweep2q_pair_kernel",
                              "kernel_ms": 1e3 * ksec,
                              "note": "achieved = 13 320 algorithmic bytes per item / HIP-event kernel time"}}
         if world == 1 and args.cpu_sample > 0:
