@@ -127,3 +127,23 @@ def test_reference_signature_wrappers(gpu):
     assert np.abs(p2c - want).max() < 1e-15
     with pytest.raises(ValueError):
         ot.convert_batch("choi", "chi", np.zeros((1, 3, 3)))
+
+
+@pytest.mark.parametrize("B,K", [(1, 4), (7, 1), (129, 3), (4097, 16)])
+def test_fused_sweep_odd_batches_and_kraus_counts(gpu, B, K):
+    """The paired sweep kernel takes two Kraus sets per wavefront: odd batches, a single item and up to
+    16 Kraus operators must give what the pairwise conversions give."""
+    from fbx import _lib, synthetic
+    from fbx import distance_measures as dm
+    from fbx.operator_tools import convert_batch
+    n, D = 2, 16
+    ks = np.ascontiguousarray(synthetic.kraus_batch(n, K, min(B, 64), seed=K)[np.arange(B) % min(B, 64)])
+    ref = convert_batch("kraus", "pauli_liouville", synthetic.kraus_batch(n, 1, 1, seed=99))
+    choi = np.empty((B, D, D), complex); ptm = np.empty_like(choi); chi = np.empty_like(choi); fid = np.empty(B)
+    _lib.check(_lib.lib().fbx_kraus_sweep(n, B, K, _lib.dptr(ks.view(np.float64)), _lib.dptr(np.ascontiguousarray(ref[0]).view(np.float64)),
+                                          _lib.dptr(choi.view(np.float64)), _lib.dptr(ptm.view(np.float64)),
+                                          _lib.dptr(chi.view(np.float64)), _lib.dptr(fid)))
+    assert np.abs(choi - convert_batch("kraus", "choi", ks)).max() < 1e-13
+    assert np.abs(ptm - convert_batch("kraus", "pauli_liouville", ks)).max() < 1e-13
+    assert np.abs(chi - convert_batch("kraus", "chi", ks)).max() < 1e-13
+    assert np.abs(fid - dm.process_fidelity_batch(ref, ptm)).max() < 1e-13
