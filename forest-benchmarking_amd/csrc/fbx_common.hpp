@@ -14,6 +14,7 @@ namespace fbx {
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 hipStream_t stream();
+int device_epoch();      // increases whenever fbx_set_device selects a different device: cached device memory is stale then
 int ensure_device();   // FBX_OK or FBX_ERR_NO_DEVICE (message set)
 
 #define FBX_HIP(call)                                                          \

@@ -407,6 +407,7 @@ __global__ void debug_log_kernel(const double* x, double* out, long long n) {
 
 static cplx* g_basis = nullptr;            // Dykstra eigenvector bases of the items in flight (see launch_pgdb)
 static size_t g_basis_bytes = 0;
+static int g_basis_epoch = -1;            // device_epoch() the workspace was allocated in
 constexpr int BASIS_CAP = 32;              // Dykstra iterations per projection that get a stored basis
 
 long long* g_phase_out = nullptr;          // diagnostics: set by fbx_debug_set_phase_buffer (also read by fbx_pgdb3.hip)
@@ -428,11 +429,11 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     constexpr int64_t CHUNK = 8192;
     const int64_t in_flight = B < CHUNK ? B : CHUNK;
     const size_t need = sizeof(cplx) * D * D * BASIS_CAP * (size_t)in_flight;
-    if (need > g_basis_bytes) {
+    if (need > g_basis_bytes || g_basis_epoch != device_epoch()) {
         if (g_basis) (void)hipFree(g_basis);
         g_basis = nullptr; g_basis_bytes = 0;
         FBX_HIP(hipMalloc((void**)&g_basis, need));
-        g_basis_bytes = need;
+        g_basis_bytes = need; g_basis_epoch = device_epoch();
     }
     const bool dbg = getenv("FBX_DEBUG_SWEEPS") != nullptr;
     const size_t m = des->dev.m;

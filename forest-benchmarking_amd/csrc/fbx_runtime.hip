@@ -10,6 +10,7 @@ namespace fbx {
 static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;
 static int g_device = -1;
+static int g_epoch = 0;
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 
 void set_error(const std::string& msg) { g_err = msg; }
@@ -35,6 +36,7 @@ int ensure_device() {
 }
 
 hipStream_t stream() { return g_stream; }
+int device_epoch() { return g_epoch; }
 
 }  // namespace fbx
 
@@ -71,6 +73,7 @@ int fbx_set_device(int device_id) {
         if (g_ev1) { (void)hipEventDestroy(g_ev1); g_ev1 = nullptr; }
     }
     if (!g_stream) FBX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (g_device != device_id) ++g_epoch;
     g_device = device_id;
     return FBX_OK;
 }

@@ -714,8 +714,14 @@ static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm
     if (NQ == 2 && K <= 16 && !getenv("FBX_SWEEP_GENERIC") && !getenv("FBX_SWEEP_SINGLE")) {
         // reference in Choi form for the on-the-fly fidelity (one 16 x 16 conversion per call)
         static double* choi_ref = nullptr;
+        static int choi_ref_epoch = -1;
         if (ptm_ref) {
-            if (!choi_ref) FBX_HIP(hipMalloc((void**)&choi_ref, sizeof(cplx) * 256));
+            if (!choi_ref || choi_ref_epoch != device_epoch()) {
+                if (choi_ref) (void)hipFree(choi_ref);
+                choi_ref = nullptr;
+                FBX_HIP(hipMalloc((void**)&choi_ref, sizeof(cplx) * 256));
+                choi_ref_epoch = device_epoch();
+            }
             { const int rc = launch_convert<2>(FBX_REP_PAULI_LIOUVILLE, FBX_REP_CHOI, 1, ptm_ref, 0, choi_ref); if (rc) return rc; }
         }
         const size_t ldsp = sizeof(cplx) * (4 * 16 * 17 + 2 * (size_t)K * 16);
