@@ -83,7 +83,7 @@ __device__ cplx r_operator_elem(const DesignDev& des, const double* __restrict__
     constexpr int d = 1 << NQ, D = d * d;
     const int m = des.m;
     pauli_expectations<NQ>(L.rho, L.r, lane);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     double s0 = 0.0;
     for (int g = lane; g < m; g += 64) {
         const int p = des.sp[g] & 0xffff;
@@ -96,13 +96,13 @@ __device__ cplx r_operator_elem(const DesignDev& des, const double* __restrict__
         s0 += 0.5 * (gp + gm);
     }
     s0 = wave_sum(s0);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     if (lane < D) {
         double acc = 0.0;
         for (int g = 0; g < m; ++g) if ((int)(des.sp[g] & 0xffff) == lane) acc += L.hd[g];
         L.w[lane] = acc / m;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     cplx out; out.re = 0.0; out.im = 0.0;
     if (lane < D) out = pauli_synthesis<NQ>(L.w, s0 / m + 0.0, lane / d, lane % d);
     // identity-observable settings contribute through w[0] as well as through s0: P_0 = I
@@ -130,9 +130,9 @@ __device__ void herm_function(const cplx* src, cplx* dst, int fn, StateLds<NQ>& 
             }
         }
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     sys_store<d>(L.Ms, lane, h);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     jacobi_eigh_lds<d>(L.Ms, L.Vs, L.rec, lane);
     double lmax = 0.0;
     if (lane < d) lmax = fabs(L.Ms[sys_index<d>(lane, lane)].re);
@@ -145,10 +145,10 @@ __device__ void herm_function(const cplx* src, cplx* dst, int fn, StateLds<NQ>& 
         else f = sqrt(l > 0.0 ? l : 0.0);
         L.lam[lane] = f;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     const Blk o = reconstruct_blk<d>(L.Vs, L.lam, lane);
     blk_store<d, d>(dst, lane, o);
-    __syncthreads();
+    FBX_WAVE_SYNC();
 }
 
 // tmp2 = A * B (row-major d x d), one output element per lane
@@ -187,7 +187,7 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
     num_meas = wave_sum(num_meas);
     cplx rho; rho.re = (act && row == col) ? 1.0 / d : 0.0; rho.im = 0.0;
     if (act) L.rho[lane] = rho;
-    __syncthreads();
+    FBX_WAVE_SYNC();
     int iteration = 1, hit = 0;
     while (true) {
         if (iteration >= maxiter) { hit = 1; break; }            // tomography.py:244-246
@@ -212,12 +212,12 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
             T.re += beta * pi.re / 2; T.im += beta * pi.im / 2;
         }
         cplx Um; Um.re = epsilon * T.re + ((act && row == col) ? 1.0 : 0.0); Um.im = epsilon * T.im;
-        __syncthreads();
+        FBX_WAVE_SYNC();
         if (act) L.U[lane] = Um;
-        __syncthreads();
+        FBX_WAVE_SYNC();
         const cplx t1 = matmul_elem<NQ>(L.rho, L.U, lane);         // rho U
         if (act) L.tmp[lane] = t1;
-        __syncthreads();
+        FBX_WAVE_SYNC();
         cplx nr = matmul_elem<NQ>(L.U, L.tmp, lane);               // U rho U
         double tr_re = (act && row == col) ? nr.re : 0.0, tr_im = (act && row == col) ? nr.im : 0.0;
         tr_re = wave_sum(tr_re); tr_im = wave_sum(tr_im);
@@ -229,9 +229,9 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
         double diff = act ? (nr.re - rho.re) * (nr.re - rho.re) + (nr.im - rho.im) * (nr.im - rho.im) : 0.0;
         diff = uniform(wave_sum(diff));
         rho = nr;
-        __syncthreads();
+        FBX_WAVE_SYNC();
         if (act) L.rho[lane] = rho;
-        __syncthreads();
+        FBX_WAVE_SYNC();
         if (sqrt(diff) < tol) break;
         ++iteration;
     }
@@ -249,7 +249,7 @@ r_operator_kernel(DesignDev des, long long B, const double* __restrict__ rho_in,
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
     if (lane < D) { L.rho[lane].re = rho_in[(item * D + lane) * 2]; L.rho[lane].im = rho_in[(item * D + lane) * 2 + 1]; }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     const cplx R = r_operator_elem<NQ>(des, expect + item * des.m, L, lane);
     if (lane < D) { r_out[(item * D + lane) * 2] = R.re; r_out[(item * D + lane) * 2 + 1] = R.im; }
 }
@@ -265,9 +265,9 @@ loglik_kernel(DesignDev des, long long B, const double* __restrict__ rho_in, con
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
     if (lane < D) { L.rho[lane].re = rho_in[(item * D + lane) * 2]; L.rho[lane].im = rho_in[(item * D + lane) * 2 + 1]; }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     pauli_expectations<NQ>(L.rho, L.r, lane);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     double ll = 0.0;
     for (int g = lane; g < des.m; g += 64) {
         const int k = des.order[g], p = des.sp[g] & 0xffff;
@@ -299,7 +299,7 @@ linv_state_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         }
         w[lane] = den > 0.0 ? num / (den * d) : 0.0;     // pinv of orthogonal rows c_k vec(P)^H
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     if (lane < D) {
         const cplx v = pauli_synthesis<NQ>(w, 1.0 / d, lane / d, lane % d);   // + I/d, tomography.py:165
         rho_out[(item * D + lane) * 2] = v.re; rho_out[(item * D + lane) * 2 + 1] = v.im;
@@ -323,7 +323,7 @@ proj_state_kernel(long long B, const double* __restrict__ rho_in, double* __rest
     const double den = tr_re * tr_re + tr_im * tr_im;
     cplx q; q.re = (v.re * tr_re + v.im * tr_im) / den; q.im = (v.im * tr_re - v.re * tr_im) / den;
     if (act) L.rho[lane] = q;
-    __syncthreads();
+    FBX_WAVE_SYNC();
     // eigh (lower triangle, like scipy.linalg.eigh)
     constexpr int NB = d / 2;
     Blk h = blk_zero();
@@ -338,7 +338,7 @@ proj_state_kernel(long long B, const double* __restrict__ rho_in, double* __rest
         }
     }
     sys_store<d>(L.Ms, lane, h);
-    __syncthreads();
+    FBX_WAVE_SYNC();
     jacobi_eigh_lds<d>(L.Ms, L.Vs, L.rec, lane);
     __shared__ int physical;
     if (lane == 0) {
@@ -353,12 +353,12 @@ proj_state_kernel(long long B, const double* __restrict__ rho_in, double* __rest
         while (i > 0 && ev[i - 1] + acc / (double)i < 0.0) { acc += ev[i - 1]; --i; }
         for (int j = 0; j < d; ++j) L.lam[idx[j]] = (j < i) ? ev[j] + acc / (double)i : 0.0;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     cplx o = q;
     if (!physical) {
         const Blk pb = reconstruct_blk<d>(L.Vs, L.lam, lane);
         blk_store<d, d>(L.tmp, lane, pb);
-        __syncthreads();
+        FBX_WAVE_SYNC();
         if (act) o = L.tmp[lane];
     }
     if (act) { out[(item * D + lane) * 2] = o.re; out[(item * D + lane) * 2 + 1] = o.im; }
@@ -382,7 +382,7 @@ state_measures_kernel(long long B, const double* __restrict__ rho_in, const doub
         b.re = sig_in[(item * D + lane) * 2]; b.im = sig_in[(item * D + lane) * 2 + 1];
         L.rho[lane] = a; L.U[lane] = b;
     }
-    __syncthreads();
+    FBX_WAVE_SYNC();
     if (purity) {                                  // Re tr(rho rho)
         double p = 0.0;
         if (act) { const cplx t = L.rho[(lane % d) * d + lane / d]; p = a.re * t.re - a.im * t.im; }
@@ -396,22 +396,22 @@ state_measures_kernel(long long B, const double* __restrict__ rho_in, const doub
     }
     if (tdist) {                                   // 0.5 * max_c sum_r |rho - sigma|[r][c]
         if (act) { const double dr = a.re - b.re, di = a.im - b.im; L.r[lane] = sqrt(dr * dr + di * di); }
-        __syncthreads();
+        FBX_WAVE_SYNC();
         double cs = 0.0;
         if (lane < d) for (int r = 0; r < d; ++r) cs += L.r[r * d + lane];
         cs = wave_max(cs);
         if (lane == 0) tdist[item] = 0.5 * cs;
-        __syncthreads();
+        FBX_WAVE_SYNC();
     }
     if (fidelity) {                                // (tr sqrtm_psd(sqrt_rho sigma sqrt_rho))^2
         herm_function<NQ>(L.rho, L.aux, 2, L, lane, true);            // sqrt_rho
         const cplx t1 = matmul_elem<NQ>(L.aux, L.U, lane);            // sqrt_rho sigma
         if (act) L.tmp[lane] = t1;
-        __syncthreads();
+        FBX_WAVE_SYNC();
         const cplx t2 = matmul_elem<NQ>(L.tmp, L.aux, lane);          // ... sqrt_rho
-        __syncthreads();
+        FBX_WAVE_SYNC();
         if (act) L.tmp[lane] = t2;
-        __syncthreads();
+        FBX_WAVE_SYNC();
         herm_function<NQ>(L.tmp, L.aux, 2, L, lane, true);            // lam = sqrt(max(mu, 0))
         double s = (lane < d) ? L.lam[lane] : 0.0;
         s = wave_sum(s);
