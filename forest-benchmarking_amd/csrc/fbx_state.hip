@@ -77,12 +77,43 @@ __device__ __forceinline__ cplx pauli_synthesis(const double* w, double w0, int 
     cplx o; o.re = re; o.im = im; return o;
 }
 
+// One setting of the design held by a lane for the whole reconstruction (designs of at most 64
+// settings -- every state-tomography design of the reference has 4^n - 1 <= 63): Pauli index,
+// coefficient and measured expectation are fetched from HBM once instead of once per iteration.
+struct LaneSetting { int p; double cf, e; bool valid; };
+template <int NQ>
+__device__ __forceinline__ LaneSetting load_lane_setting(const DesignDev& des, const double* __restrict__ e, int lane) {
+    LaneSetting s; s.valid = des.m <= 64 && lane < des.m; s.p = 0; s.cf = 1.0; s.e = 0.0;
+    if (s.valid) { s.p = des.sp[lane] & 0xffff; s.cf = des.unit_coefs ? 1.0 : des.coef[lane]; s.e = e[des.order[lane]]; }
+    return s;
+}
+
 // R operator of tomography.py:273-338 for the state in L.rho; result element of this lane.
 template <int NQ>
-__device__ cplx r_operator_elem(const DesignDev& des, const double* __restrict__ e, StateLds<NQ>& L, int lane) {
+__device__ cplx r_operator_elem(const DesignDev& des, const double* __restrict__ e, StateLds<NQ>& L, int lane,
+                                const LaneSetting* mine = nullptr) {
     constexpr int d = 1 << NQ, D = d * d;
     const int m = des.m;
     pauli_expectations<NQ>(L.rho, L.r, lane);
+    if (mine && m <= 64) {                    // register-resident settings, weights through LDS atomics
+        if (lane < D) L.w[lane] = 0.0;
+        FBX_WAVE_SYNC();
+        double s0 = 0.0;
+        if (mine->valid) {
+            const double pe = mine->cf * L.r[mine->p];
+            const double gp = ((1.0 + mine->e) * 0.5) / ((1.0 + pe) * 0.5 + DBL_MIN);
+            const double gm = ((1.0 - mine->e) * 0.5) / ((1.0 - pe) * 0.5 + DBL_MIN);
+            s0 = 0.5 * (gp + gm);
+            atomicAdd(&L.w[mine->p], mine->cf * 0.5 * (gp - gm));
+        }
+        s0 = wave_sum(s0);
+        FBX_WAVE_SYNC();
+        if (lane < D) L.w[lane] = L.w[lane] / m;
+        FBX_WAVE_SYNC();
+        cplx out; out.re = 0.0; out.im = 0.0;
+        if (lane < D) out = pauli_synthesis<NQ>(L.w, s0 / m + 0.0, lane / d, lane % d);
+        return out;
+    }
     FBX_WAVE_SYNC();
     double s0 = 0.0;
     for (int g = lane; g < m; g += 64) {
@@ -188,10 +219,11 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
     cplx rho; rho.re = (act && row == col) ? 1.0 / d : 0.0; rho.im = 0.0;
     if (act) L.rho[lane] = rho;
     FBX_WAVE_SYNC();
+    const LaneSetting mine = load_lane_setting<NQ>(des, e, lane);
     int iteration = 1, hit = 0;
     while (true) {
         if (iteration >= maxiter) { hit = 1; break; }            // tomography.py:244-246
-        cplx T = r_operator_elem<NQ>(des, e, L, lane);             // R(rho)
+        cplx T = r_operator_elem<NQ>(des, e, L, lane, &mine);      // R(rho)
         if (act && row == col) T.re -= 1.0;                        // Tk = R - I
         if (entropy_penalty > 0.0) {                               // tomography.py:252-254
             herm_function<NQ>(L.rho, L.aux, 0, L, lane, false);    // logm(rho)
