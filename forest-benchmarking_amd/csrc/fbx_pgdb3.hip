@@ -456,7 +456,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         if ((iters & 15) == 0) basis.nprev = 0;       // bounds the accumulated loss of unitarity
         basis.use_prev = outer_step < 1e-3;
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
-                                       scratch ? scratch + (size_t)blockIdx.x * D * D : nullptr,
+                                       scratch,
                                        basis.g ? &basis : nullptr);
         const Blk upd = blk_sub(proj, est);
         PH_STOP(pc, 2);
@@ -520,13 +520,13 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     }
     auto kern = pgdb3_kernel<MAXJ>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // 64 KiB of L2-resident scratch per workgroup for the warm-start product; batches are processed
-    // in chunks so the scratch stays bounded (512 workgroups = 32 MiB)
+    // per-workgroup store of Dykstra eigenvector bases (BASIS_CAP x 64 KiB); batches are processed in
+    // chunks so the store stays bounded (512 workgroups = 768 MiB)
     constexpr int64_t CHUNK = 512;
     constexpr int BASIS_CAP = 24;            // Dykstra iterations per projection with a stored basis (64 KiB each)
     cplx* scratch = nullptr;
-    FBX_HIP(hipMalloc((void**)&scratch, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK) * (1 + BASIS_CAP)));
-    cplx* basis = scratch + (size_t)p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK);
+    FBX_HIP(hipMalloc((void**)&scratch, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK) * BASIS_CAP));
+    cplx* basis = scratch;                   // (`scratch` itself only tells the kernel that warm starts are on)
     const size_t m = des->dev.m, DD = (size_t)p3::D * p3::D;
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
