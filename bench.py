@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--total-batch", type=int, default=0,
                     help="strong scaling (BASELINE configs[4]): this many reconstructions in total, "
                          "block-partitioned over the ranks (e.g. 65536); 0 = weak scaling with --batch per GPU")
+    ap.add_argument("--distinct-shards", action="store_true",
+                    help="weak scaling with a different block of synthetic experiments on every rank "
+                         "(default: every rank runs the N = 1 workload)")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--in-basis", default="pauli")
     ap.add_argument("--cpu-sample", type=int, default=12,
@@ -237,7 +240,12 @@ def main():
         B, first = hi - lo, lo
         scaling = "strong"
     else:
-        B, first = args.batch, rank * args.batch
+        # weak scaling: every rank reconstructs the SAME --batch synthetic experiments (seeds 1000 ..
+        # 1000 + batch - 1, the N = 1 workload), so that per-GPU work really is fixed as N grows; the
+        # 1024-item blocks of consecutive seeds differ by +-15 % in kernel time (one slow item decides,
+        # scripts/block_spread.py), which would otherwise read as scaling loss.  --distinct-shards
+        # gives every rank its own block of seeds instead.
+        B, first = args.batch, (rank * args.batch if args.distinct_shards else 0)
     # distinct synthetic items are generated for up to 4096 per rank and tiled beyond that
     n_distinct = min(B, 4096)
     design, _, e, c = synthetic.process_batch(2, args.in_basis, n_distinct, first_item=first)
@@ -305,6 +313,8 @@ def main():
                                    f"{args.in_basis} in-basis ({design.m} settings, 1000 shots), "
                                    f"{args.iters} fixed PGDB iterations, inputs resident in HBM",
                        "batch_per_gpu": B, "iters": args.iters, "parallelism": f"shard{world}",
+                       "shards": ("distinct seeds per rank" if (args.distinct_shards or args.total_batch > 0)
+                                  else "same experiments on every rank"),
                        "device": dev_name.strip(), "compute_units": cus,
                        "mean_dykstra_iters": float(dyk.mean()),
                        "mean_backtracks": float(bt.mean()),
