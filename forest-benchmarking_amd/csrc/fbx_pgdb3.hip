@@ -523,7 +523,10 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     // per-workgroup store of Dykstra eigenvector bases (BASIS_CAP x 64 KiB); batches are processed in
     // chunks so the store stays bounded (512 workgroups = 768 MiB)
     constexpr int64_t CHUNK = 512;
-    constexpr int BASIS_CAP = 24;            // Dykstra iterations per projection with a stored basis (64 KiB each)
+#ifndef FBX_BASIS_CAP3
+#define FBX_BASIS_CAP3 24
+#endif
+    constexpr int BASIS_CAP = FBX_BASIS_CAP3;   // Dykstra iterations per projection with a stored basis (64 KiB each)
     cplx* scratch = nullptr;
     FBX_HIP(hipMalloc((void**)&scratch, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK) * BASIS_CAP));
     cplx* basis = scratch;                   // (`scratch` itself only tells the kernel that warm starts are on)
