@@ -44,6 +44,25 @@ struct Lds {
 };
 
 __device__ __forceinline__ double bsum(double v, Lds& L) { return block_sum<NT>(v, L.red); }
+// K sums over the workgroup with ONE barrier pair instead of K (every thread gets all totals)
+template <int K>
+__device__ __forceinline__ void bsum_multi(double (&v)[K], Lds& L) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();                                   // earlier readers of `red` are done
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) L.red[k * (NT / 64) + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) s += L.red[k * (NT / 64) + w];
+        v[k] = s;
+    }
+}
 
 // ---- warm start: Ms <- V^H Ms V for the eigenvectors V of the previous projection (still in Vs).
 // LDS is full, but the intermediate product T = Ms V can take the place of Ms itself once every
@@ -206,8 +225,9 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         double i1r, i1i, i2r, i2i;
         blk_dotc(old_tp, blk_sub(new_state, last_state), i1r, i1i);
         blk_dotc(old_cp, blk_sub(cp, last_cp), i2r, i2i);
-        s1 = bsum(s1, L); s2 = bsum(s2, L);
-        i1r = bsum(i1r, L); i1i = bsum(i1i, L); i2r = bsum(i2r, L); i2i = bsum(i2i, L);
+        double red6[6] = {s1, s2, i1r, i1i, i2r, i2i};
+        bsum_multi<6>(red6, L);
+        s1 = red6[0]; s2 = red6[1]; i1r = red6[2]; i1i = red6[3]; i2r = red6[4]; i2i = red6[5];
         const double crit = s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
         if (crit < 1e-4) { ++it; break; }
         old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
