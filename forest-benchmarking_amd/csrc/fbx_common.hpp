@@ -162,6 +162,21 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     }
     return v;
 }
+// two sums at once: one barrier pair instead of two (a workgroup barrier of 16 wavefronts costs
+// thousands of cycles once the waves have drifted apart)
+template <int NT>
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+    a = wave_sum(a); b = wave_sum(b);
+    if constexpr (NT > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[NT / 64 + (threadIdx.x >> 6)] = b; }
+        __syncthreads();
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { sa += red[w]; sb += red[NT / 64 + w]; }
+        a = sa; b = sb;
+    }
+}
 // make a wave-uniform copy (lane 0's value) so branches on it are scalar
 __device__ __forceinline__ double uniform(double v) {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));

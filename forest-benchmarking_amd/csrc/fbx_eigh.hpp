@@ -360,8 +360,8 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
                 if (!(I == J && (e == 0 || e == 3))) o2 += a2;
             }
             if (!act) { o2 = 0.0; n2 = 0.0; }
-            o2 = uniform(block_sum<NT>(o2, red));
-            n2 = uniform(block_sum<NT>(n2, red));
+            block_sum2<NT>(o2, n2, red);
+            o2 = uniform(o2); n2 = uniform(n2);
             if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
