@@ -217,20 +217,25 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const cplx v = L.Vs[e * NT + t]; dst[e * NT + t] = fbx_v2d{v.re, v.im}; }
         }
+        // (per-thread parts of the stop test as early as their operands exist: old_cp and last_cp die
+        // before the TP projection instead of staying live -- in scratch -- across it)
         const Blk new_cp = blk_sub(cp, pre_cp);
+        double s1 = blk_norm2(blk_sub(new_cp, old_cp));
+        double i2r, i2i;
+        blk_dotc(old_cp, blk_sub(cp, last_cp), i2r, i2i);
+        old_cp = new_cp; last_cp = cp;
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = tp ? proj_tp(pre_tp, L, t) : proj_tni(pre_tp, L, t, sweeps);
         const Blk new_tp = blk_sub(new_state, pre_tp);
-        double s1 = blk_norm2(blk_sub(new_cp, old_cp)), s2 = blk_norm2(blk_sub(new_tp, old_tp));
-        double i1r, i1i, i2r, i2i;
+        double s2 = blk_norm2(blk_sub(new_tp, old_tp));
+        double i1r, i1i;
         blk_dotc(old_tp, blk_sub(new_state, last_state), i1r, i1i);
-        blk_dotc(old_cp, blk_sub(cp, last_cp), i2r, i2i);
+        old_tp = new_tp; last_state = new_state;
         double red6[6] = {s1, s2, i1r, i1i, i2r, i2i};
         bsum_multi<6>(red6, L);
         s1 = red6[0]; s2 = red6[1]; i1r = red6[2]; i1i = red6[3]; i2r = red6[4]; i2i = red6[5];
         const double crit = s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
         if (crit < 1e-4) { ++it; break; }
-        old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
     }
     if (store) store->nprev = it < store->cap ? it : store->cap;
     return new_state;
