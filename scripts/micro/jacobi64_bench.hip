@@ -1,0 +1,200 @@
+// Micro-benchmark: 64 x 64 Hermitian Jacobi with 1024 threads -- the library's one-block-per-thread
+// scheme against a role-split scheme (upper-triangle matrix blocks on 8 waves, eigenvector blocks on
+// the other 8, rotations computed once and published through LDS).  Diagnostics only.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../forest-benchmarking_amd/csrc -I../../include jacobi64_bench.hip -o jacobi64_bench
+#include "fbx_eigh.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+namespace fbx { void set_error(const std::string&) {} int hip_fail(hipError_t, const char*, const char*, int) { return 2; } hipStream_t stream() { return 0; } int ensure_device() { return 0; } int device_epoch() { return 0; } }
+using namespace fbx;
+constexpr int N = 64, NB = 32, LS = 1024, NT = 1024;
+
+__device__ int jacobi_eigh_split(cplx* Ms, cplx* Vs, double* rot, double* red, int t) {
+    const bool mrole = t < 512;
+    // ---- block coordinates: M role: upper blocks u = t (and 512 + t for t < 16); V role: (I, J), (I + 16, J)
+    int bI[2], bJ[2];
+    bool has[2] = {true, true};
+    if (mrole) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = t + 512 * k;
+            has[k] = u < 528;
+            int I = 0, off = 0;
+            if (has[k]) while (off + (NB - I) <= u) { off += NB - I; ++I; }
+            bI[k] = has[k] ? I : 0; bJ[k] = has[k] ? I + (u - off) : 0;
+        }
+    } else {
+        const int v = t - 512;
+        bI[0] = v / NB; bJ[0] = v % NB; bI[1] = bI[0] + 16; bJ[1] = bJ[0];
+    }
+    const bool rotrole = !mrole && (t - 512) < NB;         // pivot J = t - 512
+    // ---- read / write addresses, fixed for the whole decomposition
+    int rd[2], w0[2][4], w1[2][4];                         // w1: adjoint seats (M role, I != J)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        rd[k] = bI[k] * NB + bJ[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int sa = jacobi_seat<N>(2 * bI[k] + (e >> 1)), sb = jacobi_seat<N>(2 * bJ[k] + (e & 1));
+            if (mrole) {
+                w0[k][e] = ((sa & 1) * 2 + (sb & 1)) * LS + (sa >> 1) * NB + (sb >> 1);
+                w1[k][e] = ((sb & 1) * 2 + (sa & 1)) * LS + (sb >> 1) * NB + (sa >> 1);
+            } else {
+                w0[k][e] = ((e >> 1) * 2 + (sb & 1)) * LS + bI[k] * NB + (sb >> 1);
+                w1[k][e] = 0;
+            }
+        }
+    }
+    cplx* Mine = mrole ? Ms : Vs;
+    if (!mrole) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cplx c; c.re = (2 * bI[k] + (e >> 1) == 2 * bJ[k] + (e & 1)) ? 1.0 : 0.0; c.im = 0.0;
+                Vs[e * LS + rd[k]] = c;
+            }
+    }
+    __syncthreads();
+    int sweep = 0;
+    for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
+        {
+            double o2 = 0.0, n2 = 0.0;
+            if (mrole) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double wgt = !has[k] ? 0.0 : (bI[k] == bJ[k] ? 1.0 : 2.0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const cplx c = Ms[e * LS + rd[k]];
+                        const double a2 = wgt * (c.re * c.re + c.im * c.im);
+                        n2 += a2;
+                        if (!(bI[k] == bJ[k] && (e == 0 || e == 3))) o2 += a2;
+                    }
+                }
+            }
+            block_sum2<NT>(o2, n2, red);
+            if (!(uniform(o2) > FBX_JACOBI_TOL2 * uniform(n2))) break;
+        }
+        for (int r = 0; r < N - 1; ++r) {
+            cplx x0[4], x1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x0[e] = Mine[e * LS + rd[0]]; x1[e] = Mine[e * LS + rd[1]]; }
+            if (rotrole) {
+                const int J = t - 512, dJ = J * NB + J;
+                const double a = Ms[0 * LS + dJ].re, d = Ms[3 * LS + dJ].re;
+                const cplx b = Ms[1 * LS + dJ];
+                const JRot rj = jacobi_rotation(a, d, b.re, b.im);
+                rot[3 * J] = rj.c; rot[3 * J + 1] = rj.sr; rot[3 * J + 2] = rj.si;
+            }
+            __syncthreads();
+            if (mrole) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    cplx (&x)[4] = k == 0 ? x0 : x1;
+                    if (has[k]) {
+                        const int I = bI[k], J = bJ[k];
+                        jacobi_apply_m(rot[3 * I], rot[3 * I + 1], rot[3 * I + 2], rot[3 * J], rot[3 * J + 1], rot[3 * J + 2],
+                                       x[0], x[1], x[2], x[3]);
+                        if (I == J) { x[1].re = x[1].im = 0.0; x[2].re = x[2].im = 0.0; x[0].im = 0.0; x[3].im = 0.0; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Ms[w0[k][e]] = x[e];
+                        if (I != J) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { cplx c = x[e]; c.im = -c.im; Ms[w1[k][e]] = c; }
+                        }
+                    }
+                }
+            } else {
+                const int J = bJ[0];
+                const double cJ = rot[3 * J], sJr = rot[3 * J + 1], sJi = rot[3 * J + 2];
+                jacobi_apply_v(cJ, sJr, sJi, x0[0], x0[1], x0[2], x0[3]);
+                jacobi_apply_v(cJ, sJr, sJi, x1[0], x1[1], x1[2], x1[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Vs[w0[0][e]] = x0[e]; Vs[w0[1][e]] = x1[e]; }
+            }
+            __syncthreads();
+        }
+    }
+    return sweep;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) k64(const double* A, double* W, double* Vout, long long* cyc, int* sw, int reps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Ms = (cplx*)smem; cplx* Vs = Ms + N * N;
+    double* red = (double*)(Vs + N * N); double* rot = red + 64;
+    const int t = threadIdx.x, item = blockIdx.x;
+    long long total = 0; int sweeps = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int idx = t; idx < N * N; idx += NT) {
+            cplx c; c.re = A[((size_t)item * N * N + idx) * 2]; c.im = A[((size_t)item * N * N + idx) * 2 + 1];
+            Ms[sys_index<N>(idx / N, idx % N)] = c;
+        }
+        __syncthreads();
+        long long t0 = __builtin_readcyclecounter();
+        if (MODE == 0) sweeps += jacobi_eigh_simple<N, NT>(Ms, Vs, t, true, red);
+        else sweeps += jacobi_eigh_split(Ms, Vs, rot, red, t);
+        total += __builtin_readcyclecounter() - t0;
+        __syncthreads();
+    }
+    if (t < N) W[item * N + t] = Ms[sys_index<N>(t, t)].re;
+    for (int idx = t; idx < N * N; idx += NT) {
+        const cplx c = Vs[sys_index<N>(idx / N, idx % N)];
+        Vout[((size_t)item * N * N + idx) * 2] = c.re; Vout[((size_t)item * N * N + idx) * 2 + 1] = c.im;
+    }
+    if (t == 0) { cyc[item] = total; sw[item] = sweeps; }
+}
+
+int main(int argc, char** argv) {
+    const int mode = argc > 1 ? atoi(argv[1]) : 0, B = 256, reps = 4;
+    std::vector<double> A((size_t)B * N * N * 2);
+    srand(1);
+    for (int b = 0; b < B; ++b) {
+        std::vector<double> g(N * N * 2);
+        for (auto& x : g) x = (rand() / (double)RAND_MAX) - 0.5;
+        for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
+            A[((size_t)b * N * N + i * N + j) * 2] = g[(i * N + j) * 2] + g[(j * N + i) * 2];
+            A[((size_t)b * N * N + i * N + j) * 2 + 1] = g[(i * N + j) * 2 + 1] - g[(j * N + i) * 2 + 1];
+        }
+    }
+    double *dA, *dW, *dV; long long* dc; int* ds;
+    (void)hipMalloc(&dA, A.size() * 8); (void)hipMalloc(&dW, B * N * 8); (void)hipMalloc(&dV, A.size() * 8);
+    (void)hipMalloc(&dc, B * 8); (void)hipMalloc(&ds, B * 4);
+    (void)hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+    const size_t lds = 2 * sizeof(cplx) * N * N + sizeof(double) * (64 + 3 * 32 + 8);
+    (void)hipFuncSetAttribute((const void*)k64<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k64<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 2; ++it) {
+        (void)hipEventRecord(e0);
+        if (mode == 0) hipLaunchKernelGGL(k64<0>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
+        else hipLaunchKernelGGL(k64<1>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    std::vector<long long> c(B); std::vector<int> s(B); std::vector<double> W(B * N), V(A.size());
+    (void)hipMemcpy(c.data(), dc, B * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(s.data(), ds, B * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(W.data(), dW, B * N * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(V.data(), dV, A.size() * 8, hipMemcpyDeviceToHost);
+    double csum = 0, ssum = 0; for (int b = 0; b < B; ++b) { csum += c[b]; ssum += s[b]; }
+    double res = 0, orth = 0;
+    for (int i = 0; i < N; ++i) for (int k = 0; k < N; ++k) {
+        double re = 0, im = 0, o_re = 0, o_im = 0;
+        for (int j = 0; j < N; ++j) {
+            const double ar = A[(i * N + j) * 2], ai = A[(i * N + j) * 2 + 1], vr = V[(j * N + k) * 2], vi = V[(j * N + k) * 2 + 1];
+            re += ar * vr - ai * vi; im += ar * vi + ai * vr;
+            const double ur = V[(j * N + i) * 2], ui = V[(j * N + i) * 2 + 1];
+            o_re += ur * vr + ui * vi; o_im += ur * vi - ui * vr;
+        }
+        re -= V[(i * N + k) * 2] * W[k]; im -= V[(i * N + k) * 2 + 1] * W[k];
+        res = fmax(res, sqrt(re * re + im * im));
+        if (i == k) o_re -= 1.0;
+        orth = fmax(orth, sqrt(o_re * o_re + o_im * o_im));
+    }
+    printf("mode %d: kernel %.3f ms; per eigh %.0f cycles, %.2f sweeps, %.0f cycles/round; residual %.2e, orthogonality %.2e\n",
+           mode, ms, csum / B / reps, ssum / B / reps, csum / ssum / (N - 1), res, orth);
+    return 0;
+}
