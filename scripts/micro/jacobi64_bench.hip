@@ -9,7 +9,10 @@
 #include <cmath>
 namespace fbx { void set_error(const std::string&) {} int hip_fail(hipError_t, const char*, const char*, int) { return 2; } hipStream_t stream() { return 0; } int ensure_device() { return 0; } int device_epoch() { return 0; } }
 using namespace fbx;
-constexpr int N = 64, NB = 32, LS = 1024, NT = 1024;
+#ifndef NT_VALUE
+#define NT_VALUE 1024
+#endif
+constexpr int N = 64, NB = 32, LS = 1024, NT = NT_VALUE;
 
 __device__ int jacobi_eigh_split(cplx* Ms, cplx* Vs, double* rot, double* red, int t) {
     const bool mrole = t < 512;
@@ -121,8 +124,78 @@ __device__ int jacobi_eigh_split(cplx* Ms, cplx* Vs, double* rot, double* red, i
     return sweep;
 }
 
+// Variant 2: the first 512 threads own TWO blocks each -- (I, J) and (I + 16, J) -- so one rotation
+// chain serves two blocks and both row rotations come from lanes of the same wavefront; the other 512
+// threads only take part in the barriers (in the library they would keep their registers).
+__device__ int jacobi_eigh_two(cplx* Ms, cplx* Vs, double* red, int t) {
+    const bool act = t < 512;
+    const int I0 = act ? t / NB : 0, J = act ? t % NB : 0, I1 = I0 + 16;
+    const int me0 = I0 * NB + J, me1 = I1 * NB + J, dJ = J * NB + J;
+    int wm0[4], wm1[4], wv0[4], wv1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int sb = jacobi_seat<N>(2 * J + (e & 1));
+        const int sa0 = jacobi_seat<N>(2 * I0 + (e >> 1)), sa1 = jacobi_seat<N>(2 * I1 + (e >> 1));
+        wm0[e] = ((sa0 & 1) * 2 + (sb & 1)) * LS + (sa0 >> 1) * NB + (sb >> 1);
+        wm1[e] = ((sa1 & 1) * 2 + (sb & 1)) * LS + (sa1 >> 1) * NB + (sb >> 1);
+        wv0[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I0 * NB + (sb >> 1);
+        wv1[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I1 * NB + (sb >> 1);
+    }
+    const int lane = t & 63, src0 = lane - J + I0, src1 = lane - J + I1;      // lanes (row, J = I0) and (row, J = I1)
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cplx c; c.im = 0.0;
+            c.re = (2 * I0 + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; Vs[e * LS + me0] = c;
+            c.re = (2 * I1 + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; Vs[e * LS + me1] = c;
+        }
+    }
+    __syncthreads();
+    int sweep = 0;
+    for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
+        {
+            double o2 = 0.0, n2 = 0.0;
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const cplx a = Ms[e * LS + me0], b = Ms[e * LS + me1];
+                    const double a2 = a.re * a.re + a.im * a.im, b2 = b.re * b.re + b.im * b.im;
+                    n2 += a2 + b2;
+                    if (!(I0 == J && (e == 0 || e == 3))) o2 += a2;
+                    if (!(I1 == J && (e == 0 || e == 3))) o2 += b2;
+                }
+            }
+            block_sum2<NT>(o2, n2, red);
+            if (!(uniform(o2) > FBX_JACOBI_TOL2 * uniform(n2))) break;
+        }
+        for (int r = 0; r < N - 1; ++r) {
+            const double aJ = Ms[0 * LS + dJ].re, dJ_ = Ms[3 * LS + dJ].re;
+            const cplx bJ = Ms[1 * LS + dJ];
+            cplx m0[4], m1[4], v0[4], v1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { m0[e] = Ms[e * LS + me0]; m1[e] = Ms[e * LS + me1]; v0[e] = Vs[e * LS + me0]; v1[e] = Vs[e * LS + me1]; }
+            __syncthreads();
+            const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
+            const double c0 = __shfl(rJ.c, src0), s0r = __shfl(rJ.sr, src0), s0i = __shfl(rJ.si, src0);
+            const double c1 = __shfl(rJ.c, src1), s1r = __shfl(rJ.sr, src1), s1i = __shfl(rJ.si, src1);
+            jacobi_apply_m(c0, s0r, s0i, rJ.c, rJ.sr, rJ.si, m0[0], m0[1], m0[2], m0[3]);
+            jacobi_apply_m(c1, s1r, s1i, rJ.c, rJ.sr, rJ.si, m1[0], m1[1], m1[2], m1[3]);
+            jacobi_apply_v(rJ.c, rJ.sr, rJ.si, v0[0], v0[1], v0[2], v0[3]);
+            jacobi_apply_v(rJ.c, rJ.sr, rJ.si, v1[0], v1[1], v1[2], v1[3]);
+            if (I0 == J) { m0[1].re = m0[1].im = 0.0; m0[2].re = m0[2].im = 0.0; m0[0].im = 0.0; m0[3].im = 0.0; }
+            if (I1 == J) { m1[1].re = m1[1].im = 0.0; m1[2].re = m1[2].im = 0.0; m1[0].im = 0.0; m1[3].im = 0.0; }
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Ms[wm0[e]] = m0[e]; Ms[wm1[e]] = m1[e]; Vs[wv0[e]] = v0[e]; Vs[wv1[e]] = v1[e]; }
+            }
+            __syncthreads();
+        }
+    }
+    return sweep;
+}
+
 template <int MODE>
-__global__ void __launch_bounds__(1024) k64(const double* A, double* W, double* Vout, long long* cyc, int* sw, int reps) {
+__global__ void __launch_bounds__(NT) k64(const double* A, double* W, double* Vout, long long* cyc, int* sw, int reps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* Ms = (cplx*)smem; cplx* Vs = Ms + N * N;
     double* red = (double*)(Vs + N * N); double* rot = red + 64;
@@ -135,8 +208,9 @@ __global__ void __launch_bounds__(1024) k64(const double* A, double* W, double* 
         }
         __syncthreads();
         long long t0 = __builtin_readcyclecounter();
-        if (MODE == 0) sweeps += jacobi_eigh_simple<N, NT>(Ms, Vs, t, true, red);
-        else sweeps += jacobi_eigh_split(Ms, Vs, rot, red, t);
+        if constexpr (MODE == 0 && NT >= 1024) sweeps += jacobi_eigh_simple<N, (NT >= 1024 ? NT : 1024)>(Ms, Vs, t, true, red);
+        else if constexpr (MODE == 1) sweeps += jacobi_eigh_split(Ms, Vs, rot, red, t);
+        else sweeps += jacobi_eigh_two(Ms, Vs, red, t);
         total += __builtin_readcyclecounter() - t0;
         __syncthreads();
     }
@@ -167,12 +241,14 @@ int main(int argc, char** argv) {
     const size_t lds = 2 * sizeof(cplx) * N * N + sizeof(double) * (64 + 3 * 32 + 8);
     (void)hipFuncSetAttribute((const void*)k64<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k64<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k64<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float ms = 0;
     for (int it = 0; it < 2; ++it) {
         (void)hipEventRecord(e0);
         if (mode == 0) hipLaunchKernelGGL(k64<0>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
-        else hipLaunchKernelGGL(k64<1>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
+        else if (mode == 1) hipLaunchKernelGGL(k64<1>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
+        else hipLaunchKernelGGL(k64<2>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
     }
