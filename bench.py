@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--in-basis", default="pauli")
     ap.add_argument("--cpu-sample", type=int, default=12,
                     help="items timed on the host for cpu_baseline (0 = skip)")
-    ap.add_argument("--workload", default="pgdb", choices=["pgdb", "sweep"],
+    ap.add_argument("--workload", default="pgdb", choices=["pgdb", "sweep", "pgdb3"],
                     help="pgdb = the headline metric (BASELINE configs[1]); sweep = the secondary "
-                         "HBM-bound conversion sweep of BASELINE configs[2] (1e6 Kraus sets)")
+                         "HBM-bound conversion sweep of BASELINE configs[2] (1e6 Kraus sets); pgdb3 = BASELINE "
+                         "configs[3], 256 three-qubit process tomographies")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
     return ap.parse_args()
 
@@ -205,6 +206,74 @@ def run_sweep(args, rank, world, dist, torch):
         print(json.dumps(line), flush=True)
 
 
+def run_pgdb3(args, rank, world, dist, torch):
+    """Third line: BASELINE configs[3] -- 3-qubit (64 x 64 Choi) PGDB process tomography, batch 256 per
+    GPU, SIC in-basis (4032 settings) unless --in-basis pauli (13 608), 100 fixed iterations."""
+    import ctypes
+    from fbx import _lib, synthetic
+    B = 256
+    basis = args.in_basis if args.in_basis in ("sic", "pauli") else "sic"
+    design, _, e, c = synthetic.process_batch(3, basis, 32)
+    e = np.tile(e, (B // 32, 1)); c = np.tile(c, (B // 32, 1))
+    lib = _lib.lib()
+    d_e, d_c = _lib.DeviceBuffer.from_array(e), _lib.DeviceBuffer.from_array(c)
+    d_choi = _lib.DeviceBuffer(B * 64 * 64 * 16); d_it = _lib.DeviceBuffer(B * 4); d_dy = _lib.DeviceBuffer(B * 4)
+
+    def step():
+        _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, _lib.MODE_FIXED, args.iters,
+                                            d_choi.ptr, d_it.ptr, d_dy.ptr, None, None))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        _lib.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ms = ctypes.c_double(0.0)
+    t0 = time.perf_counter()
+    _lib.check(lib.fbx_timer_begin())
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.fbx_timer_end(ctypes.byref(ms)))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed, ms.value], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kms = t.tolist()
+    else:
+        kms = ms.value
+    if rank == 0:
+        dyk = d_dy.to_array(np.int32, (B,))
+        ksec = kms / 1e3 / args.steps
+        # algorithmic flops in the reference's dense formulation (SURVEY 8d recipe at n = 3): per outer
+        # iteration 3 R D^2 complex MACs (gradient 2, cost 1; R = 2 m rows, D^2 = 4096) + per Dykstra
+        # iteration one 64 x 64 Hermitian eigendecomposition (~25 N^3 = 6.6 MFLOP) + V L V^H (2 N^3 cmac)
+        m = design.m
+        flop = args.iters * 3 * (2 * m) * 4096 * 8 + float(dyk.mean()) * (25 * 64 ** 3 + 2 * 64 ** 3 * 8)
+        tflops = B * flop / ksec / 1e12
+        line = {"metric": "process-tomography MLE reconstructions/sec (3-qubit, 64x64 Choi, 100 iters)",
+                "value": world * B * args.steps / elapsed, "unit": "reconstructions/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"{B} independent 3-qubit process tomographies per GPU, {basis} in-basis "
+                                       f"({m} settings, 1000 shots), {args.iters} fixed PGDB iterations, inputs "
+                                       f"resident in HBM", "batch_per_gpu": B, "iters": args.iters,
+                           "parallelism": f"shard{world}", "mean_dykstra_iters": float(dyk.mean())},
+                "roofline": {"bound": "mfma", "pipe": "fp64 VALU + LDS", "achieved": tflops, "peak": FP64_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
+                             "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
+                             "note": "achieved = algorithmic flops of the dense formulation (3 x 2m x 4096 complex "
+                                     "MACs per outer iteration + ~25 N^3 per 64 x 64 eigendecomposition) / HIP-event "
+                                     "kernel time; the kernel is co-limited by LDS bandwidth and fp64 issue in "
+                                     "the eigensolver (DESIGN.md 2.2)"}}
+        print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -226,6 +295,12 @@ def main():
     from fbx import _lib, synthetic
     _lib.set_device(local_rank)                       # fails loudly without a GPU
     dev_name, cus = _lib.device_name()
+    if args.workload == "pgdb3":
+        run_pgdb3(args, rank, world, dist, torch)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "sweep":
         run_sweep(args, rank, world, dist, torch)
         if dist is not None:

@@ -39,3 +39,10 @@ if st: open(os.path.join(dst, "sweep_kernel_stats.csv"), "w").write(open(st[0]).
 print(json.dumps(res, indent=1)); print(open(os.path.join(dst, "sweep_kernel_stats.csv")).read() if st else "")
 PY
 grep -h '"metric"' "$OUT/bench_sweep_trace.log" "$OUT/bench_trace.log"
+# third workload: 3-qubit PGDB (BASELINE configs[3])
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pgdb3" -o trace -- python "$REPO/bench.py" --workload pgdb3 --in-basis sic --steps 3 --warmup 1 > "$OUT/bench_pgdb3_trace.log" 2>&1
+cd "$REPO"
+ST3=$(find "$OUT/trace_pgdb3" -name "*kernel_stats.csv" | head -1)
+[ -n "$ST3" ] && cp "$ST3" "gpurun_out/profile_$TAG/pgdb3_kernel_stats.csv" && cat "$ST3"
+grep -h '"metric"' "$OUT/bench_pgdb3_trace.log" | cut -c1-300
