@@ -47,7 +47,8 @@ def parse():
                     help="weak scaling with a different block of synthetic experiments on every rank "
                          "(default: every rank runs the N = 1 workload)")
     ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--in-basis", default="pauli")
+    ap.add_argument("--in-basis", default=None, choices=["pauli", "sic"],
+                    help="input-state basis of the process design (default: pauli for pgdb, sic for pgdb3)")
     ap.add_argument("--cpu-sample", type=int, default=12,
                     help="items timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--workload", default="pgdb", choices=["pgdb", "sweep", "pgdb3"],
@@ -212,7 +213,7 @@ def run_pgdb3(args, rank, world, dist, torch):
     import ctypes
     from fbx import _lib, synthetic
     B = 256
-    basis = args.in_basis if args.in_basis in ("sic", "pauli") else "sic"
+    basis = args.in_basis or "sic"
     design, _, e, c = synthetic.process_batch(3, basis, 32)
     e = np.tile(e, (B // 32, 1)); c = np.tile(c, (B // 32, 1))
     lib = _lib.lib()
@@ -276,6 +277,8 @@ def run_pgdb3(args, rank, world, dist, torch):
 
 def main():
     args = parse()
+    if args.workload == "pgdb" and args.in_basis is None:
+        args.in_basis = "pauli"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
