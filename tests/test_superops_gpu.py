@@ -147,3 +147,40 @@ def test_fused_sweep_odd_batches_and_kraus_counts(gpu, B, K):
     assert np.abs(ptm - convert_batch("kraus", "pauli_liouville", ks)).max() < 1e-13
     assert np.abs(chi - convert_batch("kraus", "chi", ks)).max() < 1e-13
     assert np.abs(fid - dm.process_fidelity_batch(ref, ptm)).max() < 1e-13
+
+
+def test_full_size_sweep_properties(gpu):
+    """BASELINE config 3 size (1e6 two-qubit Kraus sets, K = 4), device-resident: size-independent checks --
+    tiled inputs give bit-identical outputs, a sample of items matches the pairwise conversions, every
+    Choi matrix has trace d (trace preservation of the CPTP inputs), chi has trace 1, PTM[0][0] = 1, and
+    the process fidelities lie in [1/(d+1), 1]."""
+    import ctypes
+    from fbx import _lib, synthetic
+    from fbx.operator_tools import convert_batch
+    n, K, D, B, T = 2, 4, 16, 1_000_000, 4096
+    base = synthetic.kraus_batch(n, K, T, seed=3)
+    ks = np.ascontiguousarray(np.tile(base, (B // T + 1, 1, 1, 1))[:B])
+    ref = convert_batch("kraus", "pauli_liouville", synthetic.kraus_batch(n, 1, 1, seed=4))
+    lib = _lib.lib()
+    d_k = _lib.DeviceBuffer.from_array(ks); d_r = _lib.DeviceBuffer.from_array(np.ascontiguousarray(ref[0]))
+    d_c, d_p, d_x = (_lib.DeviceBuffer(B * D * D * 16) for _ in range(3))
+    d_f = _lib.DeviceBuffer(B * 8)
+    _lib.check(lib.fbx_kraus_sweep_dev(n, B, K, d_k.ptr, d_r.ptr, d_c.ptr, d_p.ptr, d_x.ptr, d_f.ptr))
+    _lib.synchronize()
+    fid = d_f.to_array(np.float64, (B,))
+    assert fid.min() >= 1 / 5 - 1e-12 and fid.max() <= 1 + 1e-12
+    assert np.array_equal(fid[:T], fid[T:2 * T]) and np.array_equal(fid[:B % T], fid[B - B % T:])
+    for buf, name in ((d_c, "choi"), (d_p, "pauli_liouville"), (d_x, "chi")):
+        out = buf.to_array(np.complex128, (B, D, D))
+        assert np.array_equal(out[:T], out[-(B % T) - T:-(B % T)]) , name            # last full tile == first tile
+        sample = np.r_[0, 1, 4095, 4096, 123457, B - 2, B - 1]
+        want = convert_batch("kraus", name, ks[sample])
+        assert np.abs(out[sample] - want).max() < 1e-13, name
+        tr = np.trace(out[::997], axis1=1, axis2=2)
+        if name == "choi":
+            assert np.abs(tr - 4).max() < 1e-12
+        elif name == "chi":
+            assert np.abs(tr - 1).max() < 1e-12
+        else:
+            assert np.abs(out[::997, 0, 0] - 1).max() < 1e-12
+        del out
