@@ -204,3 +204,19 @@ def test_device_log_is_accurate_to_an_ulp(gpu):
     ulp = np.spacing(np.abs(want)) + 1e-300
     assert np.max(np.abs(out - want) / np.maximum(ulp, 2.3e-16 * np.abs(x - 1))) <= 1.5
     assert out[-5] == 0.0
+
+
+def test_config5_shard_size_properties(gpu):
+    """BASELINE config 5 per-GPU share (8192 two-qubit tomographies): Hermitian and trace preserving
+    to rounding, 100 iterations everywhere, the eight tiles of 1024 distinct items bit-identical."""
+    from fbx import synthetic, tomography
+    design, us, e, c = synthetic.process_batch(2, "pauli", 1024)
+    e8 = np.tile(e, (8, 1)); c8 = np.tile(c, (8, 1))
+    got, st = tomography.pgdb_process_estimate_batch(design, e8, c8, mode="fixed", max_iters=100, return_stats=True)
+    assert (st["iterations"] == 100).all()
+    assert np.abs(got - got.conj().transpose(0, 2, 1)).max() < 1e-12
+    pt = np.einsum("biojo->bij", got.reshape(-1, 4, 4, 4, 4))
+    assert np.abs(pt - np.eye(4)).max() < 1e-12
+    for k in range(1, 8):
+        assert np.array_equal(got[:1024], got[1024 * k:1024 * (k + 1)])
+        assert np.array_equal(st["dykstra"][:1024], st["dykstra"][1024 * k:1024 * (k + 1)])
