@@ -12,6 +12,7 @@
 //   sqrtm_psd                        operator_tools/calculational.py:77-91
 #include "fbx_eigh.hpp"
 #include <cfloat>
+#include <cstdlib>
 
 namespace fbx {
 
@@ -269,6 +270,92 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
     }
     if (act) { rho_out[(item * D + lane) * 2] = rho.re; rho_out[(item * D + lane) * 2 + 1] = rho.im; }
     if (lane == 0) { if (iters_out) iters_out[item] = iteration; if (hit_out) hit_out[item] = hit; }
+}
+
+// ---- plain diluted MLE (no entropy penalty, no hedging) for 1 and 2 qubits with SEVERAL items per
+// wavefront: a d x d state needs d^2 = 4 / 16 lanes, so 16 / 4 reconstructions share a wave, each in
+// its own group of D consecutive lanes with its own slice of LDS.  Needs m <= D settings (every
+// state-tomography design of the reference has 4^n - 1); groups that have converged idle until the
+// last one of the wave has.  Same arithmetic per item as mle_state_kernel.
+template <int D>
+__device__ __forceinline__ double group_sum(double v) {          // sum over the D lanes of a group, in every lane
+    v += dpp_permute<0xB1>(v);                                   // quad_perm [1,0,3,2]
+    v += dpp_permute<0x4E>(v);                                   // quad_perm [2,3,0,1]
+    if constexpr (D == 16) { v += dpp_permute<0x141>(v); v += dpp_permute<0x140>(v); }
+    return v;
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(64)
+mle_state_packed_kernel(DesignDev des, long long B, const double* __restrict__ expect, double epsilon, double tol,
+                        int maxiter, double* __restrict__ rho_out, int* __restrict__ iters_out, int* __restrict__ hit_out) {
+    constexpr int d = 1 << NQ, D = d * d, G = 64 / D;
+    static_assert(D == 4 || D == 16, "one or two qubits");
+    __shared__ cplx s_rho[G * D], s_U[G * D], s_tmp[G * D];
+    __shared__ double s_r[G * D], s_w[G * D];
+    const int lane = threadIdx.x, sub = lane / D, t = lane % D;
+    const int row = t / d, col = t % d;
+    const long long item = (long long)blockIdx.x * G + sub;
+    const bool valid = item < B;
+    const int m = des.m;
+    cplx* rho_l = s_rho + sub * D; cplx* U_l = s_U + sub * D; cplx* tmp_l = s_tmp + sub * D;
+    double* r_l = s_r + sub * D; double* w_l = s_w + sub * D;
+    // this lane's setting (t < m <= D)
+    const bool has = valid && t < m;
+    int sp = 0; double cf = 1.0, me = 0.0;
+    if (has) { sp = des.sp[t] & 0xffff; cf = des.unit_coefs ? 1.0 : des.coef[t]; me = expect[item * m + des.order[t]]; }
+    cplx rho; rho.re = (row == col) ? 1.0 / d : 0.0; rho.im = 0.0;
+    rho_l[t] = rho;
+    FBX_WAVE_SYNC();
+    int iteration = 1, hit = 0;
+    bool running = valid;
+    while (__ballot(running)) {
+        if (running && iteration >= maxiter) { hit = 1; running = false; }     // tomography.py:244-246
+        if (!__ballot(running)) break;
+        // ---- R(rho)  (tomography.py:273-338)
+        pauli_expectations<NQ>(rho_l, r_l, t);
+        w_l[t] = 0.0;
+        FBX_WAVE_SYNC();
+        double s0 = 0.0;
+        if (has) {
+            const double pe = cf * r_l[sp];
+            const double gp = ((1.0 + me) * 0.5) / ((1.0 + pe) * 0.5 + DBL_MIN);
+            const double gm = ((1.0 - me) * 0.5) / ((1.0 - pe) * 0.5 + DBL_MIN);
+            s0 = 0.5 * (gp + gm);
+            atomicAdd(&w_l[sp], cf * 0.5 * (gp - gm));
+        }
+        s0 = group_sum<D>(s0);
+        FBX_WAVE_SYNC();
+        w_l[t] = w_l[t] / m;
+        FBX_WAVE_SYNC();
+        cplx T = pauli_synthesis<NQ>(w_l, s0 / m + 0.0, row, col);
+        if (row == col) T.re -= 1.0;                                           // Tk = R - I
+        cplx Um; Um.re = epsilon * T.re + ((row == col) ? 1.0 : 0.0); Um.im = epsilon * T.im;
+        FBX_WAVE_SYNC();
+        U_l[t] = Um;
+        FBX_WAVE_SYNC();
+        const cplx t1 = matmul_elem<NQ>(rho_l, U_l, t);                         // rho U
+        tmp_l[t] = t1;
+        FBX_WAVE_SYNC();
+        cplx nr = matmul_elem<NQ>(U_l, tmp_l, t);                               // U rho U
+        const double tr_re = group_sum<D>((row == col) ? nr.re : 0.0), tr_im = group_sum<D>((row == col) ? nr.im : 0.0);
+        {
+            const double den = tr_re * tr_re + tr_im * tr_im;
+            const double qr = (nr.re * tr_re + nr.im * tr_im) / den, qi = (nr.im * tr_re - nr.re * tr_im) / den;
+            nr.re = qr; nr.im = qi;
+        }
+        const double diff = group_sum<D>((nr.re - rho.re) * (nr.re - rho.re) + (nr.im - rho.im) * (nr.im - rho.im));
+        FBX_WAVE_SYNC();
+        if (running) { rho = nr; rho_l[t] = rho; }
+        FBX_WAVE_SYNC();
+        if (running) {
+            if (sqrt(diff) < tol) running = false; else ++iteration;
+        }
+    }
+    if (valid) {
+        rho_out[(item * D + t) * 2] = rho.re; rho_out[(item * D + t) * 2 + 1] = rho.im;
+        if (t == 0) { if (iters_out) iters_out[item] = iteration; if (hit_out) hit_out[item] = hit; }
+    }
 }
 
 template <int NQ>
@@ -595,8 +682,16 @@ int fbx_mle_state(const fbx_design* design, int64_t B, const double* expect, con
     HostIO io; double *de, *dc, *dr; int32_t *di, *dh;
     FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.in(counts, m * B, &dc));
     FBX_TRY(io.out(D * 2 * B, &dr)); FBX_TRY(io.out((size_t)B, &di)); FBX_TRY(io.out((size_t)B, &dh));
-    FBX_DISPATCH_NQ(n, mle_state_kernel, lds, B, design->dev, (long long)B, de, dc, epsilon, entropy_penalty, beta, tol,
-                    maxiter, dr, di, dh);
+    const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !getenv("FBX_MLE_UNPACKED");
+    if (packed && n == 1)
+        hipLaunchKernelGGL(mle_state_packed_kernel<1>, dim3((unsigned)((B + 15) / 16)), dim3(64), 0, stream(), design->dev,
+                           (long long)B, de, epsilon, tol, maxiter, dr, di, dh);
+    else if (packed)
+        hipLaunchKernelGGL(mle_state_packed_kernel<2>, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, stream(), design->dev,
+                           (long long)B, de, epsilon, tol, maxiter, dr, di, dh);
+    else
+        FBX_DISPATCH_NQ(n, mle_state_kernel, lds, B, design->dev, (long long)B, de, dc, epsilon, entropy_penalty, beta, tol,
+                        maxiter, dr, di, dh);
     FBX_HIP(hipGetLastError());
     FBX_TRY(io.back(rho_out, dr, D * 2 * B)); FBX_TRY(io.back(iters_out, di, (size_t)B));
     FBX_TRY(io.back(hit_max_out, dh, (size_t)B));
