@@ -3,7 +3,9 @@
 // One 64-lane wavefront owns one reconstruction for its whole life: the Choi estimate and
 // the Dykstra state live in registers (one 2x2 block per lane), work matrices and the
 // predicted-expectation tables in LDS; HBM is read once (expectations + counts) and written
-// once (Choi + counters).
+// once (Choi + counters) -- plus the per-item store of Dykstra eigenvector bases (BasisStore,
+// fbx_choi.hpp), working state in HBM/L2 that lets an outer iteration start its decompositions
+// from the bases the previous one found.
 //
 // Replaces, for a batch that shares one design (file:line under forest/benchmarking/):
 //   pgdb_process_estimate   tomography.py:542-594
