@@ -84,6 +84,54 @@ __device__ void from_pauli_basis(const cplx* in, cplx* out, double scale, int la
     }
 }
 
+// Two-qubit fast forms of the two transforms above: P2C factors over the qubit sites, so the change of
+// basis is four in-place butterfly stages (one quad per lane) and a bit-permuting copy instead of a
+// 16-term sum per entry.  Element index = row * 16 + col with row = (a1 a0 b1 b0) = vec index c*d + r;
+// the stages pair (a bit, b bit) of the row (conj, -i) and of the column (+i); entry [k][l] of the Pauli
+// side sits at row (k3 k1 k2 k0), column (l3 l1 l2 l0).  `in` is destroyed.  Single wavefront only.
+__device__ __forceinline__ int pauli_swap12(int v) { return (v & 9) | ((v & 2) << 1) | ((v & 4) >> 1); }
+__device__ void to_pauli_basis_2q(cplx* in, cplx* out, double scale, int lane) {
+    constexpr int D = 16, LD = 17;
+    pauli_site_stage<2, false, LD>(in, lane, 7, 5, -1.0); FBX_WAVE_SYNC();
+    pauli_site_stage<2, false, LD>(in, lane, 6, 4, -1.0); FBX_WAVE_SYNC();
+    pauli_site_stage<2, false, LD>(in, lane, 3, 1, +1.0); FBX_WAVE_SYNC();
+    pauli_site_stage<2, false, LD>(in, lane, 2, 0, +1.0); FBX_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = lane + 64 * r, k = idx >> 4, l = idx & 15;
+        cplx v = in[pauli_swap12(k) * LD + pauli_swap12(l)];
+        v.re *= scale; v.im *= scale;
+        out[k * LD + l] = v;
+    }
+}
+// P2C x P2C^H = d^2 * (inverse of the forward stages)
+__device__ void from_pauli_basis_2q(const cplx* in, cplx* out, double scale, int lane) {
+    constexpr int D = 16, LD = 17;
+    const double s = scale * D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = lane + 64 * r, k = idx >> 4, l = idx & 15;
+        cplx v = in[k * LD + l];
+        v.re *= s; v.im *= s;
+        out[pauli_swap12(k) * LD + pauli_swap12(l)] = v;
+    }
+    FBX_WAVE_SYNC();
+    pauli_site_stage<2, true, LD>(out, lane, 7, 5, -1.0); FBX_WAVE_SYNC();
+    pauli_site_stage<2, true, LD>(out, lane, 6, 4, -1.0); FBX_WAVE_SYNC();
+    pauli_site_stage<2, true, LD>(out, lane, 3, 1, +1.0); FBX_WAVE_SYNC();
+    pauli_site_stage<2, true, LD>(out, lane, 2, 0, +1.0); FBX_WAVE_SYNC();
+}
+template <int NQ>
+__device__ __forceinline__ void to_pauli_wave(cplx* in, cplx* out, double scale, int lane) {
+    if constexpr (NQ == 2) to_pauli_basis_2q(in, out, scale, lane);
+    else to_pauli_basis<NQ>(in, out, scale, lane);
+}
+template <int NQ>
+__device__ __forceinline__ void from_pauli_wave(cplx* in, cplx* out, double scale, int lane) {
+    if constexpr (NQ == 2) from_pauli_basis_2q(in, out, scale, lane);
+    else from_pauli_basis<NQ>(in, out, scale, lane);
+}
+
 // choi <-> superop reshuffle (superoperator_transformations.py:267-277,351-361):
 // out[(p,q)][(r,s)] = in[(s,q)][(r,p)]
 template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
@@ -208,24 +256,24 @@ convert_kernel(int from, int to, long long B, const double* __restrict__ in, int
     const bool kraus_chi = (from == FBX_REP_KRAUS && to == FBX_REP_CHI);
     while (rep != to) {
         if (rep == FBX_REP_CHI) {                       // chi2choi: p2c chi p2c^H
-            from_pauli_basis<NQ>(cur, nxt, 1.0, lane); swap(); rep = FBX_REP_CHOI;
+            from_pauli_wave<NQ>(cur, nxt, 1.0, lane); swap(); rep = FBX_REP_CHOI;
         } else if (rep == FBX_REP_CHOI) {
             if (to == FBX_REP_CHI) {
                 if (!kraus_chi) {                       // through choi2kraus (eigh, |C|, tol 1e-9)
                     abs_via_eigh<NQ>(cur, nxt, L, 1e-9, lane); swap();
                 }
-                to_pauli_basis<NQ>(cur, nxt, inv_d * inv_d, lane); swap(); rep = FBX_REP_CHI;
+                to_pauli_wave<NQ>(cur, nxt, inv_d * inv_d, lane); swap(); rep = FBX_REP_CHI;
             } else {
                 reshuffle<NQ>(cur, nxt, lane); swap(); rep = FBX_REP_SUPEROP;
             }
         } else if (rep == FBX_REP_SUPEROP) {
             if (to == FBX_REP_PAULI_LIOUVILLE) {
-                to_pauli_basis<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
+                to_pauli_wave<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
             } else {
                 reshuffle<NQ>(cur, nxt, lane); swap(); rep = FBX_REP_CHOI;
             }
         } else {                                        // pauli-liouville -> superop
-            from_pauli_basis<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_SUPEROP;
+            from_pauli_wave<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_SUPEROP;
         }
     }
     store_matrix<NQ>(cur, out + item * (long long)D * D * 2, lane);
