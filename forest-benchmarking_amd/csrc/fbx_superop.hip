@@ -84,52 +84,53 @@ __device__ void from_pauli_basis(const cplx* in, cplx* out, double scale, int la
     }
 }
 
-// Two-qubit fast forms of the two transforms above: P2C factors over the qubit sites, so the change of
-// basis is four in-place butterfly stages (one quad per lane) and a bit-permuting copy instead of a
-// 16-term sum per entry.  Element index = row * 16 + col with row = (a1 a0 b1 b0) = vec index c*d + r;
-// the stages pair (a bit, b bit) of the row (conj, -i) and of the column (+i); entry [k][l] of the Pauli
-// side sits at row (k3 k1 k2 k0), column (l3 l1 l2 l0).  `in` is destroyed.  Single wavefront only.
-__device__ __forceinline__ int pauli_swap12(int v) { return (v & 9) | ((v & 2) << 1) | ((v & 4) >> 1); }
-__device__ void to_pauli_basis_2q(cplx* in, cplx* out, double scale, int lane) {
-    constexpr int D = 16, LD = 17;
-    pauli_site_stage<2, false, LD>(in, lane, 7, 5, -1.0); FBX_WAVE_SYNC();
-    pauli_site_stage<2, false, LD>(in, lane, 6, 4, -1.0); FBX_WAVE_SYNC();
-    pauli_site_stage<2, false, LD>(in, lane, 3, 1, +1.0); FBX_WAVE_SYNC();
-    pauli_site_stage<2, false, LD>(in, lane, 2, 0, +1.0); FBX_WAVE_SYNC();
+// Site-factored forms of the two transforms above: P2C factors over the qubits, so the change of basis
+// is 2n in-place butterfly stages (one quad per thread and stage) and a bit-permuting copy instead of a
+// D-term sum per entry.  Element index = row * D + col with row = (a_{n-1}..a_0 b_{n-1}..b_0) = vec
+// index c*d + r; the stages pair (a_t, b_t) of the row (conj: -i) and of the column (+i); Pauli digit
+// 2 a_t + b_t of label k is I, X, Y, Z, so entry [k][l] of the Pauli side sits at row site_index(k),
+// column site_index(l).  The forward form destroys `in`.  NT threads, NT >= D*D/4 or a multiple loop.
+template <int NQ>
+__device__ __forceinline__ int site_index(int k) {
+    int r = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int idx = lane + 64 * r, k = idx >> 4, l = idx & 15;
-        cplx v = in[pauli_swap12(k) * LD + pauli_swap12(l)];
+    for (int t = 0; t < NQ; ++t) r |= (((k >> (2 * t + 1)) & 1) << (NQ + t)) | (((k >> (2 * t)) & 1) << t);
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ void sites_sync() { if constexpr (NT <= 64) FBX_WAVE_SYNC(); else __syncthreads(); }
+template <int NQ, bool INVERSE, int NT, int LD>
+__device__ __forceinline__ void site_stages(cplx* M, int t) {
+    static_assert(NT >= (1 << (4 * NQ)) / 4, "one quad per thread");
+#pragma unroll
+    for (int q = NQ - 1; q >= 0; --q) { pauli_site_stage<NQ, INVERSE, LD>(M, t, 3 * NQ + q, 2 * NQ + q, -1.0); sites_sync<NT>(); }
+#pragma unroll
+    for (int q = NQ - 1; q >= 0; --q) { pauli_site_stage<NQ, INVERSE, LD>(M, t, NQ + q, q, +1.0); sites_sync<NT>(); }
+}
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
+__device__ void to_pauli_sites(cplx* in, cplx* out, double scale, int t) {
+    constexpr int D = 1 << (2 * NQ);
+    site_stages<NQ, false, NT, LD>(in, t);
+    for (int idx = t; idx < D * D; idx += NT) {
+        const int k = idx / D, l = idx % D;
+        cplx v = in[site_index<NQ>(k) * LD + site_index<NQ>(l)];
         v.re *= scale; v.im *= scale;
         out[k * LD + l] = v;
     }
 }
-// P2C x P2C^H = d^2 * (inverse of the forward stages)
-__device__ void from_pauli_basis_2q(const cplx* in, cplx* out, double scale, int lane) {
-    constexpr int D = 16, LD = 17;
+// P2C x P2C^H = D * (inverse of the forward stages)
+template <int NQ, int NT = 64, int LD = (1 << (2 * NQ)) + 1>
+__device__ void from_pauli_sites(const cplx* in, cplx* out, double scale, int t) {
+    constexpr int D = 1 << (2 * NQ);
     const double s = scale * D;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int idx = lane + 64 * r, k = idx >> 4, l = idx & 15;
+    for (int idx = t; idx < D * D; idx += NT) {
+        const int k = idx / D, l = idx % D;
         cplx v = in[k * LD + l];
         v.re *= s; v.im *= s;
-        out[pauli_swap12(k) * LD + pauli_swap12(l)] = v;
+        out[site_index<NQ>(k) * LD + site_index<NQ>(l)] = v;
     }
-    FBX_WAVE_SYNC();
-    pauli_site_stage<2, true, LD>(out, lane, 7, 5, -1.0); FBX_WAVE_SYNC();
-    pauli_site_stage<2, true, LD>(out, lane, 6, 4, -1.0); FBX_WAVE_SYNC();
-    pauli_site_stage<2, true, LD>(out, lane, 3, 1, +1.0); FBX_WAVE_SYNC();
-    pauli_site_stage<2, true, LD>(out, lane, 2, 0, +1.0); FBX_WAVE_SYNC();
-}
-template <int NQ>
-__device__ __forceinline__ void to_pauli_wave(cplx* in, cplx* out, double scale, int lane) {
-    if constexpr (NQ == 2) to_pauli_basis_2q(in, out, scale, lane);
-    else to_pauli_basis<NQ>(in, out, scale, lane);
-}
-template <int NQ>
-__device__ __forceinline__ void from_pauli_wave(cplx* in, cplx* out, double scale, int lane) {
-    if constexpr (NQ == 2) from_pauli_basis_2q(in, out, scale, lane);
-    else from_pauli_basis<NQ>(in, out, scale, lane);
+    sites_sync<NT>();
+    site_stages<NQ, true, NT, LD>(out, t);
 }
 
 // choi <-> superop reshuffle (superoperator_transformations.py:267-277,351-361):
@@ -256,24 +257,24 @@ convert_kernel(int from, int to, long long B, const double* __restrict__ in, int
     const bool kraus_chi = (from == FBX_REP_KRAUS && to == FBX_REP_CHI);
     while (rep != to) {
         if (rep == FBX_REP_CHI) {                       // chi2choi: p2c chi p2c^H
-            from_pauli_wave<NQ>(cur, nxt, 1.0, lane); swap(); rep = FBX_REP_CHOI;
+            from_pauli_sites<NQ>(cur, nxt, 1.0, lane); swap(); rep = FBX_REP_CHOI;
         } else if (rep == FBX_REP_CHOI) {
             if (to == FBX_REP_CHI) {
                 if (!kraus_chi) {                       // through choi2kraus (eigh, |C|, tol 1e-9)
                     abs_via_eigh<NQ>(cur, nxt, L, 1e-9, lane); swap();
                 }
-                to_pauli_wave<NQ>(cur, nxt, inv_d * inv_d, lane); swap(); rep = FBX_REP_CHI;
+                to_pauli_sites<NQ>(cur, nxt, inv_d * inv_d, lane); swap(); rep = FBX_REP_CHI;
             } else {
                 reshuffle<NQ>(cur, nxt, lane); swap(); rep = FBX_REP_SUPEROP;
             }
         } else if (rep == FBX_REP_SUPEROP) {
             if (to == FBX_REP_PAULI_LIOUVILLE) {
-                to_pauli_wave<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
+                to_pauli_sites<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
             } else {
                 reshuffle<NQ>(cur, nxt, lane); swap(); rep = FBX_REP_CHOI;
             }
         } else {                                        // pauli-liouville -> superop
-            from_pauli_wave<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_SUPEROP;
+            from_pauli_sites<NQ>(cur, nxt, inv_d, lane); swap(); rep = FBX_REP_SUPEROP;
         }
     }
     store_matrix<NQ>(cur, out + item * (long long)D * D * 2, lane);
@@ -322,7 +323,7 @@ convert3_kernel(int from, int to, long long B, const double* __restrict__ in, in
     const bool kraus_chi = (from == FBX_REP_KRAUS && to == FBX_REP_CHI);
     while (rep != to) {
         if (rep == FBX_REP_CHI) {
-            from_pauli_basis<NQ, NT, LD>(cur, nxt, 1.0, t); swap(); rep = FBX_REP_CHOI;
+            from_pauli_sites<NQ, NT, LD>(cur, nxt, 1.0, t); swap(); rep = FBX_REP_CHOI;
         } else if (rep == FBX_REP_CHOI) {
             if (to == FBX_REP_CHI) {
                 if (!kraus_chi) {       // |C| = sum |lambda| v v^H, as choi2kraus -> kraus2chi (tol 1e-9)
@@ -349,18 +350,18 @@ convert3_kernel(int from, int to, long long B, const double* __restrict__ in, in
                     blk_store<D, LD>(nxt, t, a);
                     swap();
                 }
-                to_pauli_basis<NQ, NT, LD>(cur, nxt, inv_d * inv_d, t); swap(); rep = FBX_REP_CHI;
+                to_pauli_sites<NQ, NT, LD>(cur, nxt, inv_d * inv_d, t); swap(); rep = FBX_REP_CHI;
             } else {
                 reshuffle<NQ, NT, LD>(cur, nxt, t); swap(); rep = FBX_REP_SUPEROP;
             }
         } else if (rep == FBX_REP_SUPEROP) {
             if (to == FBX_REP_PAULI_LIOUVILLE) {
-                to_pauli_basis<NQ, NT, LD>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
+                to_pauli_sites<NQ, NT, LD>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
             } else {
                 reshuffle<NQ, NT, LD>(cur, nxt, t); swap(); rep = FBX_REP_CHOI;
             }
         } else {
-            from_pauli_basis<NQ, NT, LD>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_SUPEROP;
+            from_pauli_sites<NQ, NT, LD>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_SUPEROP;
         }
     }
     store_matrix<NQ, NT, LD>(cur, out + item * (long long)D * D * 2, t);

@@ -6,7 +6,9 @@ import numpy as np
 from fbx import synthetic, _lib
 _lib.set_device(0)
 lib = _lib.lib()
-n, D, B = 2, 16, 200000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+D = 4 ** n
+B = {1: 1000000, 2: 200000, 3: 8192}[n]
 ks = synthetic.kraus_batch(n, 4, 4096, seed=1)
 ks = np.ascontiguousarray(np.tile(ks, (B // 4096 + 1, 1, 1, 1))[:B])
 d_k = _lib.DeviceBuffer.from_array(ks)
