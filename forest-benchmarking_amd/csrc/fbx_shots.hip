@@ -129,6 +129,72 @@ dfe_kernel(int n_qubits, int process, long long B, long long m, const double* __
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Bootstrap resampling (tomography.py:378-409): e' = 2 Beta(n_plus + prior, n_minus + prior) - 1 with
+// n_plus = (e + 1) / 2 * counts.  The reference draws from numpy's global stream; here every output
+// element (r, i) owns a counter-based Philox4x32-10 stream keyed by the caller's seed, so the result
+// does not depend on the launch shape or on R (parity with the reference is statistical; the
+// generator itself is bit-exact against oracle/fbx_oracle/acquisition.py).  Beta = Ga / (Ga + Gb),
+// gammas by Marsaglia-Tsang squeeze-free rejection, one Philox block (two 32-bit uniforms for the
+// Box-Muller normal, one 53-bit uniform for the acceptance test) per attempt.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+struct PhiloxStream {
+    uint32_t k0, k1, e0, e1, draw;
+    __device__ __forceinline__ void next(double& u1, double& u2, double& u3) {
+        uint32_t c[4] = {e0, e1, draw++, 0u};
+        philox4x32_10(c, k0, k1);
+        u1 = ((double)c[0] + 0.5) * 0x1p-32;
+        u2 = ((double)c[1] + 0.5) * 0x1p-32;
+        u3 = ((double)(((unsigned long long)(c[2] >> 5) << 26) | (unsigned long long)(c[3] >> 6)) + 0.5) * 0x1p-53;
+    }
+};
+constexpr int FBX_GAMMA_MAX_TRIES = 64;     // acceptance >= 0.95 per try
+__device__ double gamma_marsaglia_tsang(double a, PhiloxStream& s) {
+    double boost = 1.0, u1, u2, u3;
+    if (a < 1.0) { s.next(u1, u2, u3); boost = pow(u3, 1.0 / a); a += 1.0; }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (int tries = 0; tries < FBX_GAMMA_MAX_TRIES; ++tries) {
+        s.next(u1, u2, u3);
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) return boost * d * v;
+    }
+    return boost * d;
+}
+__global__ void __launch_bounds__(256)
+beta_resample_kernel(long long n, long long R, const double* __restrict__ expect, const double* __restrict__ counts,
+                     double prior, unsigned long long seed, double* __restrict__ out, double* __restrict__ counts_out) {
+    const long long total = n * R;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long i = idx % n;
+        const double e = expect[i], cnt = counts[i];
+        const double n_plus = ((e + 1.0) / 2.0) * cnt, n_minus = cnt - n_plus;
+        const double a = n_plus + prior, b = n_minus + prior;
+        double val = __builtin_nan("");
+        if (a > 0.0 && b > 0.0) {
+            PhiloxStream s{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)idx, (uint32_t)((unsigned long long)idx >> 32), 0u};
+            const double ga = gamma_marsaglia_tsang(a, s);
+            const double gb = gamma_marsaglia_tsang(b, s);
+            val = 2.0 * (ga / (ga + gb)) - 1.0;
+        }
+        out[idx] = val;
+        if (counts_out) counts_out[idx] = cnt;
+    }
+}
+
 }  // namespace fbx
 
 using namespace fbx;
@@ -199,6 +265,43 @@ int fbx_dfe_estimate(int n_qubits, int kind, int64_t B, int64_t m, const double*
     FBX_HIP(hipGetLastError());
     FBX_HIP(hipMemcpyAsync(mean_out, dm.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
     FBX_HIP(hipMemcpyAsync(err_out, dr.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
+
+int fbx_beta_resample_dev(int64_t n, int64_t R, const double* d_expect, const double* d_counts, double prior_counts,
+                          uint64_t seed, double* d_out, double* d_counts_out) {
+    FBX_REQUIRE(n >= 0 && R >= 0, "fbx_beta_resample: need n >= 0 and R >= 0");
+    FBX_REQUIRE(prior_counts > 0.0, "fbx_beta_resample: prior_counts must be positive");
+    FBX_REQUIRE(n * R == 0 || (d_expect && d_counts && d_out), "fbx_beta_resample: NULL buffer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n * R == 0) return FBX_OK;
+    const long long total = (long long)n * R, want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < 256 * 32 ? want : 256 * 32);
+    hipLaunchKernelGGL(beta_resample_kernel, dim3(grid), dim3(256), 0, stream(), (long long)n, (long long)R, d_expect,
+                       d_counts, prior_counts, (unsigned long long)seed, d_out, d_counts_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_beta_resample(int64_t n, int64_t R, const double* expect, const double* counts, double prior_counts,
+                      uint64_t seed, double* out) {
+    FBX_REQUIRE(n >= 0 && R >= 0, "fbx_beta_resample: need n >= 0 and R >= 0");
+    FBX_REQUIRE(prior_counts > 0.0, "fbx_beta_resample: prior_counts must be positive");
+    FBX_REQUIRE(n * R == 0 || (expect && counts && out), "fbx_beta_resample: NULL buffer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n * R == 0) return FBX_OK;
+    DevBuf de, dc, dout;
+    if ((rc = de.alloc(sizeof(double) * n)) || (rc = dc.alloc(sizeof(double) * n)) ||
+        (rc = dout.alloc(sizeof(double) * n * R)))
+        return rc;
+    FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(dc.p, counts, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+    rc = fbx_beta_resample_dev(n, R, de.as<double>(), dc.as<double>(), prior_counts, seed, dout.as<double>(), nullptr);
+    if (rc) return rc;
+    FBX_HIP(hipMemcpyAsync(out, dout.p, sizeof(double) * n * R, hipMemcpyDeviceToHost, stream()));
     FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
 }

@@ -75,6 +75,8 @@ PROTOTYPES = {
     "fbx_convert_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
     "fbx_proj_choi_dev": [C.c_int, C.c_int, _i64, _vp, _vp, _vp],
     "fbx_process_fidelity_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp],
+    "fbx_beta_resample": [_i64, _i64, _dp, _dp, C.c_double, C.c_uint64, _dp],
+    "fbx_beta_resample_dev": [_i64, _i64, _vp, _vp, C.c_double, C.c_uint64, _vp, _vp],
 }
 
 

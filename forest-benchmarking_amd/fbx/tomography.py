@@ -186,11 +186,22 @@ def _resample_expectations_with_beta(results, prior_counts=1):
     return resampled
 
 
-def resample_expectations_with_beta_batch(expectations, total_counts, n_resamples, prior_counts=1):
-    """[n_resamples, m] Beta-resampled expectations drawn from the global np.random stream in the
-    order the reference draws them (resample by resample, result by result; tomography.py:391-402)."""
+def resample_expectations_with_beta_batch(expectations, total_counts, n_resamples, prior_counts=1, seed=None):
+    """Beta-resampled expectations, ``[n_resamples, *expectations.shape]``.
+
+    ``seed=None``: drawn on the host from the global np.random stream in the order the reference
+    draws them (resample by resample, result by result; tomography.py:391-402) -- expectations must
+    then be one experiment ``[m]``.  ``seed=int``: drawn on the device by the counter-based generator
+    of ``fbx_beta_resample`` (reproducible, any batch shape; same distribution, different stream)."""
     e = np.asarray(expectations, dtype=float)
     c = np.asarray(total_counts, dtype=float)
+    if seed is not None:
+        e = np.ascontiguousarray(e)
+        c = np.ascontiguousarray(np.broadcast_to(c, e.shape))
+        out = np.empty((int(n_resamples),) + e.shape)
+        _lib.check(_lib.lib().fbx_beta_resample(e.size, int(n_resamples), _lib.dptr(e), _lib.dptr(c),
+                                               float(prior_counts), int(seed) & (2 ** 64 - 1), _lib.dptr(out)))
+        return out
     num_plus = ((e + 1) / 2) * c
     num_minus = c - num_plus
     a = np.broadcast_to(num_plus + prior_counts, (n_resamples, e.size))
@@ -217,14 +228,15 @@ def _batched_form(tomo_estimator):
 
 def estimate_variance(results: List[ExperimentResult], qubits: List[int], tomo_estimator: Callable,
                       functional: Callable, target_state=None, n_resamples: int = 40,
-                      project_to_physical: bool = False) -> Tuple[float, float]:
+                      project_to_physical: bool = False, seed=None) -> Tuple[float, float]:
     """tomography.py:412-453 (bootstrap error bar of a functional of the state).
 
     When `tomo_estimator` is one of this module's state estimators and `functional` one of
     ``dm.purity / fidelity / infidelity / trace_distance / hilbert_schmidt_ip`` the whole bootstrap
     is three batched device calls (estimate, project, measure) over the `n_resamples` resampled
     experiments -- the resamples are the batch axis; any other callables take the reference's
-    one-at-a-time loop."""
+    one-at-a-time loop.  ``seed`` (extension): None = the reference's np.random stream, an int = the
+    device generator (batched path only)."""
     from .operator_tools.project_state_matrix import (project_state_matrix_to_physical,
                                                        project_state_matrix_to_physical_batch)
     if functional != dm.purity:
@@ -237,7 +249,7 @@ def estimate_variance(results: List[ExperimentResult], qubits: List[int], tomo_e
     if batched is not None and functional in measures:
         impl, kwargs = batched
         design, e, c = flatten_results(results, qubits, "state")
-        e_rs = resample_expectations_with_beta_batch(e, c, n_resamples)
+        e_rs = resample_expectations_with_beta_batch(e, c, n_resamples, seed=seed)
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
             rhos = impl(design, e_rs, np.broadcast_to(c, e_rs.shape), **kwargs)
@@ -317,6 +329,51 @@ def pgdb_process_estimate(results: List[ExperimentResult], qubits: List[int],
     """tomography.py:542-594 (projected gradient descent with backtracking)."""
     design, e, c = flatten_results(results, qubits, "process")
     return pgdb_process_estimate_batch(design, e, c, trace_preserving)[0]
+
+
+def process_fidelity_variance_batch(design: Design, expectations, total_counts, target_ptm,
+                                    n_resamples: int = 40, seed: int = 0, prior_counts=1,
+                                    trace_preserving=True, mode="converge", max_iters=0,
+                                    return_samples=False):
+    """Bootstrap error bars of the process fidelity of B process tomographies (the
+    process analogue of ``estimate_variance``, tomography.py:412-453): every experiment is resampled
+    ``n_resamples`` times (Beta posterior of each expectation, tomography.py:378-409), all
+    ``n_resamples * B`` resampled experiments are reconstructed by PGDB in ONE launch, converted to
+    Pauli transfer matrices and compared with ``target_ptm`` ([D, D] or [B, D, D]).  Everything between
+    the upload of (expectations, counts) and the download of the fidelities stays in HBM.
+    Returns (mean[B], var[B]) (and the [n_resamples, B] fidelities with ``return_samples``)."""
+    if mode not in ("converge", "fixed"):
+        raise ValueError("mode must be 'converge' or 'fixed'")
+    e, c = _batch_arrays(design, expectations, total_counts)
+    B, m, n, D = e.shape[0], design.m, design.n_qubits, design.dim ** 2
+    R = int(n_resamples)
+    tgt = np.asarray(target_ptm, dtype=np.complex128)
+    if tgt.shape == (D, D):
+        tgt = np.broadcast_to(tgt, (B, D, D))
+    if tgt.shape != (B, D, D):
+        raise ValueError("target_ptm must be [D, D] or [B, D, D]")
+    if R < 1 or B == 0:
+        raise ValueError("need n_resamples >= 1 and a non-empty batch")
+    lib, DB = _lib.lib(), _lib.DeviceBuffer
+    d_e, d_c = DB.from_array(e), DB.from_array(c)
+    d_er, d_cr = DB(R * B * m * 8), DB(R * B * m * 8)
+    _lib.check(lib.fbx_beta_resample_dev(B * m, R, d_e.ptr, d_c.ptr, float(prior_counts),
+                                         int(seed) & (2 ** 64 - 1), d_er.ptr, d_cr.ptr))
+    d_choi, d_ptm = DB(R * B * D * D * 16), DB(R * B * D * D * 16)
+    _lib.check(lib.fbx_pgdb_process_dev(design.handle, R * B, d_er.ptr, d_cr.ptr, int(bool(trace_preserving)),
+                                        _lib.MODE_FIXED if mode == "fixed" else _lib.MODE_CONVERGE, int(max_iters),
+                                        d_choi.ptr, None, None, None, None))
+    _lib.check(lib.fbx_convert_dev(_lib.REP_CHOI, _lib.REP_PAULI_LIOUVILLE, n, R * B, d_choi.ptr, 0, d_ptm.ptr))
+    d_tgt = DB.from_array(np.ascontiguousarray(np.broadcast_to(tgt, (R, B, D, D))))
+    d_f = DB(R * B * 8)
+    _lib.check(lib.fbx_process_fidelity_dev(n, R * B, d_tgt.ptr, d_ptm.ptr, None, d_f.ptr))
+    _lib.synchronize()
+    fid = d_f.to_array(np.float64, (R, B))
+    for buf in (d_e, d_c, d_er, d_cr, d_choi, d_ptm, d_tgt, d_f):
+        buf.free()
+    if return_samples:
+        return fid.mean(axis=0), fid.var(axis=0), fid
+    return fid.mean(axis=0), fid.var(axis=0)
 
 
 def estimate_by_qubit_groups(results, qubit_groups, kind="process", estimator="pgdb", **kwargs):

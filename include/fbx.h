@@ -208,6 +208,20 @@ int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, 
 int fbx_dfe_estimate(int n_qubits, int kind, int64_t B, int64_t m, const double* expect,
                      const double* std_err, double* mean_out, double* err_out);
 
+/* Bootstrap resampling of expectations, _resample_expectations_with_beta (tomography.py:378-409), for
+ * all resamples at once: out[r][i] = 2 Beta(n_plus_i + prior, n_minus_i + prior) - 1 with
+ * n_plus = (expect_i + 1) / 2 * counts_i, i < n (= batch * settings, flattened), r < R.  The reference
+ * draws from numpy's global stream; here element (r, i) owns a counter-based Philox4x32-10 stream
+ * keyed by `seed` (counter = (r * n + i, draw number)), so results are reproducible and independent
+ * of R and of the launch shape; parity with the reference is distributional.  Elements whose Beta
+ * parameters are not positive come out as NaN.  The _dev form optionally also writes
+ * d_counts_out[r][i] = counts[i] so that the R * batch resampled experiments can be handed to a
+ * batched estimator as one launch. */
+int fbx_beta_resample(int64_t n, int64_t R, const double* expect, const double* counts,
+                      double prior_counts, uint64_t seed, double* out);
+int fbx_beta_resample_dev(int64_t n, int64_t R, const double* d_expect, const double* d_counts,
+                          double prior_counts, uint64_t seed, double* d_out, double* d_counts_out);
+
 /* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
  * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16, 32, 64}.  This is the
  * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators

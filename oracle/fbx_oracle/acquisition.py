@@ -46,3 +46,91 @@ def estimate_dfe(expectations, std_errs, n_qubits, kind):
         p = 1.0 / d ** 2 + slope * e.mean()
         return (d * d * p + d) / (d * d + d), d / (d + 1.0) * slope * rms
     raise ValueError("Kind can only be 'state' or 'process'.")
+
+
+# --------------------------------------------------------------------------------------------------
+# Counter-based bootstrap resampling.  The reference draws e' = 2 Beta(n+ + prior, n- + prior) - 1
+# from numpy's global stream (tomography.py:378-409); the device version cannot share that stream, so
+# it defines its own generator.  This is the CPU statement of exactly that generator (checker only):
+# Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; known-answer
+# vectors of the Random123 distribution are in tests/test_resample_cpu.py), counter = (element index
+# low, high, draw number, 0), key = (seed low, high); per attempt one block -> two 32-bit uniforms for
+# a Box-Muller normal and one 53-bit uniform for the Marsaglia-Tsang acceptance test.
+# --------------------------------------------------------------------------------------------------
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+GAMMA_MAX_TRIES = 64
+
+
+def philox4x32_10(counter, key):
+    """counter [..., 4] uint32, key [..., 2] uint32 -> [..., 4] uint32"""
+    c = [np.asarray(counter[..., j], dtype=np.uint64) for j in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint64)
+    k1 = np.asarray(key[..., 1], dtype=np.uint64)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(_M0) * c[0]
+        p1 = np.uint64(_M1) * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0 = (k0 + np.uint64(_W0)) & mask
+        k1 = (k1 + np.uint64(_W1)) & mask
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def _draw(idx, draw, seed):
+    ctr = np.stack([idx & 0xFFFFFFFF, idx >> 32, draw, np.zeros_like(idx)], axis=-1).astype(np.uint32)
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32), idx.shape + (2,))
+    x = philox4x32_10(ctr, key).astype(np.uint64)
+    u1 = (x[..., 0].astype(np.float64) + 0.5) * 2.0 ** -32
+    u2 = (x[..., 1].astype(np.float64) + 0.5) * 2.0 ** -32
+    u3 = ((((x[..., 2] >> np.uint64(5)) << np.uint64(26)) | (x[..., 3] >> np.uint64(6))).astype(np.float64) + 0.5) * 2.0 ** -53
+    return u1, u2, u3
+
+
+def _gamma(a, idx, draw, seed):
+    """Marsaglia-Tsang for every element; `draw` (int64 array) is advanced in place."""
+    a = a.copy()
+    boost = np.ones_like(a)
+    small = a < 1.0
+    if small.any():
+        _, _, u3 = _draw(idx[small], draw[small], seed)
+        boost[small] = u3 ** (1.0 / a[small])
+        a[small] += 1.0
+        draw[small] += 1
+    d = a - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    out = boost * d
+    todo = np.ones(a.shape, dtype=bool)
+    for _ in range(GAMMA_MAX_TRIES):
+        if not todo.any():
+            break
+        w = np.nonzero(todo)[0]
+        u1, u2, u3 = _draw(idx[w], draw[w], seed)
+        draw[w] += 1
+        x = np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586476925 * u2)
+        v = 1.0 + c[w] * x
+        ok = v > 0.0
+        v3 = np.where(ok, v, 1.0) ** 3
+        acc = ok & (np.log(u3) < 0.5 * x * x + d[w] - d[w] * v3 + d[w] * np.log(v3))
+        out[w[acc]] = boost[w[acc]] * d[w[acc]] * v3[acc]
+        todo[w[acc]] = False
+    return out
+
+
+def beta_resample(expectations, total_counts, n_resamples, prior_counts=1.0, seed=0):
+    """[n_resamples, *expectations.shape] resampled expectations of the counter-based generator."""
+    e = np.asarray(expectations, dtype=np.float64)
+    cnt = np.broadcast_to(np.asarray(total_counts, dtype=np.float64), e.shape)
+    n = e.size
+    idx = np.arange(n * n_resamples, dtype=np.int64)
+    ef, cf = np.tile(e.ravel(), n_resamples), np.tile(cnt.ravel(), n_resamples)
+    n_plus = ((ef + 1.0) / 2.0) * cf
+    a, b = n_plus + prior_counts, (cf - n_plus) + prior_counts
+    good = (a > 0) & (b > 0)
+    out = np.full(idx.shape, np.nan)
+    draw = np.zeros(good.sum(), dtype=np.int64)
+    ga = _gamma(a[good], idx[good], draw, seed)
+    gb = _gamma(b[good], idx[good], draw, seed)
+    out[good] = 2.0 * (ga / (ga + gb)) - 1.0
+    return out.reshape((n_resamples,) + e.shape)
