@@ -653,18 +653,56 @@ int check_state_design(const fbx_design* des, const char* who) {
 
 extern "C" {
 
+// Every estimator / measure below comes as a device-pointer form (`_dev`: checks + launch on the library
+// stream, no synchronisation) and a host-pointer form (staging buffers, H2D, the `_dev` form, D2H, sync).
+
+int fbx_linv_state_dev(const fbx_design* design, int64_t B, const double* d_expect, double* d_rho_out) {
+    FBX_TRY(check_state_design(design, "fbx_linv_state"));
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_expect && d_rho_out)), "fbx_linv_state: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    FBX_DISPATCH_NQ(design->dev.n, linv_state_kernel, 0, B, design->dev, (long long)B, d_expect, d_rho_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 int fbx_linv_state(const fbx_design* design, int64_t B, const double* expect, double* rho_out) {
     FBX_TRY(check_state_design(design, "fbx_linv_state"));
     FBX_REQUIRE(B >= 0 && (B == 0 || (expect && rho_out)), "fbx_linv_state: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
+    const size_t m = design->dev.m, D = design->dev.D;
     HostIO io; double *de, *dr;
     FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.out(D * 2 * B, &dr));
-    FBX_DISPATCH_NQ(n, linv_state_kernel, 0, B, design->dev, (long long)B, de, dr);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_linv_state_dev(design, B, de, dr));
     FBX_TRY(io.back(rho_out, dr, D * 2 * B));
     return io.sync();
+}
+
+int fbx_mle_state_dev(const fbx_design* design, int64_t B, const double* d_expect, const double* d_counts,
+                      double epsilon, double entropy_penalty, double beta, double tol, int maxiter,
+                      double* d_rho_out, int32_t* d_iters_out, int32_t* d_hit_max_out) {
+    FBX_TRY(check_state_design(design, "fbx_mle_state"));
+    FBX_REQUIRE(!(entropy_penalty != 0.0 && beta != 0.0),
+                "One can't sensibly do entropy penalty and hedging. Do one or the other but not both.");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_expect && d_counts && d_rho_out)), "fbx_mle_state: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
+    const size_t lds = state_lds(n, (int)m);
+    if (lds > 64 * 1024) { set_error("fbx_mle_state: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !getenv("FBX_MLE_UNPACKED");
+    if (packed && n == 1)
+        hipLaunchKernelGGL(mle_state_packed_kernel<1>, dim3((unsigned)((B + 15) / 16)), dim3(64), 0, stream(), design->dev,
+                           (long long)B, d_expect, epsilon, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
+    else if (packed)
+        hipLaunchKernelGGL(mle_state_packed_kernel<2>, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, stream(), design->dev,
+                           (long long)B, d_expect, epsilon, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
+    else
+        FBX_DISPATCH_NQ(n, mle_state_kernel, lds, B, design->dev, (long long)B, d_expect, d_counts, epsilon, entropy_penalty,
+                        beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
 }
 
 int fbx_mle_state(const fbx_design* design, int64_t B, const double* expect, const double* counts,
@@ -676,26 +714,27 @@ int fbx_mle_state(const fbx_design* design, int64_t B, const double* expect, con
     FBX_REQUIRE(B >= 0 && (B == 0 || (expect && counts && rho_out)), "fbx_mle_state: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
-    const size_t lds = state_lds(n, (int)m);
-    if (lds > 64 * 1024) { set_error("fbx_mle_state: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    const size_t m = design->dev.m, D = design->dev.D;
     HostIO io; double *de, *dc, *dr; int32_t *di, *dh;
     FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.in(counts, m * B, &dc));
     FBX_TRY(io.out(D * 2 * B, &dr)); FBX_TRY(io.out((size_t)B, &di)); FBX_TRY(io.out((size_t)B, &dh));
-    const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !getenv("FBX_MLE_UNPACKED");
-    if (packed && n == 1)
-        hipLaunchKernelGGL(mle_state_packed_kernel<1>, dim3((unsigned)((B + 15) / 16)), dim3(64), 0, stream(), design->dev,
-                           (long long)B, de, epsilon, tol, maxiter, dr, di, dh);
-    else if (packed)
-        hipLaunchKernelGGL(mle_state_packed_kernel<2>, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, stream(), design->dev,
-                           (long long)B, de, epsilon, tol, maxiter, dr, di, dh);
-    else
-        FBX_DISPATCH_NQ(n, mle_state_kernel, lds, B, design->dev, (long long)B, de, dc, epsilon, entropy_penalty, beta, tol,
-                        maxiter, dr, di, dh);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_mle_state_dev(design, B, de, dc, epsilon, entropy_penalty, beta, tol, maxiter, dr, di, dh));
     FBX_TRY(io.back(rho_out, dr, D * 2 * B)); FBX_TRY(io.back(iters_out, di, (size_t)B));
     FBX_TRY(io.back(hit_max_out, dh, (size_t)B));
     return io.sync();
+}
+
+int fbx_r_operator_dev(const fbx_design* design, int64_t B, const double* d_rho, const double* d_expect, double* d_r_out) {
+    FBX_TRY(check_state_design(design, "fbx_r_operator"));
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_rho && d_expect && d_r_out)), "fbx_r_operator: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n;
+    const size_t lds = state_lds(n, (int)design->dev.m);
+    if (lds > 64 * 1024) { set_error("fbx_r_operator: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    FBX_DISPATCH_NQ(n, r_operator_kernel, lds, B, design->dev, (long long)B, d_rho, d_expect, d_r_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
 }
 
 int fbx_r_operator(const fbx_design* design, int64_t B, const double* rho, const double* expect, double* r_out) {
@@ -703,15 +742,24 @@ int fbx_r_operator(const fbx_design* design, int64_t B, const double* rho, const
     FBX_REQUIRE(B >= 0 && (B == 0 || (rho && expect && r_out)), "fbx_r_operator: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
-    const size_t lds = state_lds(n, (int)m);
-    if (lds > 64 * 1024) { set_error("fbx_r_operator: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    const size_t m = design->dev.m, D = design->dev.D;
     HostIO io; double *dr, *de, *dout;
     FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.out(D * 2 * B, &dout));
-    FBX_DISPATCH_NQ(n, r_operator_kernel, lds, B, design->dev, (long long)B, dr, de, dout);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_r_operator_dev(design, B, dr, de, dout));
     FBX_TRY(io.back(r_out, dout, D * 2 * B));
     return io.sync();
+}
+
+int fbx_state_log_likelihood_dev(const fbx_design* design, int64_t B, const double* d_rho, const double* d_expect,
+                                 const double* d_counts, double* d_ll_out) {
+    FBX_TRY(check_state_design(design, "fbx_state_log_likelihood"));
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_rho && d_expect && d_counts && d_ll_out)), "fbx_state_log_likelihood: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n;
+    FBX_DISPATCH_NQ(n, loglik_kernel, state_lds(n, 1), B, design->dev, (long long)B, d_rho, d_expect, d_counts, d_ll_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
 }
 
 int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* rho, const double* expect,
@@ -720,15 +768,30 @@ int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* 
     FBX_REQUIRE(B >= 0 && (B == 0 || (rho && expect && counts && ll_out)), "fbx_state_log_likelihood: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
-    const size_t lds = state_lds(n, 1);
+    const size_t m = design->dev.m, D = design->dev.D;
     HostIO io; double *dr, *de, *dc, *dout;
     FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.in(counts, m * B, &dc));
     FBX_TRY(io.out((size_t)B, &dout));
-    FBX_DISPATCH_NQ(n, loglik_kernel, lds, B, design->dev, (long long)B, dr, de, dc, dout);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_state_log_likelihood_dev(design, B, dr, de, dc, dout));
     FBX_TRY(io.back(ll_out, dout, (size_t)B));
     return io.sync();
+}
+
+int fbx_eigh_dev(int N, int64_t B, const double* d_a, double* d_w_out, double* d_v_out) {
+    FBX_REQUIRE(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "fbx_eigh: N must be a power of two in 2..64");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_a && d_w_out)), "fbx_eigh: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    switch (N) {
+        case 2: FBX_TRY(launch_eigh<2>(B, d_a, d_w_out, d_v_out)); break;
+        case 4: FBX_TRY(launch_eigh<4>(B, d_a, d_w_out, d_v_out)); break;
+        case 8: FBX_TRY(launch_eigh<8>(B, d_a, d_w_out, d_v_out)); break;
+        case 16: FBX_TRY(launch_eigh<16>(B, d_a, d_w_out, d_v_out)); break;
+        case 32: FBX_TRY(launch_eigh<32>(B, d_a, d_w_out, d_v_out)); break;
+        default: FBX_TRY(launch_eigh<64>(B, d_a, d_w_out, d_v_out)); break;
+    }
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
 }
 
 int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
@@ -740,17 +803,19 @@ int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
     HostIO io; double *da, *dw, *dv = nullptr;
     FBX_TRY(io.in(a, nn, &da)); FBX_TRY(io.out((size_t)N * B, &dw));
     if (v_out) FBX_TRY(io.out(nn, &dv));
-    switch (N) {
-        case 2: FBX_TRY(launch_eigh<2>(B, da, dw, dv)); break;
-        case 4: FBX_TRY(launch_eigh<4>(B, da, dw, dv)); break;
-        case 8: FBX_TRY(launch_eigh<8>(B, da, dw, dv)); break;
-        case 16: FBX_TRY(launch_eigh<16>(B, da, dw, dv)); break;
-        case 32: FBX_TRY(launch_eigh<32>(B, da, dw, dv)); break;
-        default: FBX_TRY(launch_eigh<64>(B, da, dw, dv)); break;
-    }
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_eigh_dev(N, B, da, dw, dv));
     FBX_TRY(io.back(w_out, dw, (size_t)N * B)); FBX_TRY(io.back(v_out, dv, nn));
     return io.sync();
+}
+
+int fbx_proj_state_physical_dev(int n_qubits, int64_t B, const double* d_rho, double* d_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_proj_state_physical: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_rho && d_out)), "fbx_proj_state_physical: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    FBX_DISPATCH_NQ(n_qubits, proj_state_kernel, state_lds(n_qubits, 1), B, (long long)B, d_rho, d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
 }
 
 int fbx_proj_state_physical(int n_qubits, int64_t B, const double* rho, double* out) {
@@ -761,10 +826,21 @@ int fbx_proj_state_physical(int n_qubits, int64_t B, const double* rho, double* 
     const size_t d = (size_t)1 << n_qubits, D = d * d;
     HostIO io; double *dr, *dout;
     FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.out(D * 2 * B, &dout));
-    FBX_DISPATCH_NQ(n_qubits, proj_state_kernel, state_lds(n_qubits, 1), B, (long long)B, dr, dout);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_proj_state_physical_dev(n_qubits, B, dr, dout));
     FBX_TRY(io.back(out, dout, D * 2 * B));
     return io.sync();
+}
+
+int fbx_state_measures_dev(int n_qubits, int64_t B, const double* d_rho, const double* d_sigma, double* d_purity_out,
+                           double* d_fidelity_out, double* d_trace_dist_out, double* d_hs_ip_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_state_measures: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_rho && d_sigma)), "fbx_state_measures: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    FBX_DISPATCH_NQ(n_qubits, state_measures_kernel, state_lds(n_qubits, 1), B, (long long)B, d_rho, d_sigma, d_purity_out,
+                    d_fidelity_out, d_trace_dist_out, d_hs_ip_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
 }
 
 int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double* sigma, double* purity_out,
@@ -780,8 +856,7 @@ int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double*
     if (fidelity_out) FBX_TRY(io.out((size_t)B, &df));
     if (trace_dist_out) FBX_TRY(io.out((size_t)B, &dt));
     if (hs_ip_out) FBX_TRY(io.out((size_t)B, &dh));
-    FBX_DISPATCH_NQ(n_qubits, state_measures_kernel, state_lds(n_qubits, 1), B, (long long)B, dr, ds, dp, df, dt, dh);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_state_measures_dev(n_qubits, B, dr, ds, dp, df, dt, dh));
     FBX_TRY(io.back(purity_out, dp, (size_t)B)); FBX_TRY(io.back(fidelity_out, df, (size_t)B));
     FBX_TRY(io.back(trace_dist_out, dt, (size_t)B)); FBX_TRY(io.back(hs_ip_out, dh, (size_t)B));
     return io.sync();

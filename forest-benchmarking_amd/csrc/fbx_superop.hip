@@ -949,20 +949,30 @@ struct HostIO {     // host <-> device staging for the host-pointer entry points
 
 extern "C" {
 
+int fbx_linv_process_dev(const fbx_design* design, int64_t B, const double* d_expect, double* d_choi_out) {
+    FBX_REQUIRE(design != nullptr, "fbx_linv_process: NULL design");
+    FBX_REQUIRE(design->dev.kind == FBX_KIND_PROCESS, "fbx_linv_process: needs a process design");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_expect && d_choi_out)), "fbx_linv_process: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int n = design->dev.n;
+    if (n == 3) FBX_TRY(linv_process3_launch(design, B, d_expect, d_choi_out));
+    else if (n == 1) hipLaunchKernelGGL(linv_process_kernel<1>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, d_expect, d_choi_out);
+    else hipLaunchKernelGGL(linv_process_kernel<2>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, d_expect, d_choi_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect, double* choi_out) {
     FBX_REQUIRE(design != nullptr, "fbx_linv_process: NULL design");
     FBX_REQUIRE(design->dev.kind == FBX_KIND_PROCESS, "fbx_linv_process: needs a process design");
     FBX_REQUIRE(B >= 0 && (B == 0 || (expect && choi_out)), "fbx_linv_process: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    const int n = design->dev.n;
     const size_t m = design->dev.m, D = design->dev.D;
     HostIO io; double *de, *dout;
     FBX_TRY(io.in(expect, m * B, &de)); FBX_TRY(io.out(D * D * 2 * B, &dout));
-    if (n == 3) FBX_TRY(linv_process3_launch(design, B, de, dout));
-    else if (n == 1) hipLaunchKernelGGL(linv_process_kernel<1>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, de, dout);
-    else hipLaunchKernelGGL(linv_process_kernel<2>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, de, dout);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_linv_process_dev(design, B, de, dout));
     FBX_TRY(io.back(choi_out, dout, D * D * 2 * B));
     return io.sync();
 }
@@ -1064,6 +1074,18 @@ int fbx_proj_choi(int proj_kind, int n_qubits, int64_t B, const double* choi, do
     return io.sync();
 }
 
+int fbx_apply_choi_dev(int n_qubits, int64_t B, const double* d_choi, const double* d_rho, double* d_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_apply_choi: n_qubits must be 1..3");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_choi && d_rho && d_out)), "fbx_apply_choi: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t d = (size_t)1 << n_qubits, D = d * d;
+    const long long total = (long long)B * D;
+    hipLaunchKernelGGL(apply_choi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(), (int)d, (long long)B, d_choi, d_rho, d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rho, double* out) {
     FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_apply_choi: n_qubits must be 1..3");
     FBX_REQUIRE(B >= 0 && (B == 0 || (choi && rho && out)), "fbx_apply_choi: bad batch / NULL buffer");
@@ -1072,9 +1094,7 @@ int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rh
     const size_t d = (size_t)1 << n_qubits, D = d * d;
     HostIO io; double *dc, *dr, *dout;
     FBX_TRY(io.in(choi, D * D * 2 * B, &dc)); FBX_TRY(io.in(rho, D * 2 * B, &dr)); FBX_TRY(io.out(D * 2 * B, &dout));
-    const long long total = (long long)B * D;
-    hipLaunchKernelGGL(apply_choi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(), (int)d, (long long)B, dc, dr, dout);
-    FBX_HIP(hipGetLastError());
+    FBX_TRY(fbx_apply_choi_dev(n_qubits, B, dc, dr, dout));
     FBX_TRY(io.back(out, dout, D * 2 * B));
     return io.sync();
 }

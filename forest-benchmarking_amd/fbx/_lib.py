@@ -75,6 +75,15 @@ PROTOTYPES = {
     "fbx_convert_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
     "fbx_proj_choi_dev": [C.c_int, C.c_int, _i64, _vp, _vp, _vp],
     "fbx_process_fidelity_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp],
+    "fbx_linv_process_dev": [_vp, _i64, _vp, _vp],
+    "fbx_linv_state_dev": [_vp, _i64, _vp, _vp],
+    "fbx_mle_state_dev": [_vp, _i64, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp],
+    "fbx_r_operator_dev": [_vp, _i64, _vp, _vp, _vp],
+    "fbx_state_log_likelihood_dev": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "fbx_proj_state_physical_dev": [C.c_int, _i64, _vp, _vp],
+    "fbx_apply_choi_dev": [C.c_int, _i64, _vp, _vp, _vp],
+    "fbx_state_measures_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fbx_eigh_dev": [C.c_int, _i64, _vp, _vp, _vp],
     "fbx_beta_resample": [_i64, _i64, _dp, _dp, C.c_double, C.c_uint64, _dp],
     "fbx_beta_resample_dev": [_i64, _i64, _vp, _vp, C.c_double, C.c_uint64, _vp, _vp],
 }

@@ -116,10 +116,14 @@ int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_ex
 /* linear_inv_process_estimate (tomography.py:459-491): choi_out[B][D][D]. */
 int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect,
                      double* choi_out);
+int fbx_linv_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                         double* d_choi_out);
 
 /* ---------------------------------------------------------------- state estimators
  * linear_inv_state_estimate (tomography.py:130-165): rho_out[B][d][d], d = 2^n. */
 int fbx_linv_state(const fbx_design* design, int64_t B, const double* expect, double* rho_out);
+int fbx_linv_state_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                       double* d_rho_out);
 
 /* iterative_mle_state_estimate (tomography.py:168-270) incl. _R (:273-338): diluted
  * iterative MLE with optional max-entropy (entropy_penalty > 0) or hedging (beta > 0).
@@ -129,14 +133,23 @@ int fbx_mle_state(const fbx_design* design, int64_t B, const double* expect,
                   const double* counts, double epsilon, double entropy_penalty, double beta,
                   double tol, int maxiter, double* rho_out, int32_t* iters_out,
                   int32_t* hit_max_out);
+int fbx_mle_state_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                      const double* d_counts, double epsilon, double entropy_penalty, double beta,
+                      double tol, int maxiter, double* d_rho_out, int32_t* d_iters_out,
+                      int32_t* d_hit_max_out);
 
 /* _R (tomography.py:273-338): r_out[B][d][d] for given states rho[B][d][d]. */
 int fbx_r_operator(const fbx_design* design, int64_t B, const double* rho, const double* expect,
                    double* r_out);
+int fbx_r_operator_dev(const fbx_design* design, int64_t B, const double* d_rho,
+                       const double* d_expect, double* d_r_out);
 
 /* state_log_likelihood (tomography.py:341-375): ll_out[B] (log10). */
 int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* rho,
                              const double* expect, const double* counts, double* ll_out);
+int fbx_state_log_likelihood_dev(const fbx_design* design, int64_t B, const double* d_rho,
+                                 const double* d_expect, const double* d_counts,
+                                 double* d_ll_out);
 
 /* ---------------------------------------------------------------- operator tools
  * fbx_convert: the pairwise conversions of operator_tools/superoperator_transformations.py
@@ -168,9 +181,12 @@ int fbx_proj_choi_dev(int proj_kind, int n_qubits, int64_t B, const double* d_ch
 
 /* project_state_matrix_to_physical (operator_tools/project_state_matrix.py:6-52). */
 int fbx_proj_state_physical(int n_qubits, int64_t B, const double* rho, double* out);
+int fbx_proj_state_physical_dev(int n_qubits, int64_t B, const double* d_rho, double* d_out);
 
 /* apply_choi_matrix_2_state (operator_tools/apply_superoperator.py:60-90): out[B][d][d]. */
 int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rho, double* out);
+int fbx_apply_choi_dev(int n_qubits, int64_t B, const double* d_choi, const double* d_rho,
+                       double* d_out);
 
 /* entanglement_fidelity / process_fidelity (distance_measures.py:271-359) on
  * Pauli-Liouville matrices [B][D][D] (real parts of tr(A^H B) / d^2): fe_out, fp_out may be
@@ -186,6 +202,9 @@ int fbx_process_fidelity_dev(int n_qubits, int64_t B, const double* d_ptm0, cons
 int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double* sigma,
                        double* purity_out, double* fidelity_out, double* trace_dist_out,
                        double* hs_ip_out);
+int fbx_state_measures_dev(int n_qubits, int64_t B, const double* d_rho, const double* d_sigma,
+                           double* d_purity_out, double* d_fidelity_out,
+                           double* d_trace_dist_out, double* d_hs_ip_out);
 
 /* ---------------------------------------------------------------- shots -> moments
  * shots_to_obs_moments (observable_estimation.py:804-853), the reduction immediately before the
@@ -229,6 +248,7 @@ int fbx_beta_resample_dev(int64_t n, int64_t R, const double* d_expect, const do
  * sqrtm_psd (calculational.py:77-91) and the spectral distance measures (distance_measures.py:153-195,440-460).
  * w_out[B][N]; v_out[B][N][N] holds the eigenvectors as columns (phases arbitrary), may be NULL. */
 int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out);
+int fbx_eigh_dev(int N, int64_t B, const double* d_a, double* d_w_out, double* d_v_out);
 
 #ifdef __cplusplus
 }
