@@ -252,7 +252,7 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         const double m1 = a1 > 1e-300 ? a1 * fast_rsqrt(a1) : 0.0, m2 = a2 > 1e-300 ? a2 * fast_rsqrt(a2) : 0.0;
         const double crit = uniform(s1 + s2 + 2.0 * m1 + 2.0 * m2);
         PH_STOP(*L.pc, 7);
-        if (crit < 1e-4) { ++it; break; }
+        if (!(crit >= 1e-4)) { ++it; break; }        // converged -- or not finite (NaN input): never spin
         old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
     }
     if (store) store->nprev = it < store->cap ? it : store->cap;

@@ -374,7 +374,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         outer_step = alpha * sqrt(uniform(wave_sum(blk_norm2(upd))));
         ++iters;
         if (mode == FBX_MODE_CONVERGE) {
-            if (old_cost - new_cost < PGDB_STOP) break;          // tomography.py:589
+            if (!(old_cost - new_cost >= PGDB_STOP)) break;      // tomography.py:589; a NaN cost also ends the loop
             if (max_iters > 0 && iters >= max_iters) break;
         }
         old_cost = new_cost;

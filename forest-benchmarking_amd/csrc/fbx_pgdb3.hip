@@ -235,7 +235,7 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         bsum_multi<6>(red6, L);
         s1 = red6[0]; s2 = red6[1]; i1r = red6[2]; i1i = red6[3]; i2r = red6[4]; i2i = red6[5];
         const double crit = s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
-        if (crit < 1e-4) { ++it; break; }
+        if (!(crit >= 1e-4)) { ++it; break; }        // converged -- or not finite (NaN input): never spin
     }
     if (store) store->nprev = it < store->cap ? it : store->cap;
     return new_state;
@@ -509,7 +509,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         ++iters;
         PH_STOP(pc, 5);
         if (mode == FBX_MODE_CONVERGE) {
-            if (old_cost - new_cost < STOP) break;
+            if (!(old_cost - new_cost >= STOP)) break;          // tomography.py:589; a NaN cost also ends the loop
             if (max_iters > 0 && iters >= max_iters) break;
         }
         old_cost = new_cost;

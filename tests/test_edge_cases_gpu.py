@@ -170,3 +170,33 @@ def test_design_with_more_than_576_settings(gpu):
     assert d.m == 740
     _check(d, e2, c2, mode="fixed", max_iters=8)
     _check(d, e2, c2)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("mode", ["converge", "fixed"])
+def test_non_finite_input_terminates_and_stays_local(gpu, mode):
+    """A NaN / Inf expectation can never satisfy the reference's stopping rules (its loops would spin);
+    here the poisoned item ends with a non-finite result and its neighbours are untouched."""
+    from fbx import synthetic, tomography
+    for n in (1, 2):
+        design, us, e, c = synthetic.process_batch(n, "pauli", 5)
+        kw = dict(mode=mode, max_iters=20 if mode == "fixed" else 0)
+        clean = tomography.pgdb_process_estimate_batch(design, e, c, **kw)
+        bad = e.copy()
+        bad[1, 3] = np.nan
+        bad[3, 0] = np.inf
+        got = tomography.pgdb_process_estimate_batch(design, bad, c, **kw)
+        assert not np.isfinite(got[1]).all() and not np.isfinite(got[3]).all()
+        for b in (0, 2, 4):
+            assert np.array_equal(got[b], clean[b])
+    # state estimator: capped by maxiter, same locality
+    design, rhos, e, c = synthetic.state_batch(2, 4, shots=200)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clean = tomography.iterative_mle_state_estimate_batch(design, e, c, maxiter=200)
+        bad = e.copy(); bad[2, 1] = np.nan
+        got = tomography.iterative_mle_state_estimate_batch(design, bad, c, maxiter=200)
+    assert not np.isfinite(got[2]).all()
+    for b in (0, 1, 3):
+        assert np.array_equal(got[b], clean[b])
