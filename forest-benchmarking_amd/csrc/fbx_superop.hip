@@ -855,12 +855,12 @@ __global__ void apply_choi_kernel(int d, long long B, const double* __restrict__
 // entanglement / process fidelity: Fe = Re tr(A^H B) / d^2 ; Fp = (d Fe + 1) / (d + 1)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-process_fidelity_kernel(int d, long long B, const double* __restrict__ a, const double* __restrict__ b,
+process_fidelity_kernel(int d, long long B, const double* __restrict__ a, int a_batched, const double* __restrict__ b,
                         double* __restrict__ fe_out, double* __restrict__ fp_out) {
     const int lane = threadIdx.x;
     const int DD = d * d * d * d;
     for (long long item = blockIdx.x; item < B; item += gridDim.x) {
-        const double* pa = a + item * (long long)DD * 2;
+        const double* pa = a + (a_batched ? item : 0) * (long long)DD * 2;      // one shared reference or one per item
         const double* pb = b + item * (long long)DD * 2;
         double acc = 0.0;
         for (int idx = lane; idx < 2 * DD; idx += 64) acc += pa[idx] * pb[idx];
@@ -871,6 +871,32 @@ process_fidelity_kernel(int d, long long B, const double* __restrict__ a, const 
             if (fp_out) fp_out[item] = (d * fe + 1.0) / (d + 1.0);
         }
     }
+}
+
+// Three qubits: the sweep is the composition of the pairwise 64 x 64 conversions (one 1024-thread
+// workgroup per item each) and the fidelity reduction -- same results as the fused kernels, unfused.
+static int launch_sweep3(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi, double* ptm,
+                         double* chi, double* fid) {
+    constexpr size_t D = 64;
+    DevBuf tmp;
+    double* ptm_buf = ptm;
+    if (fid && !ptm_buf) {
+        const int rc = tmp.alloc(sizeof(cplx) * D * D * (size_t)B);
+        if (rc) return rc;
+        ptm_buf = tmp.as<double>();
+    }
+    int rc = FBX_OK;
+    if (choi && (rc = launch_convert3(FBX_REP_KRAUS, FBX_REP_CHOI, B, kraus, K, choi))) return rc;
+    if (ptm_buf && (rc = launch_convert3(FBX_REP_KRAUS, FBX_REP_PAULI_LIOUVILLE, B, kraus, K, ptm_buf))) return rc;
+    if (chi && (rc = launch_convert3(FBX_REP_KRAUS, FBX_REP_CHI, B, kraus, K, chi))) return rc;
+    if (fid) {
+        const unsigned grid = (unsigned)(B < 8192 ? B : 8192);
+        hipLaunchKernelGGL(process_fidelity_kernel, dim3(grid), dim3(64), 0, stream(), 8, (long long)B, ptm_ref, 0, ptm_buf,
+                           (double*)nullptr, fid);
+        FBX_HIP(hipGetLastError());
+        if (tmp.p) FBX_HIP(hipStreamSynchronize(stream()));      // the scratch PTMs go away with `tmp`
+    }
+    return FBX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,18 +1037,19 @@ int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double*
 
 int fbx_kraus_sweep_dev(int n_qubits, int64_t B, int K, const double* d_kraus, const double* d_ptm_ref,
                         double* d_choi_out, double* d_ptm_out, double* d_chi_out, double* d_fid_out) {
-    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_kraus_sweep: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_kraus_sweep: n_qubits must be 1..3");
     FBX_REQUIRE(B >= 0 && K >= 1 && (B == 0 || d_kraus), "fbx_kraus_sweep: bad arguments");
     FBX_REQUIRE(!d_fid_out || d_ptm_ref, "fbx_kraus_sweep: fidelity output needs a reference PTM");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
+    if (n_qubits == 3) return launch_sweep3(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
     if (n_qubits == 1) return launch_sweep<1>(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
     return launch_sweep<2>(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
 }
 
 int fbx_kraus_sweep(int n_qubits, int64_t B, int K, const double* kraus, const double* ptm_ref,
                     double* choi_out, double* ptm_out, double* chi_out, double* fid_out) {
-    FBX_REQUIRE(n_qubits == 1 || n_qubits == 2, "fbx_kraus_sweep: this build handles 1 and 2 qubits");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_kraus_sweep: n_qubits must be 1..3");
     FBX_REQUIRE(B >= 0 && K >= 1 && (B == 0 || kraus), "fbx_kraus_sweep: bad arguments");
     FBX_REQUIRE(!fid_out || ptm_ref, "fbx_kraus_sweep: fidelity output needs a reference PTM");
     FBX_TRY(ensure_device());
@@ -1105,7 +1132,7 @@ int fbx_process_fidelity_dev(int n_qubits, int64_t B, const double* d_ptm0, cons
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const unsigned grid = (unsigned)(B < 8192 ? B : 8192);
-    hipLaunchKernelGGL(process_fidelity_kernel, dim3(grid), dim3(64), 0, stream(), 1 << n_qubits, (long long)B, d_ptm0, d_ptm1, d_fe_out, d_fp_out);
+    hipLaunchKernelGGL(process_fidelity_kernel, dim3(grid), dim3(64), 0, stream(), 1 << n_qubits, (long long)B, d_ptm0, 1, d_ptm1, d_fe_out, d_fp_out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;
 }

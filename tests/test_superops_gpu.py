@@ -92,9 +92,10 @@ def test_process_fidelity_and_apply(gpu, n):
     assert np.abs(out - g["apply_choi"]).max() < 1e-13
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_kraus_sweep_fused(gpu, n):
-    """BASELINE config 3 pipeline: kraus -> choi -> PTM -> chi + process_fidelity, one kernel."""
+    """BASELINE config 3 pipeline: kraus -> choi -> PTM -> chi + process_fidelity, one kernel (1 and 2
+    qubits; for 3 qubits the same entry point composes the pairwise 64 x 64 conversions)."""
     import ctypes
     from fbx import _lib
     g = gold(n)
@@ -110,6 +111,11 @@ def test_kraus_sweep_fused(gpu, n):
     assert np.abs(ptm - g["kraus4_ptm"]).max() < TOL
     assert np.abs(chi - g["choi2chi"]).max() < 1e-11        # reference's eigh route, CP input
     assert np.abs(fid - g["proc_fid"]).max() < 1e-13
+    # fidelity only (no matrix leaves the device) gives the same numbers
+    fid2 = np.empty(B)
+    _lib.check(_lib.lib().fbx_kraus_sweep(n, B, 4, _lib.dptr(ks.view(np.float64)), _lib.dptr(ref.view(np.float64)),
+                                          None, None, None, _lib.dptr(fid2)))
+    assert np.abs(fid2 - fid).max() < 1e-15
 
 
 def test_reference_signature_wrappers(gpu):
