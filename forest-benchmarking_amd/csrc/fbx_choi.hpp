@@ -64,7 +64,13 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
     PH_STOP(*L.pc, 2);
     // warm start: the eigenvectors of the previous projection (still in Vs) nearly diagonalise
     // this matrix, because consecutive Dykstra iterates are close
-    if (warm) jacobi_rotate_into_basis<D>(L.Ms, L.Vs, (cplx*)L.Mw, lane);
+    if (warm) {
+#ifndef FBX_ROTATE_VALU
+        if constexpr (D == 16) jacobi_rotate_into_basis_mfma16(L.Ms, L.Vs, lane);
+        else
+#endif
+            jacobi_rotate_into_basis<D>(L.Ms, L.Vs, (cplx*)L.Mw, lane);
+    }
     sweeps += jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane, !warm);
     PH_STOP(*L.pc, 0);
     if (lane < D) {

@@ -457,6 +457,52 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     FBX_WAVE_SYNC();
 }
 
+// The same warm-start transform for N = 16 on one full wavefront, on the fp64 matrix cores.  The two
+// 16 x 16 x 16 complex products are four real v_mfma_f64_16x16x4_f64 chains each (lane l feeds
+// A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; accumulator r is D[(l >> 4) + 4 r][l & 15]).
+// With T = H V accumulated first, the operands of M' = V^H T are already in place: conj(V[k][i]) is
+// the V element loaded as B operand of the first product, and T[4 k4 + (l >> 4)][l & 15] is
+// accumulator k4 of this lane.  8 LDS loads + 4 stores per lane instead of 128 + 8 for the
+// register-blocked VALU form, which is LDS-bandwidth bound with four wavefronts per CU.
+#ifndef FBX_ROTATE_VALU
+typedef double fbx_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void jacobi_rotate_into_basis_mfma16(cplx* Ms, const cplx* Vs, int lane) {
+    constexpr int NB = 8, LS = 64;
+    const int c = lane & 15, g = lane >> 4;
+    auto at = [](int r, int cc) { return ((r & 1) * 2 + (cc & 1)) * LS + (r >> 1) * NB + (cc >> 1); };
+    cplx h[4], v[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        const int k = 4 * k4 + g;
+        h[k4] = Ms[at(c, k)];            // H[i = c][k]
+        v[k4] = Vs[at(k, c)];            // V[k][j = c]  (= V[k][i = c] of the second product)
+    }
+    fbx_v4d tre = {0.0, 0.0, 0.0, 0.0}, tim = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {     // T = H V
+        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(h[k4].re, v[k4].re, tre, 0, 0, 0);
+        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(h[k4].re, v[k4].im, tim, 0, 0, 0);
+        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(-h[k4].im, v[k4].im, tre, 0, 0, 0);
+        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(h[k4].im, v[k4].re, tim, 0, 0, 0);
+    }
+    fbx_v4d mre = {0.0, 0.0, 0.0, 0.0}, mim = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {     // M' = V^H T: conj(v) * t
+        mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v[k4].re, tre[k4], mre, 0, 0, 0);
+        mim = __builtin_amdgcn_mfma_f64_16x16x4f64(v[k4].re, tim[k4], mim, 0, 0, 0);
+        mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v[k4].im, tim[k4], mre, 0, 0, 0);
+        mim = __builtin_amdgcn_mfma_f64_16x16x4f64(-v[k4].im, tre[k4], mim, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = g + 4 * r;
+        cplx o; o.re = mre[r]; o.im = row == c ? 0.0 : mim[r];
+        Ms[at(row, c)] = o;
+    }
+    FBX_WAVE_SYNC();
+}
+#endif
+
 template <int N, int NT = 64>
 __device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, int lane,
                                                bool init_identity = true, double* red = nullptr) {

@@ -32,6 +32,12 @@ constexpr double PGDB_EPS = 1e-6;     // probability clip, tomography.py:597,613
 constexpr double PGDB_GAMMA = 0.3;    // tomography.py:567
 constexpr double PGDB_STOP = 1e-10;   // tomography.py:589
 constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
+#ifndef FBX_DBG_NOLADDER
+#define FBX_DBG_NOLADDER 0
+#endif
+#ifndef FBX_SMALL_STEP_LIMIT
+#define FBX_SMALL_STEP_LIMIT 0x1p-3      // alpha * max |pu / pe| below which the line search uses the power-sum series
+#endif
 
 template <int NQ>
 struct PgdbLds {
@@ -176,6 +182,9 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     FBX_WAVE_SYNC();
 
     int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
+#ifdef FBX_DEBUG_LS
+    int ls_full = 0;
+#endif
     // eigenvector bases of the previous outer iteration's Dykstra run (fbx_choi.hpp BasisStore)
     BasisStore basis;
     basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
@@ -306,13 +315,15 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         // The near-clip outcomes are few and scattered over lanes and slots: they are compacted into
         // one entry per lane (through LDS -- the Jacobi work area is idle during the line search), so
         // an evaluation costs one clipped log per lane instead of one per flagged slot and sign.
-        constexpr int CL_MAX = 64;
+        // the list lives in the Jacobi work area (Ms + Vs, idle during the line search): 4 rows of CL_MAX doubles
+        constexpr int CL_MAX = (2 * sizeof(cplx) * D * D) / (4 * sizeof(double)) < 64 ? (int)((2 * sizeof(cplx) * D * D) / (4 * sizeof(double))) : 64;
+        static_assert(4 * CL_MAX * sizeof(double) <= 2 * sizeof(cplx) * D * D, "compact list must fit into Ms + Vs");
         double clip_pe = 1.0, clip_pu = 0.0, clip_n = 0.0;       // this lane's entry of the compact list
         bool clip_listed = false;
         double clip_base = 0.0;
+        int n_clip = 0;
         if (near_clip) {
-            double* cl = (double*)L.choi.Ms;                     // [3][CL_MAX]
-            int n_clip = 0;
+            double* cl = (double*)L.choi.Ms;                     // [4][CL_MAX]: pe, pu, n, n log(clip(pe))
             const unsigned long long below = (1ull << lane) - 1ull;
             FBX_WAVE_SYNC();
 #pragma unroll
@@ -334,27 +345,56 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             if (clip_listed) {
                 if (lane < n_clip) { clip_pe = cl[lane]; clip_pu = cl[CL_MAX + lane]; clip_n = cl[2 * CL_MAX + lane]; }
                 clip_base = clip_n * fast_log_pos(clip_pe < PGDB_EPS ? PGDB_EPS : clip_pe);
+                if (lane < n_clip) cl[3 * CL_MAX + lane] = clip_base;       // for the one-pass ladder below
             }                                                    // more than CL_MAX of them: full evaluations only
             FBX_WAVE_SYNC();
         }
-        auto log1p_small = [](double x) __attribute__((always_inline)) -> double {
-            double q = fma(x, -1.0 / 6.0, 0.2);
-            q = fma(x, q, -0.25);
-            q = fma(x, q, 1.0 / 3.0);
-            q = fma(x, q, -0.5);
-            q = fma(x, q, 1.0);
-            return x * q;
-        };
         auto clipped_log = [](double p) __attribute__((always_inline)) -> double { return fast_log_pos(p < PGDB_EPS ? PGDB_EPS : p); };
-        auto cost_step = [&](double alpha) __attribute__((always_inline)) -> double {
-            if (!(small_ok && (near_clip == 0u || clip_listed) && alpha * rmax < 0x1p-9)) return cost_at(alpha);
-            double acc = 0.0;
+        // sum_o n_o log1p(alpha r_o) = sum_k c_k alpha^k S_k with the power sums S_k = sum_o n_o r_o^k,
+        // c_k = (-1)^(k+1) / k, reduced ONCE per outer iteration (on the first small step): every further
+        // halving is a Horner evaluation (+ the clipped logs of the listed outcomes) instead of a pass
+        // over all outcomes.  Degree 16 below alpha rmax = 2^-3: remainder < 2^-51 / 17 per unit of n,
+        // below the rounding of the exact evaluation.
+        constexpr int NS = 16;
+        double Sk[NS];
+        bool have_sums = false;
+        auto small_regime = [&](double alpha) __attribute__((always_inline)) -> bool {
+            return small_ok && (near_clip == 0u || clip_listed) && alpha * rmax < FBX_SMALL_STEP_LIMIT;
+        };
+        auto series = [&](double alpha) __attribute__((always_inline)) -> double {      // alpha may differ per lane
+            double q = Sk[NS - 1];
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j)
-                acc += npl[j] * log1p_small(alpha * rp[j]) + nmi[j] * log1p_small(alpha * rm[j]);
+            for (int k = NS - 2; k >= 0; --k) q = fma(alpha, q, Sk[k]);
+            return alpha * q;
+        };
+        auto cost_step = [&](double alpha) __attribute__((always_inline)) -> double {
+            if (!small_regime(alpha)) {
+#ifdef FBX_DEBUG_LS
+                ++ls_full;
+#endif
+                return cost_at(alpha);
+            }
+            if (!have_sums) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Sk[k] = 0.0;
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {
+#pragma unroll
+                    for (int sg = 0; sg < 2; ++sg) {
+                        const double x = sg ? rm[j] : rp[j];
+                        double t = (sg ? nmi[j] : npl[j]) * x;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) { Sk[k] += t; t *= x; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Sk[k] = uniform(wave_sum(Sk[k])) * ((k & 1) ? -1.0 : 1.0) / (double)(k + 1);
+                have_sums = true;
+            }
+            double acc = series(alpha);
             if (near_clip)                   // the listed outcomes: exact difference of clipped logs
-                acc += clip_n * clipped_log(fma(alpha, clip_pu, clip_pe)) - clip_base;
-            return old_cost - uniform(wave_sum(acc));
+                acc += uniform(wave_sum(clip_n * clipped_log(fma(alpha, clip_pu, clip_pe)) - clip_base));
+            return old_cost - acc;
         };
 #else
         auto cost_step = [&](double alpha) -> double { return cost_at(alpha); };
@@ -362,9 +402,40 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         double alpha = 1.0;
         new_cost = cost_step(alpha);
         double change = PGDB_GAMMA * alpha * ipr;
+#ifndef FBX_NO_SMALL_STEP
+        int small_fails = 0;
+#endif
         while (new_cost > old_cost + change) {
+#ifndef FBX_NO_SMALL_STEP
+            // Two series evaluations in a row have failed: this is one of the long halving runs of a
+            // stalled iteration.  The rest of the ladder alpha 2^-L, L = 1, 2, ... is evaluated in ONE pass,
+            // lane L taking its own alpha (same series; the listed outcomes, one per lane so far, are
+            // walked from their LDS list by every lane), and the first L that the sequential loop would
+            // have stopped at -- sufficient decrease, or alpha below the floor -- is taken.
+            if (small_fails >= 2 && !FBX_DBG_NOLADDER) {
+                const double a_l = __builtin_ldexp(alpha, -lane), c_l = __builtin_ldexp(change, -lane);
+                double acc = series(a_l);
+                if (near_clip) {
+                    const double* cl = (const double*)L.choi.Ms;
+                    for (int e = 0; e < n_clip; ++e) {
+                        const double pe = cl[e], pu = cl[CL_MAX + e], nn = cl[2 * CL_MAX + e];
+                        acc += nn * clipped_log(fma(a_l, pu, pe)) - cl[3 * CL_MAX + e];
+                    }
+                }
+                const double val = old_cost - acc;
+                const unsigned long long stop = __ballot(lane >= 1 && (a_l < PGDB_ALPHA_MIN || !(val > old_cost + c_l)));
+                const int Ls = __builtin_ctzll(stop);          // alpha <= 1: lane 50 is below the floor at the latest
+                alpha = __builtin_ldexp(alpha, -Ls); change = __builtin_ldexp(change, -Ls);
+                new_cost = uniform(__shfl(val, Ls));
+                backtracks += Ls;
+                break;
+            }
+#endif
             alpha *= 0.5;
             change *= 0.5;
+#ifndef FBX_NO_SMALL_STEP
+            if (small_regime(alpha)) ++small_fails;
+#endif
             new_cost = cost_step(alpha);
             ++backtracks;
             if (alpha < PGDB_ALPHA_MIN) break;
@@ -390,6 +461,9 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             o[0] = est.re[e]; o[1] = est.im[e];
         }
     }
+#ifdef FBX_DEBUG_LS
+    sweeps = ls_full;
+#endif
     if (lane == 0) {
         if (iters_out) iters_out[item] = iters;
         if (dykstra_out) dykstra_out[item] = dyk;

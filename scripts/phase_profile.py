@@ -23,6 +23,7 @@ names = ['jacobi', 'reconstruct', 'hermitize+wait', 'transforms', 'gradient', 'l
 tot = ph.sum(1)
 print('B', B, mode, 'time %.1f ms' % (1e3 * dt), 'recon/s %.0f' % (B / dt))
 print('cycles/item mean %.3e max %.3e' % (tot.mean(), tot.max()))
+print('slowest items', np.argsort(-tot)[:6], (np.sort(tot)[::-1][:6] / 1e6).round(1), 'Mcycles; p50 %.1f p90 %.1f p99 %.1f' % tuple(np.percentile(tot, [50, 90, 99]) / 1e6))
 for i, n in enumerate(names):
     print('  %-14s mean %.3e (%.1f%%)  max-item share %.3e' % (n, ph[:, i].mean(), 100 * ph[:, i].sum() / tot.sum(), ph[tot.argmax(), i]))
 print('per eigh jacobi cycles %.0f ; dykstra iters mean %.1f max %d; backtracks mean %.1f max %d' % (
