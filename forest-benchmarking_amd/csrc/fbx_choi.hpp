@@ -177,6 +177,19 @@ struct BasisStore {
     int cap;          // slots
     int nprev;        // slots that hold a basis of the previous call
     bool use_prev;    // outer step small: prefer the previous call's basis over the previous iteration's
+    // one basis in flight from HBM to registers (single-wavefront kernels, D <= 16: 16 B per lane and u)
+    cplx pf[4];
+    int pf_slot = -1; // slot the registers hold / are waiting for, -1: none
+    template <int DD>
+    __device__ __forceinline__ void prefetch(int slot, int lane) {
+        const fbx_global_cplx_ptr src = (fbx_global_cplx_ptr)(g + (size_t)slot * DD);
+#pragma unroll
+        for (int u = 0; u < (DD + 63) / 64; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < DD) { const fbx_v2d w = src[idx]; pf[u].re = w.x; pf[u].im = w.y; }
+        }
+        pf_slot = slot;
+    }
 };
 
 template <int NQ>
@@ -186,9 +199,11 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
     constexpr int DD = ChoiLds<NQ>::D * ChoiLds<NQ>::D;
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
+    // (the caller passes the address of a local BasisStore unconditionally -- a pointer chosen at run time
+    // would keep the in-flight registers of the store in scratch memory)
+    const bool have_store = store != nullptr && store->g != nullptr;
     constexpr int PF = (DD + 63) / 64;         // 16-byte loads per lane for one basis
-    cplx pf[PF];                               // basis of the NEXT iteration, fetched while this one finishes
-    bool have_pf = false;
+    static_assert(PF <= 4, "BasisStore::pf holds one basis of at most 256 entries");
     int it = 0;
     for (; it < max_iter; ++it) {
         ++iters;
@@ -196,38 +211,27 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         bool warm = FBX_WARM_START && it > 0;
         bool from_slot = false;
         const int sweeps_before = sweeps;
-        if (FBX_WARM_START && store && it < store->nprev && (it == 0 || store->use_prev)) {
+        if (FBX_WARM_START && have_store && it < store->nprev && (it == 0 || store->use_prev)) {
             from_slot = true;
             FBX_WAVE_SYNC();
-            if (!have_pf) {                                       // nothing in flight (first iteration): fetch now
-                const fbx_global_cplx_ptr src = (fbx_global_cplx_ptr)(store->g + (size_t)it * DD);
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int idx = lane + 64 * u;
-                    if (idx < DD) { const fbx_v2d w = src[idx]; pf[u].re = w.x; pf[u].im = w.y; }
-                }
-            }
+            if (store->pf_slot != it) store->template prefetch<DD>(it, lane);      // nothing in flight: fetch now
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int idx = lane + 64 * u;
-                if (idx < DD) L.Vs[idx] = pf[u];
+                if (idx < DD) L.Vs[idx] = store->pf[u];
             }
+            store->pf_slot = -1;
+#ifdef FBX_DBG_WAITPHASE
+            PH_STOP(*L.pc, 7);
+#endif
             warm = true;
         }
+        // the basis of the NEXT iteration is requested before this iteration's decomposition, so that
+        // its HBM / L2 latency lies behind the Jacobi sweeps
+        if (FBX_WARM_START && have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
+            store->template prefetch<DD>(it + 1, lane);
         const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm);
-        have_pf = false;
-        if (FBX_WARM_START && store && it < store->cap) {
-            // loads of the next basis first, stores of this one behind them: vector memory returns in
-            // issue order, so consuming the loads next iteration never waits for the stores
-            if (store->use_prev && it + 1 < store->nprev) {      // overlaps the TP projection and the stop test
-                const fbx_global_cplx_ptr nxt = (fbx_global_cplx_ptr)(store->g + (size_t)(it + 1) * DD);
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int idx = lane + 64 * u;
-                    if (idx < DD) { const fbx_v2d w = nxt[idx]; pf[u].re = w.x; pf[u].im = w.y; }
-                }
-                have_pf = true;
-            }
+        if (FBX_WARM_START && have_store && it < store->cap) {
             // every basis is written back (4 KB per decomposition, ~2 GB per 1024-item launch = 1 % of
             // the HBM bandwidth): writing only the slots the next call is predicted to use measured
             // 2 % slower, the first small step then finds part of its trajectory without a basis
@@ -261,7 +265,7 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
         if (!(crit >= 1e-4)) { ++it; break; }        // converged -- or not finite (NaN input): never spin
         old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
     }
-    if (store) store->nprev = it < store->cap ? it : store->cap;
+    if (have_store) { store->nprev = it < store->cap ? it : store->cap; store->pf_slot = -1; }
     return new_state;
 }
 

@@ -46,13 +46,19 @@ struct PgdbLds {
     double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
     double* Tupd;   // [S*D]  same for the update direction; reused as Wt[S][D] in the gradient
     double* Cl;     // [S*D]  Bloch coefficients of the input states, one state per row: Cl[s * D + j] = C[j][s]
-    static size_t bytes(int S, int /*m*/) {
+    double* Ln;     // [2*ceil(m/64)][64]  normalised counts n+ / n- of this lane's outcomes (row 2 j + sign): item
+                    // constants that are only read by the cost / gradient passes -- kept here, not in 36 registers
+    // Rb and Tupd are adjacent: both are dead while the projection runs, and together (>= 16 D^2 bytes,
+    // Tupd is sized for at least D states) they park the gradient block of every lane meanwhile
+    static size_t bytes(int S, int m) {
         constexpr int D = ChoiLds<NQ>::D;
-        return ((ChoiLds<NQ>::bytes() + 15) & ~(size_t)15) + sizeof(double) * ((size_t)D * D + 3 * (size_t)S * D) + 64;
+        const size_t Su = S > D ? S : D;
+        return ((ChoiLds<NQ>::bytes() + 15) & ~(size_t)15) +
+               sizeof(double) * ((size_t)D * D + (Su + 2 * (size_t)S) * D + 2 * (size_t)((m + 63) / 64) * 64) + 64;
     }
     // every pointer is a plain offset from the start of the dynamic LDS segment (no conditional
     // layout), so the compiler keeps them in the LDS address space (ds_* instead of flat_*)
-    __device__ void carve(char* p, int S, int /*m*/) {
+    __device__ void carve(char* p, int S, int m) {
         constexpr int D = ChoiLds<NQ>::D;
         char* q = p;
         choi.carve(q);
@@ -61,9 +67,10 @@ struct PgdbLds {
         constexpr size_t aligned = (ChoiLds<NQ>::bytes() + 15) & ~(size_t)15;
         p += aligned;
         Rb = (double*)p; p += sizeof(double) * D * D;
+        Tupd = (double*)p; p += sizeof(double) * (S > D ? S : D) * D;
         Test = (double*)p; p += sizeof(double) * S * D;
-        Tupd = (double*)p; p += sizeof(double) * S * D;
         Cl = (double*)p; p += sizeof(double) * D * S;
+        Ln = (double*)p; p += sizeof(double) * 2 * ((m + 63) / 64) * 64;
     }
 };
 
@@ -106,28 +113,35 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     const long long item = blockIdx.x;
     const int m = des.m, S = des.S;
     PgdbLds<NQ> L;
-    L.carve(smem, S, m);
+    L.carve(smem, S, 64 * MAXJ);
 
     for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
 
     // ---- data: n+-[k] = counts * (1 +- e)/2 / grand_total   (tomography.py:528-538)
-    double npl[MAXJ], nmi[MAXJ];
     double tot = 0.0;
+    {
+        double npl[MAXJ], nmi[MAXJ];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int g = lane + 64 * j;
-        npl[j] = 0.0; nmi[j] = 0.0;
-        if (g < m) {
-            const int k = des.order[g];
-            const double e = expect[item * m + k], c = counts[item * m + k];
-            const double plus = (1.0 + e) / 2.0;
-            npl[j] = c * plus; nmi[j] = c * (1.0 - plus);
-            tot += c;
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = lane + 64 * j;
+            npl[j] = 0.0; nmi[j] = 0.0;
+            if (g < m) {
+                const int k = des.order[g];
+                const double e = expect[item * m + k], c = counts[item * m + k];
+                const double plus = (1.0 + e) / 2.0;
+                npl[j] = c * plus; nmi[j] = c * (1.0 - plus);
+                tot += c;
+            }
+        }
+        tot = uniform(wave_sum(tot));
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
         }
     }
-    tot = uniform(wave_sum(tot));
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) { npl[j] /= tot; nmi[j] /= tot; }
+    FBX_WAVE_SYNC();
+#define NPL(j) (L.Ln[(2 * (j)) * 64 + lane])
+#define NMI(j) (L.Ln[(2 * (j) + 1) * 64 + lane])
 
     const double half_dd = 0.5 / (double)(d * d);      // 1 / (2 d^2)
     const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
@@ -145,16 +159,20 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     double pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
-    auto load_probs = [&](const double* T, double (&pp)[MAXJ], double (&pm)[MAXJ]) {
+    // (every slot is assigned -- `missing` for lanes without an outcome -- so that the arrays are dead
+    // between two calls and do not occupy registers across the projection)
+    auto load_probs = [&](const double* T, double (&pp)[MAXJ], double (&pm)[MAXJ], double missing) {
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
+            double a = missing, b = missing;
             if (g < m) {
                 const int s = spw[j] >> 16, p = spw[j] & 0xffff;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
                 const double tr = T[s * D], ex = cf * T[s * D + p];
-                pp[j] = (tr + ex) * half_dd; pm[j] = (tr - ex) * half_dd;
+                a = (tr + ex) * half_dd; b = (tr - ex) * half_dd;
             }
+            pp[j] = a; pm[j] = b;
         }
     };
     // negative log-likelihood at est + alpha * update (tomography.py:597-614)
@@ -167,7 +185,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 double pp = fma(alpha, pup[j], pep[j]), pm = fma(alpha, pum[j], pem[j]);
                 pp = pp < PGDB_EPS ? PGDB_EPS : pp;
                 pm = pm < PGDB_EPS ? PGDB_EPS : pm;
-                acc -= npl[j] * fast_log_pos(pp) + nmi[j] * fast_log_pos(pm);
+                acc -= NPL(j) * fast_log_pos(pp) + NMI(j) * fast_log_pos(pm);
             }
         }
         return uniform(wave_sum(acc));
@@ -197,6 +215,13 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
+        // the cross-iteration bases are dropped every 16 iterations to bound the accumulated loss of
+        // unitarity (~1e-16 per rotation); the first basis of this iteration's projection is requested
+        // now, so that it arrives behind the gradient
+        if ((iters & FBX_BASIS_RESET_MASK) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
+#ifndef FBX_NO_VFIRST
+        if (basis.g && basis.nprev > 0 && FBX_WARM_START) basis.template prefetch<D * D>(0, lane);
+#endif
         // ---- prediction table of the current estimate
         FBX_WAVE_SYNC();
         blk_store<D, LD>(L.choi.Mw, lane, est);
@@ -207,7 +232,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
         FBX_WAVE_SYNC();
         PH_STOP(pc, 7);
-        load_probs(L.Test, pep, pem);
+        load_probs(L.Test, pep, pem, 1.0);
         if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }   // tomography.py:565
 
         // ---- gradient (tomography.py:617-633): eta = n / clip(p); per input state s the weights of the
@@ -223,7 +248,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             if (g < m) {
                 const double pp = pep[j] < PGDB_EPS ? PGDB_EPS : pep[j];
                 const double pm = pem[j] < PGDB_EPS ? PGDB_EPS : pem[j];
-                const double ep = npl[j] / pp, em = nmi[j] / pm;
+                const double ep = NPL(j) / pp, em = NMI(j) / pm;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
                 const int st = spw[j] >> 16, p = spw[j] & 0xffff;
                 atomicAdd(&Wt[st * D], 0.5 * (ep + em));
@@ -251,23 +276,39 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             }
         }
         FBX_WAVE_SYNC();
-        const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, L.choi.Mw, lane);
-        PH_STOP(pc, 4);
-
-        // ---- projected step (tomography.py:572)
-        const Blk x = blk_axpy(est, -inv_mu, grad);
-        // the cross-iteration bases are dropped every 16 iterations to bound the accumulated loss of
-        // unitarity (~1e-16 per rotation); below a step of 1e-3 the previous run's trajectory is closer
-        // to this one than consecutive Dykstra iterates are to each other (those stop at ~1e-2)
-        if ((iters & FBX_BASIS_RESET_MASK) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
+        Blk x;
+        {
+            const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, L.choi.Mw, lane);
+            PH_STOP(pc, 4);
+            // ---- projected step (tomography.py:572)
+            x = blk_axpy(est, -inv_mu, grad);
+            // the gradient is needed again after the projection (inner product with the update): parked in
+            // Rb + Tupd, not in 16 registers across the Dykstra loop
+            FBX_WAVE_SYNC();
+            if (lane < NACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { L.Rb[(2 * e) * NACT + lane] = grad.re[e]; L.Rb[(2 * e + 1) * NACT + lane] = grad.im[e]; }
+            }
+            FBX_WAVE_SYNC();
+        }
+        // below a step of 1e-3 the previous run's trajectory is closer to this one than consecutive
+        // Dykstra iterates are to each other (those stop at ~1e-2)
         basis.use_prev = outer_step < FBX_BASIS_STEP;
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
 #ifdef FBX_NO_VFIRST
                                                nullptr);
 #else
-                                               basis.g ? &basis : nullptr);
+                                               &basis);
 #endif
         const Blk upd = blk_sub(proj, est);
+        Blk grad = blk_zero();
+        if (lane < NACT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { grad.re[e] = L.Rb[(2 * e) * NACT + lane]; grad.im[e] = L.Rb[(2 * e + 1) * NACT + lane]; }
+        }
+        double ipr, ipi;
+        blk_dotc(upd, grad, ipr, ipi);
+        ipr = uniform(wave_sum(ipr));
         PH_STOP(pc, 2);
 
         // ---- prediction table of the update direction
@@ -278,12 +319,10 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         FBX_WAVE_SYNC();
         predict_table<NQ>(L.Rb, L.Cl, L.Tupd, S, lane);
         FBX_WAVE_SYNC();
-        load_probs(L.Tupd, pup, pum);
+        load_probs(L.Test, pep, pem, 1.0);      // again: not kept in registers across the projection
+        load_probs(L.Tupd, pup, pum, 0.0);
         PH_STOP(pc, 3);
         // ---- backtracking line search (tomography.py:575-585)
-        double ipr, ipi;
-        blk_dotc(upd, grad, ipr, ipi);
-        ipr = uniform(wave_sum(ipr));
 #ifndef FBX_NO_SMALL_STEP
         // Small steps: cost(alpha) = cost(0) - sum n log1p(alpha pu / pe), and cost(0) is old_cost.
         // Once alpha |pu / pe| < 2^-9 for every outcome (and nothing sits at the clip), log1p is a
@@ -300,13 +339,11 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         auto exact = [](double pu, double pe) __attribute__((always_inline)) -> bool {
             return pe < 2.0 * PGDB_EPS || fabs(pu) > pe;
         };
-        double rmax = 0.0;
-        double rp[MAXJ], rm[MAXJ];           // pu / pe per outcome (0 for the listed ones), kept for the evaluations
+        double rmax = 0.0;                   // max |pu / pe| over the outcomes that are not listed
         uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            rp[j] = ratio(pup[j], pep[j]); rm[j] = ratio(pum[j], pem[j]);
-            rmax = fmax(rmax, fmax(fabs(rp[j]), fabs(rm[j])));
+            rmax = fmax(rmax, fmax(fabs(ratio(pup[j], pep[j])), fabs(ratio(pum[j], pem[j]))));
             if (__ballot(exact(pup[j], pep[j]))) near_clip |= 1u << (2 * j);
             if (__ballot(exact(pum[j], pem[j]))) near_clip |= 2u << (2 * j);
         }
@@ -331,7 +368,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
                     if (near_clip & ((1u + sg) << (2 * j))) {
-                        const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? nmi[j] : npl[j];
+                        const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? NMI(j) : NPL(j);
                         const bool f = exact(pu, pe);
                         const unsigned long long mk = __ballot(f);
                         const int pos = n_clip + __popcll(mk & below);
@@ -381,8 +418,8 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 for (int j = 0; j < MAXJ; ++j) {
 #pragma unroll
                     for (int sg = 0; sg < 2; ++sg) {
-                        const double x = sg ? rm[j] : rp[j];
-                        double t = (sg ? nmi[j] : npl[j]) * x;
+                        const double x = sg ? ratio(pum[j], pem[j]) : ratio(pup[j], pep[j]);   // recomputed: not kept live
+                        double t = (sg ? NMI(j) : NPL(j)) * x;
 #pragma unroll
                         for (int k = 0; k < NS; ++k) { Sk[k] += t; t *= x; }
                     }
@@ -492,7 +529,7 @@ template <int NQ, int MAXJ>
 static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                        int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
                        double* cost) {
-    const size_t lds = PgdbLds<NQ>::bytes(des->dev.S, des->dev.m);
+    const size_t lds = PgdbLds<NQ>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
     if (lds > 160 * 1024) {
         set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
         return FBX_ERR_UNSUPPORTED;
