@@ -397,15 +397,15 @@ def main():
                        "mean_dykstra_iters": float(dyk.mean()),
                        "mean_backtracks": float(bt.mean()),
                        "mean_outer_iters": float(iters.mean())},
-            "roofline": {"bound": "mfma", "pipe": "fp64 VALU", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS,
                          "traffic": traffic,
                          "kernel": "pgdb_kernel<2,9>", "kernel_ms": 1e3 * kernel_s,
                          "note": "PGDB is fp64-compute bound (SURVEY.md 8d): achieved = "
                                  "0.77 GFLOP algorithmic (dense-A formulation) x batch / HIP-event "
                                  "kernel time; peak = dense fp64 MFMA peak of MI355X, which equals its fp64 "
-                                 "vector peak -- the kernel's flops are VALU FMAs (no GEMM with K >= 16 "
-                                 "on the 2-qubit path)",
+                                 "vector peak -- the Jacobi rotations are VALU FMAs, the warm-start "
+                                 "basis change of every eigendecomposition runs on the fp64 MFMA pipe",
                          "hbm": {"achieved": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9 / HBM_PEAK_GBS}},
