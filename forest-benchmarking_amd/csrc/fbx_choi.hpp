@@ -49,7 +49,8 @@ struct ChoiLds {
 // project_superoperators.py:19-34.  `x` need not be Hermitian.  `sweeps` accumulates Jacobi
 // sweeps (diagnostics).
 template <int NQ>
-__device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, bool warm = false) {
+__device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, bool warm = false,
+                       bool check_basis = false) {
     constexpr int D = ChoiLds<NQ>::D;
     FBX_WAVE_SYNC();                       // previous readers of Ms / Vs are done
     sys_store<D>(L.Ms, lane, x);
@@ -64,6 +65,13 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
     PH_STOP(*L.pc, 2);
     // warm start: the eigenvectors of the previous projection (still in Vs) nearly diagonalise
     // this matrix, because consecutive Dykstra iterates are close
+    // A basis that came from the HBM store is only trusted after the change of basis: a unitary
+    // similarity preserves the Frobenius norm, anything else (a damaged or torn slot) does not -- then
+    // the matrix is restored and the decomposition starts from the identity.  For the single-wavefront
+    // 16 x 16 solver the test rides on its first off-norm reduction (one extra wave reduction here, which
+    // overlaps the matrix-core products).
+    double hn2 = -1.0;
+    if (warm && check_basis) hn2 = uniform(wave_sum(blk_norm2(h)));
     if (warm) {
 #ifndef FBX_ROTATE_VALU
         if constexpr (D == 16) jacobi_rotate_into_basis_mfma16(L.Ms, L.Vs, lane);
@@ -71,7 +79,34 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
 #endif
             jacobi_rotate_into_basis<D>(L.Ms, L.Vs, (cplx*)L.Mw, lane);
     }
-    sweeps += jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane, !warm);
+    int sw;
+#ifndef FBX_JACOBI_NO_PIPELINE
+    if constexpr (D == 16) {
+        sw = jacobi_eigh_wave<D>(L.Ms, L.Vs, lane, !warm, hn2);
+    } else
+#endif
+    {
+        if (warm && check_basis) {
+            constexpr int LS = (D / 2) * (D / 2);
+            double mn2 = 0.0;
+            if (lane < LS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * LS + lane]; mn2 = fma(v.re, v.re, fma(v.im, v.im, mn2)); }
+            }
+            mn2 = uniform(wave_sum(mn2));
+            sw = (fabs(mn2 - hn2) <= FBX_BASIS_NORM_TOL * hn2) ? jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane, false) : -1;
+        } else sw = jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane, !warm);
+    }
+    if (sw < 0) {                              // rejected basis: cold start on the restored matrix
+        FBX_WAVE_SYNC();
+        sys_store<D>(L.Ms, lane, h);
+        FBX_WAVE_SYNC();
+        sw = jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane, true);
+#ifdef FBX_DEBUG_REJECT
+        sweeps += 1000000;
+#endif
+    }
+    sweeps += sw;
     PH_STOP(*L.pc, 0);
     if (lane < D) {
         const double l = L.Ms[sys_index<D>(lane, lane)].re;
@@ -224,13 +259,16 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
 #ifdef FBX_DBG_WAITPHASE
             PH_STOP(*L.pc, 7);
 #endif
+#ifdef FBX_DBG_CORRUPT_BASIS                   // test hook: damage every basis loaded for Dykstra iteration 1
+            if (it == 1 && lane < 3) L.Vs[17 * lane].re += 0.25;
+#endif
             warm = true;
         }
         // the basis of the NEXT iteration is requested before this iteration's decomposition, so that
         // its HBM / L2 latency lies behind the Jacobi sweeps
         if (FBX_WARM_START && have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
             store->template prefetch<DD>(it + 1, lane);
-        const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm);
+        const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm, from_slot);
         if (FBX_WARM_START && have_store && it < store->cap) {
             // every basis is written back (4 KB per decomposition, ~2 GB per 1024-item launch = 1 % of
             // the HBM bandwidth): writing only the slots the next call is predicted to use measured

@@ -163,7 +163,10 @@ constexpr int FBX_JACOBI_MAX_SWEEPS = 40;
 #ifndef FBX_JACOBI_TOL2_VALUE
 #define FBX_JACOBI_TOL2_VALUE 1e-26
 #endif
-constexpr double FBX_JACOBI_TOL2 = FBX_JACOBI_TOL2_VALUE;   // stop when off(A)^2 <= TOL2 * ||A||_F^2
+constexpr double FBX_JACOBI_TOL2 = FBX_JACOBI_TOL2_VALUE;
+#ifndef FBX_BASIS_NORM_TOL
+#define FBX_BASIS_NORM_TOL 1e-9      // relative change of ||.||_F^2 under a stored basis above which it is discarded
+#endif   // stop when off(A)^2 <= TOL2 * ||A||_F^2
 
 // Rotation helpers ----------------------------------------------------------------------------
 // Rotation R = [[c, s], [-conj(s), c]] that diagonalises the Hermitian pivot [[a, b], [conj(b), d]]
@@ -247,7 +250,8 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 // one wavefront execute in program order, so no barrier or wait separates the rounds.
 #ifndef FBX_JACOBI_NO_PIPELINE
 template <int N>
-__device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity) {
+__device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
+                                double expect_n2 = -1.0) {
     constexpr int NB = N / 2, LS = NB * NB;
     static_assert(LS == 64, "every lane of the wavefront owns one 2x2 block");
     const int I = lane / NB, J = lane % NB;
@@ -288,6 +292,9 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
             }
             o2 = uniform(wave_sum(o2));
             n2 = uniform(wave_sum(n2));
+            // expect_n2 >= 0: the matrix was brought into a basis loaded from memory; a unitary similarity
+            // keeps ||.||_F^2 (here to FBX_BASIS_NORM_TOL), a damaged basis does not -> tell the caller (-1)
+            if (sweep == 0 && expect_n2 >= 0.0 && !(fabs(n2 - expect_n2) <= FBX_BASIS_NORM_TOL * expect_n2)) return -1;
             if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
