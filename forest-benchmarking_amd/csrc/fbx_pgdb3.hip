@@ -111,7 +111,8 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
 }
 
 // ---- CP projection (project_superoperators.py:19-34)
-__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr) {
+__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr,
+                       bool check_basis = false) {
     __syncthreads();
     sys_store<D>(L.Ms, t, x);
     __syncthreads();
@@ -123,7 +124,25 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
     sys_store<D>(L.Ms, t, h);
     __syncthreads();
     PH_STOP(*L.pc, 2);
-    if (warm) rotate_into_basis(L, Tg, t);
+    if (warm) {
+        // a basis loaded from the store is only trusted if the change of basis kept ||.||_F^2 (unitary
+        // similarity); otherwise the matrix is restored and the decomposition starts from the identity
+        // (same guard as proj_cp_blk, fbx_choi.hpp)
+        double n2[2] = {0.0, 0.0};
+        if (check_basis) n2[0] = blk_norm2(h);
+        rotate_into_basis(L, Tg, t);
+        if (check_basis) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * NT + t]; n2[1] = fma(v.re, v.re, fma(v.im, v.im, n2[1])); }
+            bsum_multi<2>(n2, L);
+            if (!(fabs(n2[1] - n2[0]) <= FBX_BASIS_NORM_TOL * n2[0])) {
+                __syncthreads();
+                sys_store<D>(L.Ms, t, h);
+                __syncthreads();
+                warm = false;
+            }
+        }
+    }
     PH_STOP(*L.pc, 6);
     sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, !warm, L.red);
     PH_STOP(*L.pc, 0);
@@ -203,7 +222,9 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         // outer step was small, from the basis the previous call found at the same Dykstra
         // iteration (BasisStore, fbx_choi.hpp) -- the first projection always, it has no other
         bool warm = it > 0 && Tg != nullptr;
+        bool from_slot = false;
         if (store && Tg && it < store->nprev && (it == 0 || store->use_prev)) {
+            from_slot = true;
             __syncthreads();
             const fbx_global_cplx_ptr src = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
@@ -211,7 +232,7 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
             __syncthreads();
             warm = true;
         }
-        const Blk cp = proj_cp(pre_cp, L, t, sweeps, warm, Tg);
+        const Blk cp = proj_cp(pre_cp, L, t, sweeps, warm, Tg, from_slot);
         if (store && it < store->cap) {
             fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
