@@ -280,18 +280,19 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
     }
     double pc = 1.0, psr = 0.0, psi = 0.0;          // rotation whose eigenvector update is still pending
     int sweep = 0;
+    double n2 = 0.0;                                // ||A||_F^2: invariant under the rotations, reduced once
     for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
         {
-            double o2 = 0.0, n2 = 0.0;
+            double o2 = 0.0, a_all = 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const cplx v = Ms[e * LS + me];
                 const double a2 = v.re * v.re + v.im * v.im;
-                n2 += a2;
+                a_all += a2;
                 if (!(I == J && (e == 0 || e == 3))) o2 += a2;
             }
             o2 = uniform(wave_sum(o2));
-            n2 = uniform(wave_sum(n2));
+            if (sweep == 0) n2 = uniform(wave_sum(a_all));
             // expect_n2 >= 0: the matrix was brought into a basis loaded from memory; a unitary similarity
             // keeps ||.||_F^2 (here to FBX_BASIS_NORM_TOL), a damaged basis does not -> tell the caller (-1)
             if (sweep == 0 && expect_n2 >= 0.0 && !(fabs(n2 - expect_n2) <= FBX_BASIS_NORM_TOL * expect_n2)) return -1;
