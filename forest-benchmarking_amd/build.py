@@ -60,5 +60,30 @@ def build(force=False, verbose=True, profile=False):
     return out
 
 
+def build_guard_test(verbose=True):
+    """libfbx_cor.so: the product sources with every stored basis that is loaded for Dykstra iteration 1
+    damaged on purpose and the rejections counted -- only loaded by tests/test_basis_guard_gpu.py.
+    Only fbx_pgdb.hip differs; the other objects are those of libfbx.so."""
+    out = os.path.join(HERE, "libfbx_cor.so")
+    lib = build(verbose=verbose)
+    src = os.path.join(CSRC, "fbx_pgdb.hip")
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(lib):
+        return out
+    obj = os.path.join(HERE, "build", "fbx_pgdb.hip.cor.o")
+    cmd = [HIPCC] + FLAGS + ["-DFBX_DBG_CORRUPT_BASIS", "-DFBX_DEBUG_REJECT", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs = [obj] + [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if s != src]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, profile="--profile" in sys.argv)
+    if "--guard-test" in sys.argv:
+        build_guard_test()
+    else:
+        build(force="--force" in sys.argv, profile="--profile" in sys.argv)
