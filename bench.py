@@ -1,23 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: process-tomography MLE reconstructions/sec (2-qubit, 100 iters).
+"""bench.py -- process-tomography MLE reconstructions/sec (2-qubit, 100 iters) on MI355X.
 
-Workload (BASELINE.json configs[1]): a batch of 1024 independent 2-qubit process tomographies
-per GPU (Pauli in-basis, 540 settings, 1000 shots), 100 fixed outer iterations of projected
-gradient descent with backtracking (fbx_pgdb_process_dev, FBX_MODE_FIXED), fp64.  Inputs are
-resident in HBM before the timed region; a "step" is one pass of the kernel over the batch.
-
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py                                   # N = 1: headline + the secondary workloads
+    python bench.py --gpus N --steps K --warmup W     # spawns its N ranks itself (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N ...         # same ranks, launched by torchrun
 
-One process per GPU; the batch axis is embarrassingly parallel, so ranks shard items with no
-data-path collective (scaling = weak: every rank owns `--batch` items).  torch.distributed is
-used only for the barrier and the max-over-ranks of the elapsed time.
+A "step" is one pass of the hot path (fbx_pgdb_process_dev, FBX_MODE_FIXED, 100 outer iterations
+of projected gradient descent with backtracking, fp64) over one batch that is already resident in HBM.
+
+N = 1 (BASELINE.json configs[1], the configuration the metric is quoted on): 1024 independent 2-qubit
+process tomographies (Pauli in-basis, 540 settings, 1000 shots).  The same run also times, outside
+the headline's timed region and reported under "secondary": the conversion sweep of configs[2]
+(10^6 Kraus sets), the 3-qubit PGDB of configs[3] (batch 256), the converge-mode (reference
+semantics) throughput, the host-pointer (H2D + D2H inclusive) rate, the latency of one experiment
+through the reference-signature call, a parity self-check of the timed items against the oracle and
+the CPU baselines (oracle = numpy restatement of the reference, timed on this box's host cores).
+
+N > 1 (BASELINE.json configs[4]): 65 536 two-qubit tomographies with distinct seeds, block-partitioned
+over the ranks (strong scaling: the total is fixed for N = 2, 4, 8), no data-path collective.  The
+line also carries the weak-scaling figure with configs[1]'s 1024 items on every rank
+("per_gpu_1024"), which is the number comparable with the N = 1 headline.
+
+No torch: ranks meet through fbx.parallel (RCCL communicator inside libfbx.so; rank 0's unique id
+travels through a rendezvous directory); barrier and max-over-ranks of the elapsed time are RCCL
+all-reduces.  When RCCL cannot be initialised (e.g. test ranks sharing one GPU with
+--oversubscribe) the barrier falls back to the rendezvous files and the line says so.
 """
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,11 +41,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "forest-benchmarking_amd"))
 
-# algorithmic work of one 2-qubit, 100-iteration reconstruction in the
-# reference's dense formulation (~7.7 MFLOP per outer iteration) and its HBM bytes
-# (540 expectations + 540 counts in, 16x16 complex128 Choi out).
+# algorithmic work of one 2-qubit, 100-iteration reconstruction in the reference's
+# dense formulation (~7.7 MFLOP per outer iteration) and its HBM bytes (540 expectations + 540
+# counts in, 16 x 16 complex128 Choi out).
 ALGO_FLOP_PER_RECON = 0.77e9
-ALGO_BYTES_PER_RECON = 12736
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector == fp64 MFMA (v_mfma_f64_16x16x4) dense peak
 HBM_PEAK_GBS = 8000.0
 
@@ -39,41 +54,167 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="reconstructions per GPU per step")
-    ap.add_argument("--total-batch", type=int, default=0,
-                    help="strong scaling (BASELINE configs[4]): this many reconstructions in total, "
-                         "block-partitioned over the ranks (e.g. 65536); 0 = weak scaling with --batch per GPU")
-    ap.add_argument("--distinct-shards", action="store_true",
-                    help="weak scaling with a different block of synthetic experiments on every rank "
-                         "(default: every rank runs the N = 1 workload)")
+    ap.add_argument("--batch", type=int, default=1024, help="reconstructions per GPU per step (weak form)")
+    ap.add_argument("--total-batch", type=int, default=-1,
+                    help="reconstructions in total, block-partitioned over the ranks; default: 65536 "
+                         "(BASELINE configs[4]) when --gpus > 1, 0 = weak scaling with --batch per GPU")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--in-basis", default=None, choices=["pauli", "sic"],
                     help="input-state basis of the process design (default: pauli for pgdb, sic for pgdb3)")
     ap.add_argument("--cpu-sample", type=int, default=12,
-                    help="items timed on the host for cpu_baseline (0 = skip)")
-    ap.add_argument("--workload", default="pgdb", choices=["pgdb", "sweep", "pgdb3"],
-                    help="pgdb = the headline metric (BASELINE configs[1]); sweep = the secondary "
-                         "HBM-bound conversion sweep of BASELINE configs[2] (1e6 Kraus sets); pgdb3 = BASELINE "
-                         "configs[3], 256 three-qubit process tomographies")
+                    help="items run through the oracle for cpu_baseline and the parity self-check (0 = skip)")
+    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "pgdb3"],
+                    help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "
+                         "sweep / pgdb3 = that workload as the primary line")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="testing: allow more ranks than visible GPUs (ranks share devices; host-file barrier)")
     return ap.parse_args()
 
 
-def cpu_baseline(design, e, c, n_items, iters):
-    """The oracle (numpy restatement of the reference) on a bounded sample of the same batch,
-    one core, design matrix hoisted out of the loop (the fair variant of BASELINE.md section 3)."""
+# ================================================================================== rank spawning
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) with the
+    environment torchrun would give them and relay rank 0's line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    rdzv = tempfile.mkdtemp(prefix="fbx_rdzv_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBX_RDZV_DIR=rdzv,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    try:
+        os.rmdir(rdzv)
+    except OSError:
+        pass
+    if any(codes):
+        sys.exit(f"bench.py: rank exit codes {codes}")
+
+
+# ================================================================================== timing
+def timed_steps(step, steps, warmup, comm, _lib):
+    """W untimed steps, then exactly K steps bracketed by barrier + stream synchronisation on both
+    sides; returns (wall seconds, HIP-event milliseconds on the launch stream), max over ranks."""
+    for _ in range(warmup):
+        step()
+    comm.barrier()
+    ms = ctypes.c_double(0.0)
+    t0 = time.perf_counter()
+    _lib.check(_lib.lib().fbx_timer_begin())
+    for _ in range(steps):
+        step()
+    _lib.check(_lib.lib().fbx_timer_end(ctypes.byref(ms)))      # HIP events on the stream the kernels run on
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed, kms = comm.allreduce([elapsed, ms.value], "max")
+    return float(elapsed), float(kms)
+
+
+def _profiled(key):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
+# ================================================================================== flop accounting
+def pgdb2q_executed_flop(m, S, iters, dyk, backtracks, work):
+    """Floating-point operations the 2-qubit kernel EXECUTES for one reconstruction (mean over the
+    batch), counted from the source (csrc/fbx_pgdb.hip, fbx_choi.hpp, fbx_eigh.hpp; fma = 2, DESIGN.md
+    2.1) and the per-item work counters the kernel returns.  Kronecker formulation: the dense design
+    matrix A of the reference (the 0.77 GFLOP numerator) is never applied."""
+    D, lanes = 16, 64
+    sweeps, terms, cost_evals, sum_passes = (float(np.mean(work[:, k])) for k in range(4))
+    it, dy, bt = float(np.mean(iters)), float(np.mean(dyk)), float(np.mean(backtracks))
+    f = {}
+    f["jacobi_sweeps"] = sweeps * 15 * lanes * 162                 # rotation 42 + 2x2 block update 80 + eigenvector update 40 per lane and round
+    f["jacobi_offnorm_tests"] = (sweeps + dy) * lanes * 20
+    f["basis_change_mfma"] = max(dy - np.ceil(it / 16.0), 0.0) * 32 * 2 * 16 * 16 * 4   # 32 v_mfma_f64_16x16x4 per warm decomposition
+    f["reconstruct"] = terms * lanes * 28                          # V diag(lam+) V^H, one rank-1 term per kept eigenvalue
+    f["dykstra_rest"] = dy * lanes * 220                           # Hermitise, differences, TP projection, stop functional
+    f["pauli_transforms"] = it * 3 * 3300                          # estimate, update direction, gradient (4 butterfly stages each)
+    f["prediction_tables"] = it * 2 * 2 * S * D * D                # T = R C for estimate and update direction
+    f["gradient"] = it * (30 * m + 2 * S * D * D)                  # eta = n / p, LDS-atomic weights, W C^T
+    f["probabilities"] = it * 3 * 6 * m
+    f["cost_evaluations"] = cost_evals * 2 * m * 45                # clip + log (~40) + accumulate per outcome
+    f["power_sums"] = sum_passes * 2 * m * 40
+    f["series_steps"] = bt * lanes * 34
+    return sum(f.values()), f
+
+
+def pgdb3q_executed_flop(m, S, iters, dyk, work):
+    sweeps, terms, cost_evals = (float(np.mean(work[:, k])) for k in range(3))
+    it, dy = float(np.mean(iters)), float(np.mean(dyk))
+    f = {}
+    f["jacobi_sweeps"] = sweeps * 63 * 1024 * 162
+    f["basis_change"] = dy * 2 * 64 ** 3 * 8                       # V^H H V as two dense complex 64^3 products (VALU)
+    f["reconstruct"] = terms * 1024 * 28
+    f["dykstra_rest"] = dy * 1024 * 240
+    f["tables_mfma"] = it * 3 * 2 * S * 64 * 64                    # T = C^T R^T (x2) and R^G = -W C^T / d^2 on the fp64 matrix cores
+    f["gradient_probabilities"] = it * 48 * m
+    f["cost_evaluations"] = cost_evals * 2 * m * 45
+    f["pauli_transforms"] = it * 3 * 6 * 4096 * 4
+    return sum(f.values()), f
+
+
+# ================================================================================== CPU legs (oracle)
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    from fbx_oracle import design as od, estimators as oe
+    from fbx_oracle import design as od, estimators as oe, superops as so, measures as om
+    return od, oe, so, om
+
+
+def cpu_baseline_and_parity(design, us, e, c, n_items, iters, gpu_fixed, gpu_conv):
+    """The oracle on the first `n_items` items of the bench batch, one core.  Returns the cpu_baseline
+    object (fixed mode, design matrix hoisted -- the fair variant of BASELINE.md section 3), the
+    converge-mode and reference-faithful (design rebuilt per call, tomography.py:494-539) variants,
+    and the parity self-check of the GPU results of the timed launch against the oracle."""
+    od, oe, so, om = _oracle()
     d = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)
     A = oe.design_matrix_A(d)
+
+    def fid(choi, b):
+        return om.process_fidelity(so.kraus2pauli_liouville([us[b]]), so.choi2pauli_liouville(choi))
+
+    def compare(mode, gpu, label):
+        choi_g, st_g = gpu
+        t0 = time.perf_counter()
+        res = [oe.pgdb_process_estimate(d, e[b], c[b], mode=mode, max_iters=iters if mode == "fixed" else 0,
+                                        A=A, return_stats=True) for b in range(n_items)]
+        dt = time.perf_counter() - t0
+        dchoi = max(float(np.abs(choi_g[b] - res[b][0]).max()) for b in range(n_items))
+        dfid = max(abs(fid(choi_g[b], b) - fid(res[b][0], b)) for b in range(n_items))
+        mism = {k: int(sum(int(st_g[k][b]) != res[b][1][k] for b in range(n_items)))
+                for k in ("iterations", "dykstra", "backtracks")}
+        return dt, {"mode": label, "items": n_items, "max_abs_choi_diff": dchoi,
+                    "max_process_fidelity_diff": dfid, "count_mismatches": mism,
+                    "mean_oracle_iterations": float(np.mean([r[1]["iterations"] for r in res]))}
+
+    dt_fixed, par_fixed = compare("fixed", gpu_fixed, f"fixed {iters} iterations (the timed mode)")
+    dt_conv, par_conv = compare("converge", gpu_conv, "converge (reference semantics, tomography.py:589)")
+    n_faith = max(1, min(3, n_items))
     t0 = time.perf_counter()
-    for b in range(n_items):
-        oe.pgdb_process_estimate(d, e[b], c[b], mode="fixed", max_iters=iters, A=A)
-    dt = time.perf_counter() - t0
-    return {"value": n_items / dt, "unit": "reconstructions/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_items} items of the bench batch, fixed {iters} iterations, "
-                      f"numpy oracle with the design matrix hoisted, {dt:.1f} s"}
+    for b in range(n_faith):
+        oe.pgdb_process_estimate(d, e[b], c[b], mode="converge")          # A rebuilt inside, as the reference does
+    dt_faith = time.perf_counter() - t0
+    base = {"value": n_items / dt_fixed, "unit": "reconstructions/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_items} items of the bench batch, fixed {iters} iterations, numpy oracle with "
+                      f"the design matrix hoisted, {dt_fixed:.1f} s",
+            "converge_mode": {"value": n_items / dt_conv, "unit": "reconstructions/s",
+                              "sample": f"same items to convergence, {dt_conv:.1f} s"},
+            "reference_faithful": {"value": n_faith / dt_faith, "unit": "reconstructions/s",
+                                   "sample": f"first {n_faith} items to convergence with the design matrix "
+                                             f"rebuilt per call as tomography.py:494-539 does, {dt_faith:.1f} s"}}
+    return base, [par_fixed, par_conv]
 
 
 _POOL_WORKER = r"""
@@ -96,7 +237,6 @@ def cpu_baseline_pool(design, e, c, iters, per_core=1, max_cores=64):
     """The fair multi-core variant of SURVEY.md 8d: one single-threaded oracle process per host core
     (separate interpreters -- nothing is forked from the process that owns the GPU), `per_core`
     items each, design matrix hoisted once per process and left out of the timed region."""
-    import subprocess, tempfile
     cores = max(1, min(os.cpu_count() or 1, max_cores, e.shape[0] // per_core))
     n_items = cores * per_core
     with tempfile.TemporaryDirectory() as tmp:
@@ -115,18 +255,8 @@ def cpu_baseline_pool(design, e, c, iters, per_core=1, max_cores=64):
                       f"fixed {iters} iterations, slowest worker {busy:.1f} s (wall incl. start-up {wall:.1f} s)"}
 
 
-def _profiled(key):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        return json.load(open(path)).get(key)
-    except Exception:
-        return None
-
-
 def sweep_cpu_baseline(ks, ref, n_items):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from fbx_oracle import superops as so, measures as om
+    _, _, so, om = _oracle()
     t0 = time.perf_counter()
     for b in range(n_items):
         choi = so.kraus2choi(list(ks[b]))
@@ -139,285 +269,327 @@ def sweep_cpu_baseline(ks, ref, n_items):
                       f"rebuilt per call, choi2chi through eigh), {dt:.1f} s"}
 
 
-def run_sweep(args, rank, world, dist, torch):
-    """Secondary line: kraus2choi -> choi2pauli_liouville -> choi2chi + process_fidelity on
-    `--sweep-items` random 2-qubit CPTP Kraus sets (K = 4) per GPU, inputs resident in HBM."""
-    import ctypes
-    from fbx import _lib, synthetic
+def pgdb3_cpu_baseline(design, e, c, iters):
+    """One 3-qubit item, 2 outer iterations of the oracle (dense 8064 x 4096 design matrix, hoisted),
+    scaled to `iters` iterations: the per-iteration cost is constant."""
+    od, oe, _, _ = _oracle()
+    d = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)
+    A = oe.design_matrix_A(d)
+    t0 = time.perf_counter()
+    oe.pgdb_process_estimate(d, e[0], c[0], mode="fixed", max_iters=2, A=A)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt * iters / 2.0), "unit": "reconstructions/s", "cores": 1, "kind": "port",
+            "sample": f"item 0, 2 outer iterations of the numpy oracle ({dt:.1f} s, design matrix hoisted), "
+                      f"extrapolated linearly to {iters} iterations"}
+
+
+# ================================================================================== workloads
+def run_sweep(args, comm, _lib, synthetic, with_cpu):
+    """BASELINE configs[2]: kraus2choi -> choi2pauli_liouville -> choi2chi + process_fidelity on
+    `--sweep-items` random 2-qubit CPTP Kraus sets (K = 4) per GPU, generated ON THE DEVICE from the
+    counter-based Philox stream keyed by the item id, all three representations written."""
     n, K, D = 2, 4, 16
     B = args.sweep_items
-    base = synthetic.kraus_batch(n, K, 8192, seed=17 + rank)
-    ks = np.ascontiguousarray(np.tile(base, (B // 8192 + 1, 1, 1, 1))[:B])
-    cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=np.complex128)
     lib = _lib.lib()
+    d_k = _lib.DeviceBuffer(B * K * D * 16)
+    _lib.check(lib.fbx_random_kraus_dev(n, B, K, 17, comm.rank * B, d_k.ptr))
+    cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=np.complex128)
     ref = np.empty((1, D, D), dtype=np.complex128)
     _lib.check(lib.fbx_convert(_lib.REP_KRAUS, _lib.REP_PAULI_LIOUVILLE, n, 1,
                                _lib.dptr(np.ascontiguousarray(cnot[None, None]).view(np.float64)), 1,
                                _lib.dptr(ref.view(np.float64))))
-    d_k = _lib.DeviceBuffer.from_array(ks)
     d_r = _lib.DeviceBuffer.from_array(ref)
-    d_c = _lib.DeviceBuffer(B * D * D * 16); d_p = _lib.DeviceBuffer(B * D * D * 16)
-    d_x = _lib.DeviceBuffer(B * D * D * 16); d_f = _lib.DeviceBuffer(B * 8)
+    d_c, d_p, d_x = (_lib.DeviceBuffer(B * D * D * 16) for _ in range(3))
+    d_f = _lib.DeviceBuffer(B * 8)
 
     def step():
         _lib.check(lib.fbx_kraus_sweep_dev(n, B, K, d_k.ptr, d_r.ptr, d_c.ptr, d_p.ptr, d_x.ptr, d_f.ptr))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        _lib.synchronize()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ms = ctypes.c_double(0.0)
-    t0 = time.perf_counter()
-    _lib.check(lib.fbx_timer_begin())
-    for _ in range(args.steps):
-        step()
-    _lib.check(lib.fbx_timer_end(ctypes.byref(ms)))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed, ms.value], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kms = t.tolist()
-    else:
-        kms = ms.value
-    if rank == 0:
-        bytes_item = K * D * 16 + 3 * D * D * 16 + 8            # 13 320 B (SURVEY 8d)
-        ksec = kms / 1e3 / args.steps
-        gbs = B * bytes_item / ksec / 1e9
-        line = {"metric": "conversion sweep items/sec (2-qubit Kraus -> Choi -> PTM -> chi + process_fidelity)",
-                "value": world * B * args.steps / elapsed, "unit": "items/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                "data": "synthetic",
-                "config": {"workload": f"{B} random 2-qubit CPTP Kraus sets (K=4) per GPU, all three "
-                                       f"representations + fidelity written, inputs resident in HBM",
-                           "items_per_gpu": B, "parallelism": f"shard{world}"},
-                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": gbs / HBM_PEAK_GBS, "traffic": _profiled("sweep_kernel_hbm_bytes_per_launch"),
-                             "kernel": "sweep2q_pair_kernel",
-                             "kernel_ms": 1e3 * ksec,
-                             "note": "achieved = 13 320 algorithmic bytes per item / HIP-event kernel time"}}
-        if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = sweep_cpu_baseline(ks, ref[0], 2000)
-        print(json.dumps(line), flush=True)
+    elapsed, kms = timed_steps(step, args.steps, args.warmup, comm, _lib)
+    bytes_item = K * D * 16 + 3 * D * D * 16 + 8            # 13 320 B (SURVEY 8d)
+    ksec = kms / 1e3 / args.steps
+    gbs = B * bytes_item / ksec / 1e9
+    fid = d_f.to_array(np.float64, (min(B, 4096),))
+    line = {"metric": "conversion sweep items/sec (2-qubit Kraus -> Choi -> PTM -> chi + process_fidelity)",
+            "value": comm.world * B * args.steps / elapsed, "unit": "items/s", "n_gpus": comm.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{B} random 2-qubit CPTP Kraus sets (K=4) per GPU generated on the device "
+                                   f"(Philox4x32-10 keyed by item id), all three representations + fidelity "
+                                   f"written, inputs resident in HBM",
+                       "items_per_gpu": B, "parallelism": f"shard{comm.world}",
+                       "mean_fidelity_to_cnot": float(fid.mean())},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": _profiled("sweep_kernel_hbm_bytes_per_launch"),
+                         "kernel": "sweep2q_pair_kernel", "kernel_ms": 1e3 * ksec,
+                         "note": "achieved = 13 320 algorithmic bytes per item / HIP-event kernel time"}}
+    if with_cpu and comm.rank == 0:
+        ks = d_k.to_array(np.complex128, (2000, K, 4, 4))
+        line["cpu_baseline"] = sweep_cpu_baseline(ks, ref[0], 2000)
+    for buf in (d_k, d_r, d_c, d_p, d_x, d_f):
+        buf.free()
+    return line
 
 
-def run_pgdb3(args, rank, world, dist, torch):
-    """Third line: BASELINE configs[3] -- 3-qubit (64 x 64 Choi) PGDB process tomography, batch 256 per
-    GPU, SIC in-basis (4032 settings) unless --in-basis pauli (13 608), 100 fixed iterations."""
-    import ctypes
-    from fbx import _lib, synthetic
+def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
+    """BASELINE configs[3]: 3-qubit (64 x 64 Choi) PGDB process tomography, batch 256 per GPU, SIC
+    in-basis (4032 settings) unless --in-basis pauli (13 608), 100 fixed iterations."""
     B = 256
     basis = args.in_basis or "sic"
-    design, _, e, c = synthetic.process_batch(3, basis, 32)
-    e = np.tile(e, (B // 32, 1)); c = np.tile(c, (B // 32, 1))
+    design, _, e32, c32 = synthetic.process_batch(3, basis, 32, first_item=32 * comm.rank)
+    e = np.tile(e32, (B // 32, 1)); c = np.tile(c32, (B // 32, 1))
     lib = _lib.lib()
     d_e, d_c = _lib.DeviceBuffer.from_array(e), _lib.DeviceBuffer.from_array(c)
-    d_choi = _lib.DeviceBuffer(B * 64 * 64 * 16); d_it = _lib.DeviceBuffer(B * 4); d_dy = _lib.DeviceBuffer(B * 4)
+    d_choi = _lib.DeviceBuffer(B * 64 * 64 * 16)
+    d_it, d_dy, d_w = _lib.DeviceBuffer(B * 4), _lib.DeviceBuffer(B * 4), _lib.DeviceBuffer(B * 16)
 
     def step():
         _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, _lib.MODE_FIXED, args.iters,
-                                            d_choi.ptr, d_it.ptr, d_dy.ptr, None, None))
+                                            d_choi.ptr, d_it.ptr, d_dy.ptr, None, None, d_w.ptr))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        _lib.synchronize()
-        torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 3))
+    elapsed, kms = timed_steps(step, steps, min(args.warmup, 1), comm, _lib)
+    dyk = d_dy.to_array(np.int32, (B,)); its = d_it.to_array(np.int32, (B,)); work = d_w.to_array(np.int32, (B, 4))
+    ksec = kms / 1e3 / steps
+    m = design.m
+    # algorithmic flops in the reference's dense formulation (SURVEY 8d recipe at n = 3): per outer
+    # iteration 3 R D^2 complex MACs (gradient 2, cost 1; R = 2 m rows, D^2 = 4096) + per Dykstra
+    # iteration one 64 x 64 Hermitian eigendecomposition (~25 N^3) + V L V^H (2 N^3 complex MACs)
+    flop = args.iters * 3 * (2 * m) * 4096 * 8 + float(dyk.mean()) * (25 * 64 ** 3 + 2 * 64 ** 3 * 8)
+    tflops = B * flop / ksec / 1e12
+    ex, parts = pgdb3q_executed_flop(m, design.n_states, its, dyk, work)
+    line = {"metric": "process-tomography MLE reconstructions/sec (3-qubit, 64x64 Choi, 100 iters)",
+            "value": comm.world * B * steps / elapsed, "unit": "reconstructions/s", "n_gpus": comm.world,
+            "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{B} independent 3-qubit process tomographies per GPU, {basis} in-basis "
+                                   f"({m} settings, 1000 shots), {args.iters} fixed PGDB iterations, inputs "
+                                   f"resident in HBM (32 distinct experiments, tiled)", "batch_per_gpu": B,
+                       "iters": args.iters, "parallelism": f"shard{comm.world}",
+                       "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean())},
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU + LDS", "achieved": tflops, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch"),
+                         "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
+                         "executed_flop": ex, "executed_tflops": B * ex / ksec / 1e12,
+                         "executed_frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
+                         "executed_breakdown": {k: round(v) for k, v in parts.items()},
+                         "note": "achieved = algorithmic flops of the reference's dense formulation (3 x 2m x 4096 "
+                                 "complex MACs per outer iteration + ~25 N^3 per 64 x 64 eigendecomposition) / "
+                                 "HIP-event kernel time; executed_* = flops the Kronecker-form kernel really "
+                                 "performs, from its work counters (DESIGN.md 2.2)"}}
+    if with_cpu and comm.rank == 0 and basis == "sic":
+        line["cpu_baseline"] = pgdb3_cpu_baseline(design, e, c, args.iters)
+    for buf in (d_e, d_c, d_choi, d_it, d_dy, d_w):
+        buf.free()
+    return line
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ms = ctypes.c_double(0.0)
-    t0 = time.perf_counter()
-    _lib.check(lib.fbx_timer_begin())
-    for _ in range(args.steps):
-        step()
-    _lib.check(lib.fbx_timer_end(ctypes.byref(ms)))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed, ms.value], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kms = t.tolist()
+
+class PgdbBatch:
+    """A resident batch of 2-qubit process tomographies and its output buffers."""
+
+    def __init__(self, _lib, synthetic, in_basis, B, first_item, max_distinct=8192):
+        n_distinct = min(B, max_distinct)
+        self.design, self.us, e, c = synthetic.process_batch(2, in_basis, n_distinct, first_item=first_item)
+        if n_distinct < B:
+            reps = -(-B // n_distinct)
+            e = np.tile(e, (reps, 1))[:B]; c = np.tile(c, (reps, 1))[:B]
+        self.e, self.c, self.B, self.n_distinct, self._lib = e, c, B, n_distinct, _lib
+        DB = _lib.DeviceBuffer
+        self.d_e, self.d_c = DB.from_array(e), DB.from_array(c)
+        self.d_choi, self.d_it, self.d_dy = DB(B * 256 * 16), DB(B * 4), DB(B * 4)
+        self.d_bt, self.d_cost, self.d_work = DB(B * 4), DB(B * 8), DB(B * 16)
+
+    def launch(self, mode, iters):
+        L = self._lib
+        L.check(L.lib().fbx_pgdb_process_dev(self.design.handle, self.B, self.d_e.ptr, self.d_c.ptr, 1, mode, iters,
+                                             self.d_choi.ptr, self.d_it.ptr, self.d_dy.ptr, self.d_bt.ptr,
+                                             self.d_cost.ptr, self.d_work.ptr))
+
+    def stats(self):
+        B = self.B
+        return {"iterations": self.d_it.to_array(np.int32, (B,)), "dykstra": self.d_dy.to_array(np.int32, (B,)),
+                "backtracks": self.d_bt.to_array(np.int32, (B,)), "work": self.d_work.to_array(np.int32, (B, 4))}
+
+    def choi(self, n):
+        return self.d_choi.to_array(np.complex128, (n, 16, 16))
+
+    def free(self):
+        for b in (self.d_e, self.d_c, self.d_choi, self.d_it, self.d_dy, self.d_bt, self.d_cost, self.d_work):
+            b.free()
+
+
+def pgdb_roofline(batch, st, kernel_s, iters):
+    B, m, S = batch.B, batch.design.m, batch.design.n_states
+    achieved = B * ALGO_FLOP_PER_RECON * (iters / 100.0) / kernel_s / 1e12
+    ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"])
+    algo_bytes = 2 * m * 8 + 4096
+    return {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+            "traffic": _profiled("pgdb_kernel_hbm_bytes_per_launch") if B == 1024 else None,
+            "kernel": "pgdb_kernel<2,9>" if m > 256 else "pgdb_kernel<2,4>", "kernel_ms": 1e3 * kernel_s,
+            "executed_flop": ex, "executed_tflops": B * ex / kernel_s / 1e12,
+            "executed_frac": B * ex / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
+            "executed_breakdown": {k: round(v) for k, v in parts.items()},
+            "note": "PGDB is fp64-compute / latency bound (SURVEY.md 8d).  achieved = the agreed numerator, 0.77 GFLOP "
+                    "per reconstruction in the reference's dense-A formulation, x batch / HIP-event kernel time: an "
+                    "ACCOUNTING figure (86 % of it is dense A-GEMV work the Kronecker-form kernel never performs).  "
+                    "executed_* = flops the kernel really executes per reconstruction, from its per-item work "
+                    "counters (Jacobi sweeps, eigenvalue terms, cost evaluations): the utilisation figure.",
+            "hbm": {"achieved": B * algo_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": B * algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": B * algo_bytes}}
+
+
+def run_pgdb(args, comm, _lib, synthetic, rank_info):
+    """The headline.  N = 1: configs[1] (1024 items).  N > 1: configs[4] (total batch block-partitioned)
+    plus the 1024-per-GPU weak figure."""
+    from fbx.parallel import shard_bounds
+    world, rank = comm.world, comm.rank
+    total = args.total_batch
+    if total < 0:
+        total = 65536 if world > 1 else 0
+    extras = {}
+    if total > 0:
+        lo, hi = shard_bounds(total, rank, world)
+        batch = PgdbBatch(_lib, synthetic, args.in_basis, hi - lo, lo)
+        scaling, shards = "strong", f"contiguous blocks of a {total}-item batch, distinct seeds ({batch.n_distinct} distinct experiments per rank, tiled beyond)"
     else:
-        kms = ms.value
-    if rank == 0:
-        dyk = d_dy.to_array(np.int32, (B,))
-        ksec = kms / 1e3 / args.steps
-        # algorithmic flops in the reference's dense formulation (SURVEY 8d recipe at n = 3): per outer
-        # iteration 3 R D^2 complex MACs (gradient 2, cost 1; R = 2 m rows, D^2 = 4096) + per Dykstra
-        # iteration one 64 x 64 Hermitian eigendecomposition (~25 N^3 = 6.6 MFLOP) + V L V^H (2 N^3 cmac)
-        m = design.m
-        flop = args.iters * 3 * (2 * m) * 4096 * 8 + float(dyk.mean()) * (25 * 64 ** 3 + 2 * 64 ** 3 * 8)
-        tflops = B * flop / ksec / 1e12
-        line = {"metric": "process-tomography MLE reconstructions/sec (3-qubit, 64x64 Choi, 100 iters)",
-                "value": world * B * args.steps / elapsed, "unit": "reconstructions/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                "data": "synthetic",
-                "config": {"workload": f"{B} independent 3-qubit process tomographies per GPU, {basis} in-basis "
-                                       f"({m} settings, 1000 shots), {args.iters} fixed PGDB iterations, inputs "
-                                       f"resident in HBM", "batch_per_gpu": B, "iters": args.iters,
-                           "parallelism": f"shard{world}", "mean_dykstra_iters": float(dyk.mean())},
-                "roofline": {"bound": "mfma", "pipe": "fp64 VALU + LDS", "achieved": tflops, "peak": FP64_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
-                             "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
-                             "note": "achieved = algorithmic flops of the dense formulation (3 x 2m x 4096 complex "
-                                     "MACs per outer iteration + ~25 N^3 per 64 x 64 eigendecomposition) / HIP-event "
-                                     "kernel time; the kernel is co-limited by LDS bandwidth and fp64 issue in "
-                                     "the eigensolver (DESIGN.md 2.2)"}}
-        print(json.dumps(line), flush=True)
+        batch = PgdbBatch(_lib, synthetic, args.in_basis, args.batch, rank * args.batch)
+        scaling, shards = "weak", "distinct seeds per rank"
+    elapsed, kms = timed_steps(lambda: batch.launch(_lib.MODE_FIXED, args.iters), args.steps, args.warmup, comm, _lib)
+    st = batch.stats()
+    total_recons = (total if total > 0 else world * batch.B) * args.steps
+    kernel_s = kms / 1e3 / args.steps
+    # whole-job summary over the ranks (the one collective of the path besides the optional all-gather)
+    sums = comm.allreduce([float(st["iterations"].sum()), float(st["dykstra"].sum()), float(st["backtracks"].sum()),
+                           float(st["work"][:, 0].sum()), float(batch.B)], "sum")
+    line = {
+        "metric": "process-tomography MLE reconstructions/sec (2-qubit, 100 iters)",
+        "value": total_recons / elapsed, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"{total} independent 2-qubit process tomographies sharded over {world} GPU(s) "
+                                f"(BASELINE configs[4])" if total > 0 else
+                                f"{batch.B} independent 2-qubit process tomographies per GPU (BASELINE configs[1])")
+                               + f", {args.in_basis} in-basis ({batch.design.m} settings, 1000 shots), {args.iters} "
+                                 f"fixed PGDB iterations, inputs resident in HBM",
+                   "batch_per_gpu": batch.B, "total_batch": total if total > 0 else world * batch.B,
+                   "iters": args.iters, "parallelism": f"shard{world}", "shards": shards,
+                   "device": rank_info["device"], "compute_units": rank_info["cus"],
+                   "collectives": rank_info["transport"],
+                   "mean_outer_iters": sums[0] / sums[4], "mean_dykstra_iters": sums[1] / sums[4],
+                   "mean_backtracks": sums[2] / sums[4], "mean_jacobi_sweeps": sums[3] / sums[4]},
+        "roofline": pgdb_roofline(batch, st, kernel_s, args.iters),
+    }
+    if world > 1 and total > 0:
+        # the N = 1-comparable figure: configs[1]'s 1024 items on every rank (weak scaling)
+        batch.free()
+        wb = PgdbBatch(_lib, synthetic, args.in_basis, args.batch, rank * args.batch)
+        el, km = timed_steps(lambda: wb.launch(_lib.MODE_FIXED, args.iters), args.steps, args.warmup, comm, _lib)
+        line["per_gpu_1024"] = {"value": world * wb.B * args.steps / el, "unit": "reconstructions/s", "scaling": "weak",
+                                "ms_per_step": 1e3 * el / args.steps, "kernel_ms": km / args.steps,
+                                "workload": f"{wb.B} items on every rank (BASELINE configs[1] per GPU), distinct seeds per rank"}
+        wb.free()
+        return line, None
+    return line, batch
+
+
+def single_gpu_extras(args, comm, _lib, synthetic, batch, line):
+    """N = 1 only, outside the headline's timed region: converge mode, PCIe-inclusive rate, latency of one
+    experiment through the reference-signature call, parity self-check + CPU baselines."""
+    from fbx import tomography
+    B, iters = batch.B, args.iters
+    n_cpu = min(args.cpu_sample, B)
+    gpu_fixed = (batch.choi(n_cpu), batch.stats()) if n_cpu else None
+    # ---- converge mode: the reference's own semantics (stop at delta cost < 1e-10)
+    el, km = timed_steps(lambda: batch.launch(_lib.MODE_CONVERGE, 0), args.steps, 1, comm, _lib)
+    stc = batch.stats()
+    gpu_conv = (batch.choi(n_cpu), stc) if n_cpu else None
+    line["converge_mode"] = {"value": B * args.steps / el, "unit": "reconstructions/s",
+                             "ms_per_step": 1e3 * el / args.steps, "kernel_ms": km / args.steps,
+                             "mean_outer_iters": float(stc["iterations"].mean()),
+                             "max_outer_iters": int(stc["iterations"].max()),
+                             "mean_dykstra_iters": float(stc["dykstra"].mean()),
+                             "note": "FBX_MODE_CONVERGE: the reference loop (tomography.py:570-592); the mode the 1e-9 / "
+                                     "1e-8 parity claim is made in"}
+    # ---- host-pointer entry point: H2D of expectations + counts, kernel, D2H of the Choi matrices
+    t_host = []
+    for k in range(4):
+        t0 = time.perf_counter()
+        tomography.pgdb_process_estimate_batch(batch.design, batch.e, batch.c, mode="fixed", max_iters=iters)
+        t_host.append(time.perf_counter() - t0)
+    th = float(np.median(t_host[1:]))
+    line["pcie_inclusive"] = {"value": B / th, "unit": "reconstructions/s", "ms_per_call": 1e3 * th,
+                              "note": "fbx_pgdb_process on host buffers (pageable numpy arrays): 8.8 MB H2D + 4.2 MB "
+                                      "D2H per call, staging buffers from the library's pool; median of 3 calls after one warm-up"}
+    # ---- one experiment at a time through the reference signature (List[ExperimentResult], qubits)
+    from fbx.observable_estimation import ExperimentResult
+    settings = tomography.generate_process_tomography_settings([0, 1], args.in_basis)
+    res = [ExperimentResult(setting=s, expectation=float(x), std_err=0.0, total_counts=int(n))
+           for s, x, n in zip(settings, batch.e[0], batch.c[0])]
+    lat = []
+    for k in range(6):
+        t0 = time.perf_counter()
+        tomography.pgdb_process_estimate(res, [0, 1])
+        lat.append(time.perf_counter() - t0)
+    line["single_experiment_latency_ms"] = {"value": 1e3 * float(np.median(lat[1:])),
+                                            "note": "pgdb_process_estimate(results, qubits) -- flattening 540 result objects, "
+                                                    "cached design, one-item launch to convergence, D2H; median of 5 after one warm-up"}
+    if n_cpu:
+        base, parity = cpu_baseline_and_parity(batch.design, batch.us, batch.e, batch.c, n_cpu, iters, gpu_fixed, gpu_conv)
+        line["cpu_baseline"] = base
+        line["parity_self_check"] = parity
+        line["cpu_baseline_multicore"] = cpu_baseline_pool(batch.design, batch.e, batch.c, iters)
 
 
 def main():
     args = parse()
-    if args.workload == "pgdb" and args.in_basis is None:
-        args.in_basis = "pauli"
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.workload in ("pgdb", "all") and args.in_basis is None:
+        args.in_basis = "pauli"
 
-    # torch first: its bundled libamdhip64.so.7 and ours share one SONAME, so loading torch
-    # before libfbx.so keeps a single HIP runtime in the process.
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
-    from fbx import _lib, synthetic
-    _lib.set_device(local_rank)                       # fails loudly without a GPU
+    from fbx import _lib, synthetic, parallel
+    comm, rdzv = parallel.init_from_env(allow_host_fallback=True, allow_oversubscribe=args.oversubscribe)   # selects GPU LOCAL_RANK; fails loudly without one
     dev_name, cus = _lib.device_name()
-    if args.workload == "pgdb3":
-        run_pgdb3(args, rank, world, dist, torch)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+    transport = {"backend": comm.backend, "ranks": comm.world}
+    if comm.backend == "rccl":
+        transport["rccl_version"] = comm.rccl_version
+    if getattr(comm, "failure", None):
+        transport["rccl_failure"] = comm.failure
+    rank_info = {"device": dev_name.strip(), "cus": cus, "transport": transport}
+    with_cpu = comm.world == 1 and args.cpu_sample > 0
+
     if args.workload == "sweep":
-        run_sweep(args, rank, world, dist, torch)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    scaling = "weak"
-    if args.total_batch > 0:                          # contiguous block partition of the batch axis
-        from fbx.parallel import shard_bounds
-        lo, hi = shard_bounds(args.total_batch, rank, world)
-        B, first = hi - lo, lo
-        scaling = "strong"
+        line = run_sweep(args, comm, _lib, synthetic, with_cpu)
+    elif args.workload == "pgdb3":
+        line = run_pgdb3(args, comm, _lib, synthetic, with_cpu)
     else:
-        # weak scaling: every rank reconstructs the SAME --batch synthetic experiments (seeds 1000 ..
-        # 1000 + batch - 1, the N = 1 workload), so that per-GPU work really is fixed as N grows; the
-        # 1024-item blocks of consecutive seeds differ by +-15 % in kernel time (one slow item decides,
-        # scripts/block_spread.py), which would otherwise read as scaling loss.  --distinct-shards
-        # gives every rank its own block of seeds instead.
-        B, first = args.batch, (rank * args.batch if args.distinct_shards else 0)
-    # distinct synthetic items are generated for up to 4096 per rank and tiled beyond that
-    n_distinct = min(B, 4096)
-    design, _, e, c = synthetic.process_batch(2, args.in_basis, n_distinct, first_item=first)
-    if n_distinct < B:
-        reps = -(-B // n_distinct)
-        e = np.tile(e, (reps, 1))[:B]; c = np.tile(c, (reps, 1))[:B]
-    d_e = _lib.DeviceBuffer.from_array(e)
-    d_c = _lib.DeviceBuffer.from_array(c)
-    D = 16
-    d_choi = _lib.DeviceBuffer(B * D * D * 16)
-    d_it = _lib.DeviceBuffer(B * 4)
-    d_dy = _lib.DeviceBuffer(B * 4)
-    d_bt = _lib.DeviceBuffer(B * 4)
-    d_cost = _lib.DeviceBuffer(B * 8)
-    lib = _lib.lib()
-
-    def step():
-        _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, _lib.MODE_FIXED,
-                                            args.iters, d_choi.ptr, d_it.ptr, d_dy.ptr, d_bt.ptr,
-                                            d_cost.ptr))
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        _lib.synchronize()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    import ctypes
-    ms = ctypes.c_double(0.0)
-    t0 = time.perf_counter()
-    _lib.check(lib.fbx_timer_begin())
-    for _ in range(args.steps):
-        step()
-    _lib.check(lib.fbx_timer_end(ctypes.byref(ms)))     # HIP events on the launch stream
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    if dist is not None:
-        t = torch.tensor([elapsed, ms.value], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_total = t.tolist()
-    else:
-        kernel_ms_total = ms.value
-
-    iters = d_it.to_array(np.int32, (B,))
-    dyk = d_dy.to_array(np.int32, (B,))
-    bt = d_bt.to_array(np.int32, (B,))
-
-    if rank == 0:
-        total_recons = (args.total_batch if args.total_batch > 0 else world * B) * args.steps
-        value = total_recons / elapsed
-        kernel_s = kernel_ms_total / 1e3 / args.steps           # average launch duration
-        achieved_tflops = B * ALGO_FLOP_PER_RECON * (args.iters / 100.0) / kernel_s / 1e12
-        traffic = _profiled("pgdb_kernel_hbm_bytes_per_launch")
-        line = {
-            "metric": "process-tomography MLE reconstructions/sec (2-qubit, 100 iters)",
-            "value": value, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{B} independent 2-qubit process tomographies per GPU, "
-                                   f"{args.in_basis} in-basis ({design.m} settings, 1000 shots), "
-                                   f"{args.iters} fixed PGDB iterations, inputs resident in HBM",
-                       "batch_per_gpu": B, "iters": args.iters, "parallelism": f"shard{world}",
-                       "shards": ("distinct seeds per rank" if (args.distinct_shards or args.total_batch > 0)
-                                  else "same experiments on every rank"),
-                       "device": dev_name.strip(), "compute_units": cus,
-                       "mean_dykstra_iters": float(dyk.mean()),
-                       "mean_backtracks": float(bt.mean()),
-                       "mean_outer_iters": float(iters.mean())},
-            "roofline": {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / FP64_PEAK_TFLOPS,
-                         "traffic": traffic,
-                         "kernel": "pgdb_kernel<2,9>", "kernel_ms": 1e3 * kernel_s,
-                         "note": "PGDB is fp64-compute bound (SURVEY.md 8d): achieved = "
-                                 "0.77 GFLOP algorithmic (dense-A formulation) x batch / HIP-event "
-                                 "kernel time; peak = dense fp64 MFMA peak of MI355X, which equals its fp64 "
-                                 "vector peak -- the Jacobi rotations are VALU FMAs, the warm-start "
-                                 "basis change of every eigendecomposition runs on the fp64 MFMA pipe",
-                         "hbm": {"achieved": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": B * ALGO_BYTES_PER_RECON / kernel_s / 1e9 / HBM_PEAK_GBS}},
-        }
-        if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(design, e, c, min(args.cpu_sample, B), args.iters)
-            line["cpu_baseline_multicore"] = cpu_baseline_pool(design, e, c, args.iters)
+        secondary = []
+        if args.workload == "all" and comm.world == 1:
+            basis = args.in_basis
+            secondary.append(run_sweep(args, comm, _lib, synthetic, with_cpu))
+            args.in_basis = None
+            secondary.append(run_pgdb3(args, comm, _lib, synthetic, with_cpu))
+            args.in_basis = basis
+            _lib.release_workspace()
+        line, batch = run_pgdb(args, comm, _lib, synthetic, rank_info)
+        if batch is not None:
+            if comm.world == 1 and args.workload == "all":
+                single_gpu_extras(args, comm, _lib, synthetic, batch, line)
+            batch.free()
+        if secondary:
+            line["secondary"] = secondary
+    comm.barrier()
+    comm.close()
+    if rdzv is not None:
+        rdzv.close()
+    if comm.rank == 0:
         print(json.dumps(line), flush=True)
-
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfbx.so")
+MAP = os.path.join(CSRC, "libfbx.map")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"] + os.environ.get("FBX_EXTRA_FLAGS", "").split()
 
@@ -20,7 +21,7 @@ def stale():
         return True
     t = os.path.getmtime(OUT)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + \
-        [os.path.join(HERE, "..", "include", "fbx.h")]
+        [os.path.join(HERE, "..", "include", "fbx.h"), MAP]
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -32,7 +33,7 @@ def build(force=False, verbose=True, profile=False):
     tag = ""
     if profile:
         out = os.path.join(HERE, "libfbx_prof.so")
-        flags.append("-DFBX_PHASE_TIMERS")
+        flags += ["-DFBX_PHASE_TIMERS", "-DFBX_DIAGNOSTICS"]
         tag = ".prof"
         force = True
     if not force and not stale():
@@ -53,7 +54,7 @@ def build(force=False, verbose=True, profile=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + MAP, "-ldl"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -70,12 +71,12 @@ def build_guard_test(verbose=True):
     if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(lib):
         return out
     obj = os.path.join(HERE, "build", "fbx_pgdb.hip.cor.o")
-    cmd = [HIPCC] + FLAGS + ["-DFBX_DBG_CORRUPT_BASIS", "-DFBX_DEBUG_REJECT", "-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + ["-DFBX_DBG_CORRUPT_BASIS", "-DFBX_DEBUG_REJECT", "-DFBX_DIAGNOSTICS", "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     objs = [obj] + [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if s != src]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + MAP, "-ldl"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

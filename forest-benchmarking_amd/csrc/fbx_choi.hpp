@@ -30,6 +30,7 @@ struct ChoiLds {
     cplx* pts;     // [d * d]    partial trace in the Jacobi layout (TNI only)
     cplx* ptV;     // [d * d]    its eigenvectors (TNI only)
     PhaseClock* pc = nullptr;   // diagnostics (FBX_PHASE_TIMERS builds)
+    int terms = 0;              // work accounting: eigenvalue terms rebuilt by the CP projections (wave-uniform)
     static constexpr size_t bytes() {
         return sizeof(cplx) * (D * LD + 2 * D * D + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
     }
@@ -108,9 +109,10 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
     }
     sweeps += sw;
     PH_STOP(*L.pc, 0);
-    if (lane < D) {
-        const double l = L.Ms[sys_index<D>(lane, lane)].re;
-        L.lam[lane] = l < 0.0 ? 0.0 : l;
+    {
+        const double l = lane < D ? L.Ms[sys_index<D>(lane, lane)].re : 0.0;
+        if (lane < D) L.lam[lane] = l < 0.0 ? 0.0 : l;
+        L.terms += __popcll(__ballot(l > 0.0));
     }
     FBX_WAVE_SYNC();
     const Blk out = reconstruct_blk<D>(L.Vs, L.lam, lane);

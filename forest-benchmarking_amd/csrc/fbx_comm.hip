@@ -1,0 +1,191 @@
+// fbx_comm.hip -- the multi-GPU side of libfbx: one process per GPU, RCCL over xGMI.
+//
+// The reconstruction path shards on the batch axis with no exchange during compute (SURVEY.md 8e;
+// natural unit in the reference: one entry of get_results_by_qubit_groups,
+// observable_estimation.py:1145-1173, one bootstrap resample, tomography.py:440-451, one Kraus set).
+// What ranks do exchange is small and happens outside the estimators:
+//   * ncclBroadcast  of design-sized constants / a reference channel        (fbx_comm_broadcast_dev)
+//   * ncclAllGather  of result slabs when the consumer wants all of them    (fbx_comm_allgather_dev)
+//   * ncclAllReduce  (sum / max) of a summary vector of a few doubles       (fbx_comm_allreduce_f64)
+// xGMI is point to point (7 links x ~153 GB/s per GPU): a 32 MiB slab per peer is ~0.2 ms, the
+// summary vector is latency only -- ring size never matters for this path.
+//
+// librccl.so is opened on the first fbx_comm_* call (dlopen), not linked: it is a 570 MB image, and
+// single-GPU users of libfbx.so never touch it.  Only the types of <rccl/rccl.h> are used at build time.
+#include "fbx_common.hpp"
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace fbx {
+
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_mu;             // guards the loader and the communicator pointer
+ncclComm_t g_comm = nullptr;
+int g_rank = 0, g_world = 0, g_comm_device = -1;
+
+template <class F> bool sym(void* h, const char* name, F& out) {
+    out = reinterpret_cast<F>(dlsym(h, name));
+    return out != nullptr;
+}
+
+int load_rccl() {
+    if (g_rccl.handle) return FBX_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) { set_error(std::string("fbx_comm: cannot open librccl.so: ") + dlerror()); return FBX_ERR_RCCL; }
+    Rccl r; r.handle = h;
+    const bool ok = sym(h, "ncclGetUniqueId", r.GetUniqueId) && sym(h, "ncclCommInitRank", r.CommInitRank) &&
+                    sym(h, "ncclCommDestroy", r.CommDestroy) && sym(h, "ncclCommAbort", r.CommAbort) &&
+                    sym(h, "ncclAllGather", r.AllGather) && sym(h, "ncclAllReduce", r.AllReduce) &&
+                    sym(h, "ncclBroadcast", r.Broadcast) && sym(h, "ncclGetErrorString", r.GetErrorString) &&
+                    sym(h, "ncclGetVersion", r.GetVersion);
+    if (!ok) { dlclose(h); set_error("fbx_comm: librccl.so lacks an expected symbol"); return FBX_ERR_RCCL; }
+    g_rccl = r;
+    return FBX_OK;
+}
+
+int rccl_fail(ncclResult_t r, const char* what) {
+    set_error(std::string("RCCL error in ") + what + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    return FBX_ERR_RCCL;
+}
+#define FBX_RCCL(call, what) do { ncclResult_t _r = (call); if (_r != ncclSuccess) return rccl_fail(_r, what); } while (0)
+
+int need_comm(const char* who) {
+    if (!g_comm) { set_error(std::string(who) + ": no communicator (call fbx_comm_init first)"); return FBX_ERR_BAD_ARG; }
+    if (g_comm_device != current_device()) {
+        set_error(std::string(who) + ": the communicator belongs to another device"); return FBX_ERR_BAD_ARG;
+    }
+    return FBX_OK;
+}
+}  // namespace
+
+}  // namespace fbx
+
+using namespace fbx;
+
+extern "C" {
+
+int fbx_comm_unique_id(uint8_t* id_out) {
+    FBX_REQUIRE(id_out != nullptr, "fbx_comm_unique_id: NULL argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    FBX_RCCL(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+    static_assert(sizeof(id) == FBX_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof id);
+    return FBX_OK;
+}
+
+int fbx_comm_init(const uint8_t* id_in, int rank, int world) {
+    FBX_REQUIRE(id_in != nullptr, "fbx_comm_init: NULL id");
+    FBX_REQUIRE(world >= 1 && rank >= 0 && rank < world, "fbx_comm_init: need 0 <= rank < world");
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    FBX_REQUIRE(g_comm == nullptr, "fbx_comm_init: a communicator already exists (fbx_comm_destroy first)");
+    rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    FBX_HIP(hipSetDevice(current_device()));
+    ncclComm_t comm = nullptr;
+    FBX_RCCL(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    g_comm = comm; g_rank = rank; g_world = world; g_comm_device = current_device();
+    return FBX_OK;
+}
+
+int fbx_comm_info(int* rank, int* world, int* rccl_version) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (rank) *rank = g_comm ? g_rank : 0;
+    if (world) *world = g_comm ? g_world : 0;
+    if (rccl_version) {
+        *rccl_version = 0;
+        if (g_rccl.handle) { int v = 0; if (g_rccl.GetVersion(&v) == ncclSuccess) *rccl_version = v; }
+    }
+    return FBX_OK;
+}
+
+int fbx_comm_destroy(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_comm) return FBX_OK;
+    ncclComm_t c = g_comm;
+    g_comm = nullptr; g_world = 0; g_rank = 0; g_comm_device = -1;
+    FBX_RCCL(g_rccl.CommDestroy(c), "ncclCommDestroy");
+    return FBX_OK;
+}
+
+int fbx_comm_allgather_dev(const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    int rc = need_comm("fbx_comm_allgather_dev");
+    if (rc) return rc;
+    FBX_REQUIRE(bytes_per_rank == 0 || (d_send && d_recv), "fbx_comm_allgather_dev: NULL buffer");
+    if (bytes_per_rank == 0) return FBX_OK;
+    // slabs are complex128 / float64 / int32 arrays: moved as bytes (8-byte words when the size allows)
+    if (bytes_per_rank % 8 == 0)
+        FBX_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank / 8, ncclUint64, g_comm, stream()), "ncclAllGather");
+    else
+        FBX_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, g_comm, stream()), "ncclAllGather");
+    return FBX_OK;
+}
+
+int fbx_comm_broadcast_dev(void* d_buf, size_t bytes, int root) {
+    int rc = need_comm("fbx_comm_broadcast_dev");
+    if (rc) return rc;
+    FBX_REQUIRE(root >= 0 && root < g_world, "fbx_comm_broadcast_dev: root out of range");
+    FBX_REQUIRE(bytes == 0 || d_buf, "fbx_comm_broadcast_dev: NULL buffer");
+    if (bytes == 0) return FBX_OK;
+    FBX_RCCL(g_rccl.Broadcast(d_buf, d_buf, bytes, ncclUint8, root, g_comm, stream()), "ncclBroadcast");
+    return FBX_OK;
+}
+
+int fbx_comm_allreduce_f64_dev(const double* d_send, double* d_recv, size_t n, int op) {
+    int rc = need_comm("fbx_comm_allreduce_f64_dev");
+    if (rc) return rc;
+    FBX_REQUIRE(op == FBX_COMM_SUM || op == FBX_COMM_MAX || op == FBX_COMM_MIN, "fbx_comm_allreduce_f64_dev: bad op");
+    FBX_REQUIRE(n == 0 || (d_send && d_recv), "fbx_comm_allreduce_f64_dev: NULL buffer");
+    if (n == 0) return FBX_OK;
+    const ncclRedOp_t rop = op == FBX_COMM_SUM ? ncclSum : op == FBX_COMM_MAX ? ncclMax : ncclMin;
+    FBX_RCCL(g_rccl.AllReduce(d_send, d_recv, n, ncclDouble, rop, g_comm, stream()), "ncclAllReduce");
+    return FBX_OK;
+}
+
+int fbx_comm_allreduce_f64(double* host_inout, size_t n, int op) {
+    int rc = need_comm("fbx_comm_allreduce_f64");
+    if (rc) return rc;
+    FBX_REQUIRE(n == 0 || host_inout, "fbx_comm_allreduce_f64: NULL buffer");
+    FBX_REQUIRE(n <= 4096, "fbx_comm_allreduce_f64: the host form is for summary vectors (n <= 4096)");
+    if (n == 0) return FBX_OK;
+    void* w = nullptr;
+    rc = workspace(WS_COMM, sizeof(double) * 4096, &w);
+    if (rc) return rc;
+    double* d = (double*)w;
+    FBX_HIP(hipMemcpyAsync(d, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+    rc = fbx_comm_allreduce_f64_dev(d, d, n, op);
+    if (rc) return rc;
+    FBX_HIP(hipMemcpyAsync(host_inout, d, sizeof(double) * n, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
+
+int fbx_comm_barrier(void) {
+    // every kernel this thread enqueued is complete on every rank when this returns
+    double one = 1.0;
+    return fbx_comm_allreduce_f64(&one, 1, FBX_COMM_SUM);
+}
+
+}  // extern "C"

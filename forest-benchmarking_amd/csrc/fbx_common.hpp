@@ -10,12 +10,27 @@
 
 namespace fbx {
 
-// ------------------------------------------------------------------ host: errors / stream
+// ------------------------------------------------------------------ host: errors / per-thread context
+// The library is re-entrant across host threads (ctypes drops the GIL during a call): every host
+// thread that enters the library owns a context -- its HIP stream, its timer events, its cached
+// device workspaces and its pool of staging buffers -- so two threads never share mutable state.
+// The only process-wide state is the selected device (fbx_set_device, "one process per GPU") and
+// the RCCL communicator (fbx_comm_*).
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
-hipStream_t stream();
+hipStream_t stream();    // the calling thread's stream (created on first use)
 int device_epoch();      // increases whenever fbx_set_device selects a different device: cached device memory is stale then
-int ensure_device();   // FBX_OK or FBX_ERR_NO_DEVICE (message set)
+int current_device();    // device selected for the process, -1 before the first use
+int ensure_device();     // FBX_OK or FBX_ERR_NO_DEVICE (message set)
+
+// Named grow-only device workspaces of the calling thread (kept between calls; released by
+// fbx_release_workspace).  A workspace only ever serves kernels on the calling thread's stream, so
+// growing it (stream sync + hipFree + hipMalloc) cannot pull memory from under another thread's kernel.
+enum WorkspaceSlot { WS_PGDB_BASIS = 0, WS_PGDB3_BASIS = 1, WS_SWEEP_REF = 2, WS_COMM = 3, WS_COUNT = 4 };
+int workspace(WorkspaceSlot slot, size_t bytes, void** out);
+// staging blocks of the host-pointer entry points: taken from / returned to the calling thread's pool
+int pool_take(size_t bytes, void** out);
+void pool_give(void* p);
 
 #define FBX_HIP(call)                                                          \
     do {                                                                       \
@@ -28,16 +43,13 @@ int ensure_device();   // FBX_OK or FBX_ERR_NO_DEVICE (message set)
         if (!(cond)) { fbx::set_error(msg); return FBX_ERR_BAD_ARG; }          \
     } while (0)
 
-// RAII device buffer for the host-pointer entry points
+// Device staging buffer of a host-pointer entry point.  The block comes from the calling thread's
+// pool (no hipMalloc / hipFree per call once the pool is warm) and goes back when the entry point
+// returns -- every such entry point synchronises its stream before it does.
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) {
-        if (bytes == 0) bytes = 16;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
-        return FBX_OK;
-    }
+    ~DevBuf() { if (p) pool_give(p); }
+    int alloc(size_t bytes) { return pool_take(bytes ? bytes : 16, &p); }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
@@ -61,6 +73,8 @@ struct DesignDev {
 
 struct fbx_design {
     fbx::DesignDev dev;
+    int device = -1;         // device (and selection epoch) the slabs were allocated on
+    int epoch = -1;
     void* slab = nullptr;    // one device allocation backing every pointer in dev
     void* slab2 = nullptr;   // linear-inversion tables (process designs)
     std::vector<double> C_host;
@@ -70,6 +84,8 @@ struct fbx_design {
 };
 
 namespace fbx {
+
+int check_design(const fbx_design* des, const char* who);   // FBX_OK, or FBX_ERR_BAD_ARG for NULL / a design of another device
 
 // ------------------------------------------------------------------ device helpers
 #if defined(__HIPCC__)

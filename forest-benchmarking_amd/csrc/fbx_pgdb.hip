@@ -105,7 +105,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
             double* __restrict__ choi_out, int* __restrict__ iters_out,
             int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-            double* __restrict__ cost_out, int* __restrict__ sweeps_out,
+            double* __restrict__ cost_out, int* __restrict__ work_out,
             long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -200,9 +200,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     FBX_WAVE_SYNC();
 
     int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
-#ifdef FBX_DEBUG_LS
-    int ls_full = 0;
-#endif
+    int ls_full = 0, ls_sums = 0;          // work accounting: full cost evaluations / power-sum reductions
     // eigenvector bases of the previous outer iteration's Dykstra run (fbx_choi.hpp BasisStore)
     BasisStore basis;
     basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
@@ -233,7 +231,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         FBX_WAVE_SYNC();
         PH_STOP(pc, 7);
         load_probs(L.Test, pep, pem, 1.0);
-        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }   // tomography.py:565
+        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; ++ls_full; }   // tomography.py:565
 
         // ---- gradient (tomography.py:617-633): eta = n / clip(p); per input state s the weights of the
         // Pauli components, Wt[s][0] = sum (eta+ + eta-)/2 and Wt[s][p] = coef (eta+ - eta-)/2, added
@@ -405,12 +403,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             return alpha * q;
         };
         auto cost_step = [&](double alpha) __attribute__((always_inline)) -> double {
-            if (!small_regime(alpha)) {
-#ifdef FBX_DEBUG_LS
-                ++ls_full;
-#endif
-                return cost_at(alpha);
-            }
+            if (!small_regime(alpha)) { ++ls_full; return cost_at(alpha); }
             if (!have_sums) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) Sk[k] = 0.0;
@@ -426,7 +419,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 }
 #pragma unroll
                 for (int k = 0; k < NS; ++k) Sk[k] = uniform(wave_sum(Sk[k])) * ((k & 1) ? -1.0 : 1.0) / (double)(k + 1);
-                have_sums = true;
+                have_sums = true; ++ls_sums;
             }
             double acc = series(alpha);
             if (near_clip)                   // the listed outcomes: exact difference of clipped logs
@@ -434,7 +427,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             return old_cost - acc;
         };
 #else
-        auto cost_step = [&](double alpha) -> double { return cost_at(alpha); };
+        auto cost_step = [&](double alpha) -> double { ++ls_full; return cost_at(alpha); };
 #endif
         double alpha = 1.0;
         new_cost = cost_step(alpha);
@@ -498,37 +491,41 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             o[0] = est.re[e]; o[1] = est.im[e];
         }
     }
-#ifdef FBX_DEBUG_LS
-    sweeps = ls_full;
-#endif
     if (lane == 0) {
         if (iters_out) iters_out[item] = iters;
         if (dykstra_out) dykstra_out[item] = dyk;
         if (backtracks_out) backtracks_out[item] = backtracks;
         if (cost_out) cost_out[item] = have_cost ? new_cost : 0.0;
-        if (sweeps_out) sweeps_out[item] = sweeps;
+        if (work_out) {     // Jacobi sweeps, eigenvalue terms rebuilt, full cost evaluations, power-sum reductions
+            work_out[4 * item] = sweeps; work_out[4 * item + 1] = L.choi.terms;
+            work_out[4 * item + 2] = ls_full; work_out[4 * item + 3] = ls_sums;
+        }
     }
 #ifdef FBX_PHASE_TIMERS
     if (lane == 0 && phase_out) for (int i = 0; i < FBX_NPHASE; ++i) phase_out[item * FBX_NPHASE + i] = pc.acc[i];
 #endif
 }
 
+#ifdef FBX_DIAGNOSTICS
 __global__ void debug_log_kernel(const double* x, double* out, long long n) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i < n) out[i] = fast_log_pos(x[i]);
 }
+#endif
 
-static cplx* g_basis = nullptr;            // Dykstra eigenvector bases of the items in flight (see launch_pgdb)
-static size_t g_basis_bytes = 0;
-static int g_basis_epoch = -1;            // device_epoch() the workspace was allocated in
 constexpr int BASIS_CAP = 32;              // Dykstra iterations per projection that get a stored basis
 
-long long* g_phase_out = nullptr;          // diagnostics: set by fbx_debug_set_phase_buffer (also read by fbx_pgdb3.hip)
+#ifdef FBX_DIAGNOSTICS
+long long* g_phase_out = nullptr;          // diagnostics builds only: set by fbx_debug_set_phase_buffer (also read by fbx_pgdb3.hip)
+#define FBX_PHASE_OUT(b0) (g_phase_out ? g_phase_out + (b0) * 8 : nullptr)
+#else
+#define FBX_PHASE_OUT(b0) ((long long*)nullptr)
+#endif
 
 template <int NQ, int MAXJ>
 static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                        int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
-                       double* cost) {
+                       double* cost, int32_t* sw) {
     const size_t lds = PgdbLds<NQ>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
     if (lds > 160 * 1024) {
         set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
@@ -536,49 +533,51 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     }
     auto kern = pgdb_kernel<NQ, MAXJ>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each), kept by the
-    // library between calls (grow-only); larger batches go in chunks that reuse it
+    // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each = 128 KiB per 2-qubit
+    // item, at most 1 GiB): a grow-only workspace of the calling thread (released by
+    // fbx_release_workspace); larger batches go in chunks that reuse it.  A single outer iteration has
+    // no previous iteration to take a basis from: no store then.
     constexpr int D = 1 << (2 * NQ);
     constexpr int64_t CHUNK = 8192;
     const int64_t in_flight = B < CHUNK ? B : CHUNK;
-    const size_t need = sizeof(cplx) * D * D * BASIS_CAP * (size_t)in_flight;
-    if (need > g_basis_bytes || g_basis_epoch != device_epoch()) {
-        if (g_basis) (void)hipFree(g_basis);
-        g_basis = nullptr; g_basis_bytes = 0;
-        FBX_HIP(hipMalloc((void**)&g_basis, need));
-        g_basis_bytes = need; g_basis_epoch = device_epoch();
+    cplx* basis = nullptr;
+    if (!(mode == FBX_MODE_FIXED && max_iters <= 1) && !(mode == FBX_MODE_CONVERGE && max_iters == 1)) {
+        void* w = nullptr;
+        const int rc = workspace(WS_PGDB_BASIS, sizeof(cplx) * D * D * BASIS_CAP * (size_t)in_flight, &w);
+        if (rc) return rc;
+        basis = (cplx*)w;
     }
-    const bool dbg = getenv("FBX_DEBUG_SWEEPS") != nullptr;
     const size_t m = des->dev.m;
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, stream(), des->dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2,
-                           it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, (!dbg && bt) ? bt + b0 : nullptr,
-                           cost ? cost + b0 : nullptr, (dbg && bt) ? bt + b0 : (int*)nullptr,
-                           g_phase_out ? g_phase_out + b0 * 8 : nullptr, g_basis, BASIS_CAP);
+                           it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr,
+                           cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr,
+                           FBX_PHASE_OUT(b0), basis, BASIS_CAP);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
 }
 
 int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
-                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost);   // fbx_pgdb3.hip
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost,
+                   int32_t* sw);   // fbx_pgdb3.hip
 
 static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                          int mode, int max_iters, double* choi, int32_t* it, int32_t* dy,
-                         int32_t* bt, double* cost) {
+                         int32_t* bt, double* cost, int32_t* sw) {
     const int n = des->dev.n, m = des->dev.m;
     if (n == 1) {
-        if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
-        if (m <= 256) return launch_pgdb<1, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+        if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+        if (m <= 256) return launch_pgdb<1, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
     } else if (n == 2) {
-        if (m <= 256) return launch_pgdb<2, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
-        if (m <= 576) return launch_pgdb<2, 9>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
-        if (m <= 1024) return launch_pgdb<2, 16>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+        if (m <= 256) return launch_pgdb<2, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+        if (m <= 576) return launch_pgdb<2, 9>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+        if (m <= 1024) return launch_pgdb<2, 16>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
     }
     else if (n == 3) {
-        return pgdb3_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+        return pgdb3_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
     }
     set_error("fbx_pgdb_process: design outside the supported sizes (1 qubit m <= 256, 2 qubits m <= 1024)");
     return FBX_ERR_UNSUPPORTED;
@@ -586,7 +585,7 @@ static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, cons
 
 static int pgdb_check(const fbx_design* des, int64_t B, const void* e, const void* c, int mode,
                       int max_iters, const void* choi) {
-    FBX_REQUIRE(des != nullptr, "fbx_pgdb_process: NULL design");
+    { const int rc = check_design(des, "fbx_pgdb_process"); if (rc) return rc; }
     FBX_REQUIRE(des->dev.kind == FBX_KIND_PROCESS, "fbx_pgdb_process: needs a process design");
     FBX_REQUIRE(B >= 0, "fbx_pgdb_process: negative batch");
     FBX_REQUIRE(B == 0 || (e && c && choi), "fbx_pgdb_process: NULL buffer");
@@ -601,11 +600,12 @@ using namespace fbx;
 
 extern "C" {
 
-// diagnostics only (not part of include/fbx.h): device buffer of 8 int64 per item that a
-// -DFBX_PHASE_TIMERS build fills with per-phase shader cycles
+#ifdef FBX_DIAGNOSTICS
+// diagnostics builds only (libfbx_prof.so / libfbx_cor.so; not part of include/fbx.h, not in libfbx.so):
+// device buffer of 8 int64 per item that a -DFBX_PHASE_TIMERS build fills with per-phase shader cycles
 int fbx_debug_set_phase_buffer(long long* d_buf) { g_phase_out = d_buf; return FBX_OK; }
 
-// diagnostics only: the device natural log used by the PGDB line search, on host arrays
+// the device natural log used by the PGDB line search, on host arrays
 int fbx_debug_log(const double* x, double* out, int64_t n) {
     int rc = ensure_device();
     if (rc) return rc;
@@ -619,47 +619,49 @@ int fbx_debug_log(const double* x, double* out, int64_t n) {
     FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
 }
+#endif
 
 int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
                          const double* d_counts, int trace_preserving, int mode, int max_iters,
                          double* d_choi_out, int32_t* d_iters_out, int32_t* d_dykstra_out,
-                         int32_t* d_backtracks_out, double* d_cost_out) {
-    int rc = pgdb_check(design, B, d_expect, d_counts, mode, max_iters, d_choi_out);
+                         int32_t* d_backtracks_out, double* d_cost_out, int32_t* d_work_out) {
+    int rc = ensure_device();
     if (rc) return rc;
-    rc = ensure_device();
+    rc = pgdb_check(design, B, d_expect, d_counts, mode, max_iters, d_choi_out);
     if (rc) return rc;
     if (B == 0) return FBX_OK;
     return pgdb_dispatch(design, B, d_expect, d_counts, trace_preserving, mode, max_iters,
-                         d_choi_out, d_iters_out, d_dykstra_out, d_backtracks_out, d_cost_out);
+                         d_choi_out, d_iters_out, d_dykstra_out, d_backtracks_out, d_cost_out, d_work_out);
 }
 
 int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
                      const double* counts, int trace_preserving, int mode, int max_iters,
                      double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
-                     int32_t* backtracks_out, double* cost_out) {
-    int rc = pgdb_check(design, B, expect, counts, mode, max_iters, choi_out);
+                     int32_t* backtracks_out, double* cost_out, int32_t* work_out) {
+    int rc = ensure_device();
     if (rc) return rc;
-    rc = ensure_device();
+    rc = pgdb_check(design, B, expect, counts, mode, max_iters, choi_out);
     if (rc) return rc;
     if (B == 0) return FBX_OK;
     const size_t m = design->dev.m, D = design->dev.D;
-    DevBuf de, dc, dchoi, dit, ddy, dbt, dcost;
+    DevBuf de, dc, dchoi, dit, ddy, dbt, dcost, dsw;
     if ((rc = de.alloc(sizeof(double) * B * m)) || (rc = dc.alloc(sizeof(double) * B * m)) ||
         (rc = dchoi.alloc(sizeof(double) * 2 * B * D * D)) || (rc = dit.alloc(sizeof(int32_t) * B)) ||
         (rc = ddy.alloc(sizeof(int32_t) * B)) || (rc = dbt.alloc(sizeof(int32_t) * B)) ||
-        (rc = dcost.alloc(sizeof(double) * B)))
+        (rc = dcost.alloc(sizeof(double) * B)) || (rc = dsw.alloc(sizeof(int32_t) * 4 * B)))
         return rc;
     FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
     FBX_HIP(hipMemcpyAsync(dc.p, counts, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
     rc = pgdb_dispatch(design, B, de.as<double>(), dc.as<double>(), trace_preserving, mode, max_iters,
                        dchoi.as<double>(), dit.as<int32_t>(), ddy.as<int32_t>(), dbt.as<int32_t>(),
-                       dcost.as<double>());
-    if (rc) return rc;
+                       dcost.as<double>(), dsw.as<int32_t>());
+    if (rc) { (void)hipStreamSynchronize(stream()); return rc; }
     FBX_HIP(hipMemcpyAsync(choi_out, dchoi.p, sizeof(double) * 2 * B * D * D, hipMemcpyDeviceToHost, stream()));
     if (iters_out) FBX_HIP(hipMemcpyAsync(iters_out, dit.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
     if (dykstra_out) FBX_HIP(hipMemcpyAsync(dykstra_out, ddy.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
     if (backtracks_out) FBX_HIP(hipMemcpyAsync(backtracks_out, dbt.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
     if (cost_out) FBX_HIP(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
+    if (work_out) FBX_HIP(hipMemcpyAsync(work_out, dsw.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, stream()));
     FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
 }

@@ -15,7 +15,12 @@
 
 namespace fbx {
 
-extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics)
+#ifdef FBX_DIAGNOSTICS
+extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
+#define FBX_PHASE_OUT3(b0) (g_phase_out ? g_phase_out + (b0) * 8 : nullptr)
+#else
+#define FBX_PHASE_OUT3(b0) ((long long*)nullptr)
+#endif
 
 namespace p3 {
 constexpr int NQ = 3, d = 8, D = 64, NB = 32, NT = 1024, LD = 64, LDs = d + 1;
@@ -30,6 +35,7 @@ struct Lds {
     // overlay on Rt (alive only while R is dead):
     cplx* pt; cplx* pts; cplx* ptV; double* lam; double* red;
     PhaseClock* pc;  // diagnostics (-DFBX_PHASE_TIMERS)
+    int terms = 0;   // work accounting: eigenvalue terms rebuilt by the CP projections
     __device__ void carve(char* p) {
         Ms = (cplx*)p; Vs = Ms + D * D; Mw = Vs; T = (double*)p;
         Rt = (double*)(p + 2 * sizeof(cplx) * D * D);
@@ -151,6 +157,11 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
         L.lam[t] = l < 0.0 ? 0.0 : l;
     }
     __syncthreads();
+    {   // work accounting: eigenvalue terms the reconstruction walks (same count in every thread)
+        int cnt = 0;
+        for (int k = 0; k < D; ++k) cnt += L.lam[k] != 0.0;
+        L.terms += cnt;
+    }
     const Blk out = reconstruct_blk<D>(L.Vs, L.lam, t);
     PH_STOP(*L.pc, 1);
     return out;
@@ -419,7 +430,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
 
     Blk est = blk_zero();
     { const int I = t / NB, J = t % NB; if (I == J) { est.re[0] = 1.0 / d; est.re[3] = 1.0 / d; } }
-    int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
+    int iters = 0, dyk = 0, backtracks = 0, sweeps = 0, cost_evals = 0;
     double old_cost = 0.0, new_cost = 0.0;
     bool have_cost = false;
     BasisStore basis;
@@ -435,7 +446,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         predict_table(des, L, t);
         load_probs(pep, pem);
         PH_STOP(pc, 7);
-        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; }
+        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; ++cost_evals; }
         PH_STOP(pc, 5);
 
         // ---- gradient (tomography.py:617-633): W[i][s] = sum over the settings of state s.
@@ -517,11 +528,11 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         blk_dotc(upd, grad, ipr, ipi);
         ipr = bsum(ipr, L);
         double alpha = 1.0;
-        new_cost = cost_at(alpha);
+        new_cost = cost_at(alpha); ++cost_evals;
         double change = GAMMA * alpha * ipr;
         while (new_cost > old_cost + change) {
             alpha *= 0.5; change *= 0.5;
-            new_cost = cost_at(alpha);
+            new_cost = cost_at(alpha); ++cost_evals; ++cost_evals;
             ++backtracks;
             if (alpha < ALPHA_MIN) break;
         }
@@ -552,13 +563,16 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         if (dykstra_out) dykstra_out[item] = dyk;
         if (backtracks_out) backtracks_out[item] = backtracks;
         if (cost_out) cost_out[item] = have_cost ? new_cost : 0.0;
-        if (sweeps_out) sweeps_out[item] = sweeps;      // FBX_DEBUG_SWEEPS: overrides the backtrack count
+        if (sweeps_out) {     // work_out[4]: Jacobi sweeps, eigenvalue terms rebuilt, cost evaluations, 0
+            sweeps_out[4 * item] = sweeps; sweeps_out[4 * item + 1] = L.terms;
+            sweeps_out[4 * item + 2] = cost_evals; sweeps_out[4 * item + 3] = 0;
+        }
     }
 }
 
 template <int MAXJ>
 static int launch3(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
-                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost) {
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw) {
     const size_t lds = p3::Lds::bytes();
     if ((size_t)des->dev.S * p3::D * sizeof(double) > 2 * sizeof(cplx) * p3::D * p3::D) {
         set_error("fbx_pgdb_process: too many distinct input states for the 3-qubit kernel");
@@ -573,8 +587,10 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
 #define FBX_BASIS_CAP3 24
 #endif
     constexpr int BASIS_CAP = FBX_BASIS_CAP3;   // Dykstra iterations per projection with a stored basis (64 KiB each)
-    cplx* scratch = nullptr;
-    FBX_HIP(hipMalloc((void**)&scratch, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK) * BASIS_CAP));
+    // (a grow-only workspace of the calling thread, released by fbx_release_workspace)
+    void* w = nullptr;
+    { const int rc = workspace(WS_PGDB3_BASIS, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK) * BASIS_CAP, &w); if (rc) return rc; }
+    cplx* scratch = (cplx*)w;
     cplx* basis = scratch;                   // (`scratch` itself only tells the kernel that warm starts are on)
     const size_t m = des->dev.m, DD = (size_t)p3::D * p3::D;
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
@@ -582,14 +598,9 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), des->dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
                            dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch,
-                           g_phase_out ? g_phase_out + b0 * 8 : nullptr,
-                           (getenv("FBX_DEBUG_SWEEPS") && bt) ? bt + b0 : nullptr, basis, BASIS_CAP);
+                           FBX_PHASE_OUT3(b0), sw ? sw + 4 * b0 : nullptr, basis, BASIS_CAP);
     }
-    hipError_t le = hipGetLastError();
-    hipError_t se = hipStreamSynchronize(stream());
-    (void)hipFree(scratch);
-    if (le != hipSuccess) return hip_fail(le, "pgdb3_kernel launch", __FILE__, __LINE__);
-    if (se != hipSuccess) return hip_fail(se, "pgdb3_kernel", __FILE__, __LINE__);
+    FBX_HIP(hipGetLastError());
     return FBX_OK;
 }
 
@@ -668,10 +679,10 @@ int linv_process3_launch(const fbx_design* des, int64_t B, const double* d_expec
 
 // called from fbx_pgdb.hip's dispatcher
 int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
-                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost) {
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw) {
     const int m = des->dev.m;
-    if (m <= 4096) return launch3<4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
-    if (m <= 14336) return launch3<14>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost);
+    if (m <= 4096) return launch3<4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+    if (m <= 14336) return launch3<14>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
     set_error("fbx_pgdb_process: 3-qubit designs are limited to 14336 settings");
     return FBX_ERR_UNSUPPORTED;
 }

@@ -3,15 +3,58 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <atomic>
 #include <map>
 
 namespace fbx {
 
 static thread_local std::string g_err;
-static hipStream_t g_stream = nullptr;
-static int g_device = -1;
-static int g_epoch = 0;
-static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static std::atomic<int> g_device{-1};     // process-wide: one process per GPU
+static std::atomic<int> g_epoch{0};
+
+// Per-thread context (see fbx_common.hpp).  Contexts are heap objects that are never destroyed behind
+// the runtime's back (a thread_local destructor could run after the HIP runtime has shut down): a thread
+// gives its device memory back with fbx_release_workspace().
+struct ThreadCtx {
+    int epoch = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    struct Block { void* p; size_t bytes; bool busy; };
+    std::vector<Block> pool;
+    void* ws[WS_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[WS_COUNT] = {0, 0, 0, 0};
+
+    void drop_memory() {
+        for (auto& b : pool) if (b.p) (void)hipFree(b.p);
+        pool.clear();
+        for (int i = 0; i < WS_COUNT; ++i) { if (ws[i]) (void)hipFree(ws[i]); ws[i] = nullptr; ws_bytes[i] = 0; }
+    }
+    void drop_all() {
+        drop_memory();
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
+        if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        timing = false;
+    }
+};
+static thread_local ThreadCtx* t_ctx = nullptr;
+
+// the calling thread's context, bound to the currently selected device (nullptr + error set on failure)
+static ThreadCtx* ctx() {
+    if (!t_ctx) t_ctx = new ThreadCtx();
+    ThreadCtx* c = t_ctx;
+    const int ep = g_epoch.load();
+    if (c->epoch != ep) {                 // first use, or the process moved to another device
+        c->drop_all();
+        if (hipSetDevice(g_device.load()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError(); c->stream = nullptr; return nullptr;
+        }
+        c->epoch = ep;
+    }
+    return c;
+}
 
 void set_error(const std::string& msg) { g_err = msg; }
 
@@ -24,19 +67,82 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 int ensure_device() {
-    if (g_device >= 0) return FBX_OK;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        (void)hipGetLastError();
-        set_error("libfbx: no HIP device visible -- the MI355X path has no CPU fallback");
-        return FBX_ERR_NO_DEVICE;
+    if (g_device.load() < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            set_error("libfbx: no HIP device visible -- the MI355X path has no CPU fallback");
+            return FBX_ERR_NO_DEVICE;
+        }
+        int rc = fbx_set_device(0);
+        if (rc) return rc;
     }
-    return fbx_set_device(0);
+    if (!ctx()) { set_error("libfbx: could not create the calling thread's HIP stream"); return FBX_ERR_HIP; }
+    return FBX_OK;
 }
 
-hipStream_t stream() { return g_stream; }
-int device_epoch() { return g_epoch; }
+hipStream_t stream() { ThreadCtx* c = ctx(); return c ? c->stream : nullptr; }
+int device_epoch() { return g_epoch.load(); }
+int current_device() { return g_device.load(); }
+
+int workspace(WorkspaceSlot slot, size_t bytes, void** out) {
+    ThreadCtx* c = ctx();
+    if (!c) { set_error("libfbx: no device context"); return FBX_ERR_HIP; }
+    if (bytes > c->ws_bytes[slot]) {
+        if (c->ws[slot]) {
+            FBX_HIP(hipStreamSynchronize(c->stream));       // kernels of this thread may still read the old block
+            (void)hipFree(c->ws[slot]);
+            c->ws[slot] = nullptr; c->ws_bytes[slot] = 0;
+        }
+        FBX_HIP(hipMalloc(&c->ws[slot], bytes));
+        c->ws_bytes[slot] = bytes;
+    }
+    *out = c->ws[slot];
+    return FBX_OK;
+}
+
+int pool_take(size_t bytes, void** out) {
+    ThreadCtx* c = ctx();
+    if (!c) { set_error("libfbx: no device context"); return FBX_ERR_HIP; }
+    int best = -1;
+    for (int i = 0; i < (int)c->pool.size(); ++i) {
+        const auto& b = c->pool[i];
+        if (!b.busy && b.bytes >= bytes && (best < 0 || b.bytes < c->pool[best].bytes)) best = i;
+    }
+    if (best >= 0 && c->pool[best].bytes <= 4 * bytes + (1u << 20)) {
+        c->pool[best].busy = true; *out = c->pool[best].p; return FBX_OK;
+    }
+    if (c->pool.size() >= 24) {            // bound the cache: drop what is idle before adding a block
+        FBX_HIP(hipStreamSynchronize(c->stream));
+        std::vector<ThreadCtx::Block> keep;
+        for (auto& b : c->pool) { if (b.busy) keep.push_back(b); else (void)hipFree(b.p); }
+        c->pool.swap(keep);
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(staging)", __FILE__, __LINE__);
+    c->pool.push_back({p, bytes, true});
+    *out = p;
+    return FBX_OK;
+}
+
+void pool_give(void* p) {
+    ThreadCtx* c = t_ctx;
+    if (!c) return;
+    for (auto& b : c->pool) if (b.p == p) { b.busy = false; return; }
+    (void)hipFree(p);                      // block of an earlier device epoch
+}
+
+int check_design(const fbx_design* des, const char* who) {
+    if (!des) { set_error(std::string(who) + ": NULL design"); return FBX_ERR_BAD_ARG; }
+    if (des->device != g_device.load() || des->epoch != g_epoch.load()) {
+        set_error(std::string(who) + ": the design was created on another device (or before fbx_set_device "
+                  "changed the device); create it again");
+        return FBX_ERR_BAD_ARG;
+    }
+    return FBX_OK;
+}
 
 }  // namespace fbx
 
@@ -44,7 +150,7 @@ using namespace fbx;
 
 extern "C" {
 
-int fbx_version(void) { return 100; }
+int fbx_version(void) { return 200; }
 
 const char* fbx_last_error(void) { return g_err.c_str(); }
 
@@ -67,14 +173,11 @@ int fbx_set_device(int device_id) {
     }
     FBX_REQUIRE(device_id >= 0 && device_id < n, "fbx_set_device: device id out of range");
     FBX_HIP(hipSetDevice(device_id));
-    if (g_stream && g_device != device_id) {
-        (void)hipStreamDestroy(g_stream); g_stream = nullptr;
-        if (g_ev0) { (void)hipEventDestroy(g_ev0); g_ev0 = nullptr; }
-        if (g_ev1) { (void)hipEventDestroy(g_ev1); g_ev1 = nullptr; }
+    if (g_device.load() != device_id) {     // every thread context and every design of the old device goes stale
+        g_device.store(device_id);
+        g_epoch.fetch_add(1);
     }
-    if (!g_stream) FBX_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    if (g_device != device_id) ++g_epoch;
-    g_device = device_id;
+    if (!ctx()) { set_error("libfbx: could not create the calling thread's HIP stream"); return FBX_ERR_HIP; }
     return FBX_OK;
 }
 
@@ -82,7 +185,7 @@ int fbx_device_name(char* buf, size_t len, int* compute_units) {
     int rc = ensure_device();
     if (rc) return rc;
     hipDeviceProp_t prop;
-    FBX_HIP(hipGetDeviceProperties(&prop, g_device));
+    FBX_HIP(hipGetDeviceProperties(&prop, g_device.load()));
     if (buf && len) snprintf(buf, len, "%s (%s)", prop.name, prop.gcnArchName);
     if (compute_units) *compute_units = prop.multiProcessorCount;
     return FBX_OK;
@@ -91,7 +194,15 @@ int fbx_device_name(char* buf, size_t len, int* compute_units) {
 int fbx_synchronize(void) {
     int rc = ensure_device();
     if (rc) return rc;
-    FBX_HIP(hipStreamSynchronize(g_stream));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
+
+int fbx_release_workspace(void) {
+    if (g_device.load() < 0 || !t_ctx) return FBX_OK;
+    ThreadCtx* c = t_ctx;
+    if (c->stream && c->epoch == g_epoch.load()) FBX_HIP(hipStreamSynchronize(c->stream));
+    c->drop_memory();
     return FBX_OK;
 }
 
@@ -112,34 +223,38 @@ int fbx_free(void* dev_ptr) {
 int fbx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
     int rc = ensure_device();
     if (rc) return rc;
-    FBX_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, g_stream));
-    FBX_HIP(hipStreamSynchronize(g_stream));
+    FBX_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
 }
 
 int fbx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
     int rc = ensure_device();
     if (rc) return rc;
-    FBX_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, g_stream));
-    FBX_HIP(hipStreamSynchronize(g_stream));
+    FBX_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
 }
 
 int fbx_timer_begin(void) {
     int rc = ensure_device();
     if (rc) return rc;
-    if (!g_ev0) { FBX_HIP(hipEventCreate(&g_ev0)); FBX_HIP(hipEventCreate(&g_ev1)); }
-    FBX_HIP(hipEventRecord(g_ev0, g_stream));
+    ThreadCtx* c = ctx();
+    if (!c->ev0) { FBX_HIP(hipEventCreate(&c->ev0)); FBX_HIP(hipEventCreate(&c->ev1)); }
+    FBX_HIP(hipEventRecord(c->ev0, c->stream));
+    c->timing = true;
     return FBX_OK;
 }
 
 int fbx_timer_end(double* elapsed_ms) {
-    FBX_REQUIRE(elapsed_ms != nullptr && g_ev0 != nullptr, "fbx_timer_end without fbx_timer_begin");
-    FBX_HIP(hipEventRecord(g_ev1, g_stream));
-    FBX_HIP(hipEventSynchronize(g_ev1));
+    ThreadCtx* c = t_ctx;
+    FBX_REQUIRE(elapsed_ms != nullptr && c != nullptr && c->timing, "fbx_timer_end without fbx_timer_begin");
+    FBX_HIP(hipEventRecord(c->ev1, c->stream));
+    FBX_HIP(hipEventSynchronize(c->ev1));
     float ms = 0.f;
-    FBX_HIP(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+    FBX_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *elapsed_ms = ms;
+    c->timing = false;
     return FBX_OK;
 }
 
@@ -387,6 +502,7 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
         des->dev.pptr = (const int*)(b2 + oPp);
         des->dev.pinvT = (const double*)(b2 + oPi);
     }
+    des->device = current_device(); des->epoch = device_epoch();
     *out = des;
     return FBX_OK;
 }

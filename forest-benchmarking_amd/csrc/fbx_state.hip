@@ -602,6 +602,10 @@ static int launch_eigh(int64_t B, const double* da, double* dw, double* dv) {
 
 using namespace fbx;
 
+#ifndef FBX_MLE_UNPACKED
+#define FBX_MLE_UNPACKED 0      // diagnostics: 1 = always one reconstruction per wavefront
+#endif
+
 namespace {
 struct HostIO {
     std::vector<DevBuf*> bufs;
@@ -645,7 +649,7 @@ size_t state_lds(int n, int m) {
     return n == 1 ? StateLds<1>::bytes(m) : n == 2 ? StateLds<2>::bytes(m) : StateLds<3>::bytes(m);
 }
 int check_state_design(const fbx_design* des, const char* who) {
-    if (!des) { set_error(std::string(who) + ": NULL design"); return FBX_ERR_BAD_ARG; }
+    { const int rc = check_design(des, who); if (rc) return rc; }
     if (des->dev.kind != FBX_KIND_STATE) { set_error(std::string(who) + ": needs a state design"); return FBX_ERR_BAD_ARG; }
     return FBX_OK;
 }
@@ -691,7 +695,7 @@ int fbx_mle_state_dev(const fbx_design* design, int64_t B, const double* d_expec
     const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
     const size_t lds = state_lds(n, (int)m);
     if (lds > 64 * 1024) { set_error("fbx_mle_state: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
-    const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !getenv("FBX_MLE_UNPACKED");
+    const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !FBX_MLE_UNPACKED;
     if (packed && n == 1)
         hipLaunchKernelGGL(mle_state_packed_kernel<1>, dim3((unsigned)((B + 15) / 16)), dim3(64), 0, stream(), design->dev,
                            (long long)B, d_expect, epsilon, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);

@@ -754,35 +754,42 @@ sweep2q_pair_kernel(long long B, int K, const double* __restrict__ kraus, const 
 #undef FBX_WAVE_FENCE
 }
 
+// build-time selection of the 2-qubit sweep kernel (diagnostics): 0 = paired items (product),
+// 1 = one item per wavefront, 2 = the generic kernel
+#ifndef FBX_SWEEP_VARIANT
+#define FBX_SWEEP_VARIANT 0
+#endif
+#ifndef FBX_SWEEP_GRID
+#define FBX_SWEEP_GRID (256 * 16)
+#endif
+static_assert(FBX_SWEEP_GRID > 0, "FBX_SWEEP_GRID must be positive");
+
 template <int NQ>
 static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi,
                         double* ptm, double* chi, double* fid) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
     const size_t lds = sizeof(cplx) * (4 * D * LD + (size_t)K * D);
     if (lds > 160 * 1024) { set_error("fbx_kraus_sweep: too many Kraus operators"); return FBX_ERR_UNSUPPORTED; }
-    if (NQ == 2 && K <= 16 && !getenv("FBX_SWEEP_GENERIC") && !getenv("FBX_SWEEP_SINGLE")) {
-        // reference in Choi form for the on-the-fly fidelity (one 16 x 16 conversion per call)
-        static double* choi_ref = nullptr;
-        static int choi_ref_epoch = -1;
+    if (NQ == 2 && K <= 16 && FBX_SWEEP_VARIANT == 0) {
+        // reference in Choi form for the on-the-fly fidelity (one 16 x 16 conversion per call, into a
+        // workspace of the calling thread)
+        double* choi_ref = nullptr;
         if (ptm_ref) {
-            if (!choi_ref || choi_ref_epoch != device_epoch()) {
-                if (choi_ref) (void)hipFree(choi_ref);
-                choi_ref = nullptr;
-                FBX_HIP(hipMalloc((void**)&choi_ref, sizeof(cplx) * 256));
-                choi_ref_epoch = device_epoch();
-            }
+            void* w = nullptr;
+            { const int rc = workspace(WS_SWEEP_REF, sizeof(cplx) * 256, &w); if (rc) return rc; }
+            choi_ref = (double*)w;
             { const int rc = launch_convert<2>(FBX_REP_PAULI_LIOUVILLE, FBX_REP_CHOI, 1, ptm_ref, 0, choi_ref); if (rc) return rc; }
         }
         const size_t ldsp = sizeof(cplx) * (4 * 16 * 17 + 2 * (size_t)K * 16);
         const long long n_pairs = (B + 1) / 2;
-        const long long cap = getenv("FBX_SWEEP_GRID") ? atoll(getenv("FBX_SWEEP_GRID")) : 256 * 16;   // 8 resident per CU, the rest queued
+        const long long cap = FBX_SWEEP_GRID;                     // 8 wavefronts resident per CU, the rest queued
         const unsigned gridp = (unsigned)(n_pairs < cap ? n_pairs : cap);
         hipLaunchKernelGGL(sweep2q_pair_kernel, dim3(gridp), dim3(64), ldsp, stream(), (long long)B, K, kraus,
-                           ptm_ref ? choi_ref : (const double*)nullptr, choi, ptm, chi, fid);
+                           (const double*)choi_ref, choi, ptm, chi, fid);
         FBX_HIP(hipGetLastError());
         return FBX_OK;
     }
-    if (NQ == 2 && K <= 16 && !getenv("FBX_SWEEP_GENERIC")) {
+    if (NQ == 2 && K <= 16 && FBX_SWEEP_VARIANT == 1) {
         const size_t lds2 = sizeof(cplx) * (2 * 16 * 17 + (size_t)K * 16);
         const unsigned grid2 = (unsigned)(B < 256 * 16 ? B : 256 * 16);
         hipLaunchKernelGGL(sweep2q_kernel, dim3(grid2), dim3(64), lds2, stream(), (long long)B, K, kraus, ptm_ref, choi, ptm, chi, fid);
@@ -976,7 +983,7 @@ struct HostIO {     // host <-> device staging for the host-pointer entry points
 extern "C" {
 
 int fbx_linv_process_dev(const fbx_design* design, int64_t B, const double* d_expect, double* d_choi_out) {
-    FBX_REQUIRE(design != nullptr, "fbx_linv_process: NULL design");
+    FBX_TRY(check_design(design, "fbx_linv_process"));
     FBX_REQUIRE(design->dev.kind == FBX_KIND_PROCESS, "fbx_linv_process: needs a process design");
     FBX_REQUIRE(B >= 0 && (B == 0 || (d_expect && d_choi_out)), "fbx_linv_process: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
@@ -990,7 +997,7 @@ int fbx_linv_process_dev(const fbx_design* design, int64_t B, const double* d_ex
 }
 
 int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect, double* choi_out) {
-    FBX_REQUIRE(design != nullptr, "fbx_linv_process: NULL design");
+    FBX_TRY(check_design(design, "fbx_linv_process"));
     FBX_REQUIRE(design->dev.kind == FBX_KIND_PROCESS, "fbx_linv_process: needs a process design");
     FBX_REQUIRE(B >= 0 && (B == 0 || (expect && choi_out)), "fbx_linv_process: bad batch / NULL buffer");
     FBX_TRY(ensure_device());

@@ -7,11 +7,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("FBX_LIBRARY", os.path.join(os.path.dirname(_HERE), "libfbx.so"))
 
-FBX_OK, FBX_ERR_BAD_ARG, FBX_ERR_HIP, FBX_ERR_NO_DEVICE, FBX_ERR_UNSUPPORTED, FBX_ERR_NOMEM = range(6)
+FBX_OK, FBX_ERR_BAD_ARG, FBX_ERR_HIP, FBX_ERR_NO_DEVICE, FBX_ERR_UNSUPPORTED, FBX_ERR_NOMEM, FBX_ERR_RCCL = range(7)
+COMM_ID_BYTES = 128
+COMM_SUM, COMM_MAX, COMM_MIN = range(3)
 KIND_STATE, KIND_PROCESS = 0, 1
 MODE_CONVERGE, MODE_FIXED = 0, 1
 REP_KRAUS, REP_CHOI, REP_SUPEROP, REP_PAULI_LIOUVILLE, REP_CHI = range(5)
 PROJ_CP, PROJ_TP, PROJ_TNI, PROJ_PHYSICAL_TP, PROJ_PHYSICAL_TNI = range(5)
+RAND_GINIBRE, RAND_UNITARY, RAND_STATE_VECTOR, RAND_GINIBRE_STATE, RAND_BURES_STATE = range(5)
 
 
 class FbxError(RuntimeError):
@@ -42,6 +45,16 @@ PROTOTYPES = {
     "fbx_set_device": [C.c_int],
     "fbx_device_name": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     "fbx_synchronize": [],
+    "fbx_release_workspace": [],
+    "fbx_comm_unique_id": [_u8p],
+    "fbx_comm_init": [_u8p, C.c_int, C.c_int],
+    "fbx_comm_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "fbx_comm_destroy": [],
+    "fbx_comm_allgather_dev": [_vp, _vp, C.c_size_t],
+    "fbx_comm_broadcast_dev": [_vp, C.c_size_t, C.c_int],
+    "fbx_comm_allreduce_f64_dev": [_vp, _vp, C.c_size_t, C.c_int],
+    "fbx_comm_allreduce_f64": [_dp, C.c_size_t, C.c_int],
+    "fbx_comm_barrier": [],
     "fbx_malloc": [C.POINTER(_vp), C.c_size_t],
     "fbx_free": [_vp],
     "fbx_memcpy_h2d": [_vp, _vp, C.c_size_t],
@@ -52,8 +65,8 @@ PROTOTYPES = {
     "fbx_design_destroy": [_vp],
     "fbx_design_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                         C.POINTER(C.c_int)],
-    "fbx_pgdb_process": [_vp, _i64, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _ip, _ip, _ip, _dp],
-    "fbx_pgdb_process_dev": [_vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
+    "fbx_pgdb_process": [_vp, _i64, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _ip, _ip, _ip, _dp, _ip],
+    "fbx_pgdb_process_dev": [_vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "fbx_linv_process": [_vp, _i64, _dp, _dp],
     "fbx_linv_state": [_vp, _i64, _dp, _dp],
     "fbx_mle_state": [_vp, _i64, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -84,6 +97,10 @@ PROTOTYPES = {
     "fbx_apply_choi_dev": [C.c_int, _i64, _vp, _vp, _vp],
     "fbx_state_measures_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "fbx_eigh_dev": [C.c_int, _i64, _vp, _vp, _vp],
+    "fbx_random_operators": [C.c_int, C.c_int, C.c_int, _i64, C.c_uint64, _i64, _dp],
+    "fbx_random_operators_dev": [C.c_int, C.c_int, C.c_int, _i64, C.c_uint64, _i64, _vp],
+    "fbx_random_kraus": [C.c_int, _i64, C.c_int, C.c_uint64, _i64, _dp],
+    "fbx_random_kraus_dev": [C.c_int, _i64, C.c_int, C.c_uint64, _i64, _vp],
     "fbx_beta_resample": [_i64, _i64, _dp, _dp, C.c_double, C.c_uint64, _dp],
     "fbx_beta_resample_dev": [_i64, _i64, _vp, _vp, C.c_double, C.c_uint64, _vp, _vp],
 }
@@ -123,7 +140,16 @@ def device_count() -> int:
 
 
 def set_device(idx: int):
+    """Select the GPU of this process (one process per GPU).  Designs created on another device go
+    stale (the library refuses them), so the shim's design cache is dropped."""
     check(lib().fbx_set_device(int(idx)))
+    from . import design as _design
+    _design._design_cache.clear()
+
+
+def release_workspace():
+    """Give the calling thread's cached device workspaces / staging pool back (fbx_release_workspace)."""
+    check(lib().fbx_release_workspace())
 
 
 def device_name():

@@ -37,6 +37,11 @@ class Design:
     def dim(self):
         return 2 ** self.n_qubits
 
+    @property
+    def n_states(self):
+        """Distinct product input states of the design (S of the device tables)."""
+        return len({r.tobytes() for r in self.in_labels})
+
     def key(self):
         return (self.n_qubits, self.kind, self.in_labels.tobytes(), self.paulis.tobytes(),
                 self.coefs.tobytes())

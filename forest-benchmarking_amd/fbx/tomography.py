@@ -314,13 +314,16 @@ def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trac
     dyk = np.zeros(B, dtype=np.int32)
     bt = np.zeros(B, dtype=np.int32)
     cost = np.zeros(B)
+    work = np.zeros((B, 4), dtype=np.int32)
     _lib.check(_lib.lib().fbx_pgdb_process(
         design.handle, B, _lib.dptr(e), _lib.dptr(c), int(bool(trace_preserving)),
         _lib.MODE_FIXED if mode == "fixed" else _lib.MODE_CONVERGE, int(max_iters),
         _lib.dptr(choi.view(np.float64)), _lib.iptr(iters), _lib.iptr(dyk), _lib.iptr(bt),
-        _lib.dptr(cost)))
+        _lib.dptr(cost), _lib.iptr(work)))
     if return_stats:
-        return choi, {"iterations": iters, "dykstra": dyk, "backtracks": bt, "cost": cost}
+        return choi, {"iterations": iters, "dykstra": dyk, "backtracks": bt, "cost": cost,
+                      "jacobi_sweeps": work[:, 0], "eig_terms": work[:, 1], "cost_evals": work[:, 2],
+                      "power_sum_passes": work[:, 3]}
     return choi
 
 
@@ -362,7 +365,7 @@ def process_fidelity_variance_batch(design: Design, expectations, total_counts, 
     d_choi, d_ptm = DB(R * B * D * D * 16), DB(R * B * D * D * 16)
     _lib.check(lib.fbx_pgdb_process_dev(design.handle, R * B, d_er.ptr, d_cr.ptr, int(bool(trace_preserving)),
                                         _lib.MODE_FIXED if mode == "fixed" else _lib.MODE_CONVERGE, int(max_iters),
-                                        d_choi.ptr, None, None, None, None))
+                                        d_choi.ptr, None, None, None, None, None))
     _lib.check(lib.fbx_convert_dev(_lib.REP_CHOI, _lib.REP_PAULI_LIOUVILLE, n, R * B, d_choi.ptr, 0, d_ptm.ptr))
     d_tgt = DB.from_array(np.ascontiguousarray(np.broadcast_to(tgt, (R, B, D, D))))
     d_f = DB(R * B * 8)

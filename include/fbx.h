@@ -10,6 +10,13 @@
  * Conventions
  *  - every entry point returns int: FBX_OK or an FBX_ERR_* category; the message is
  *    available per thread through fbx_last_error().  No exceptions / abort() cross the ABI.
+ *  - threading: the library is re-entrant.  Every host thread that calls in owns its own HIP
+ *    stream, timer events, staging-buffer pool and cached device workspaces (the 2-qubit PGDB
+ *    kernel keeps up to 1 GiB of Dykstra bases per calling thread, the 3-qubit one 768 MiB);
+ *    fbx_release_workspace() gives the calling thread's cached device memory back.  The only
+ *    process-wide state is the selected device (one process per GPU: fbx_set_device once,
+ *    before other threads use the library) and the RCCL communicator (fbx_comm_*, one thread
+ *    at a time).  "The library stream" below is the calling thread's stream.
  *  - all buffers are caller-owned, C-contiguous; complex128 is interleaved (re, im) doubles
  *    (binary compatible with `double _Complex` and numpy complex128); matrices are
  *    row-major [B][row][col].  Plain entry points take HOST pointers and do H2D/D2H
@@ -38,6 +45,7 @@ extern "C" {
 #define FBX_ERR_NO_DEVICE    3   /* no gfx950 device visible: the product fails loudly */
 #define FBX_ERR_UNSUPPORTED  4   /* valid request outside what this build implements */
 #define FBX_ERR_NOMEM        5
+#define FBX_ERR_RCCL         6   /* RCCL (multi-GPU) failure, or librccl.so could not be opened */
 
 #define FBX_KIND_STATE    0
 #define FBX_KIND_PROCESS  1
@@ -69,7 +77,33 @@ const char* fbx_last_error(void);
 int         fbx_device_count(int* count);
 int         fbx_set_device(int device_id);          /* one process per GPU: call once */
 int         fbx_device_name(char* buf, size_t len, int* compute_units);
-int         fbx_synchronize(void);
+int         fbx_synchronize(void);                  /* the calling thread's stream */
+int         fbx_release_workspace(void);            /* free the calling thread's cached device workspaces / staging pool */
+
+/* ---------------------------------------------------------------- multi-GPU
+ * One process per GPU; RCCL over xGMI.  The reconstruction path shards on the batch axis (the
+ * independent units of observable_estimation.py:1145-1173 get_results_by_qubit_groups,
+ * tomography.py:440-451 bootstrap resamples) with NO collective on the data path; these entry
+ * points cover what ranks exchange around it: broadcast of design-sized constants, all-gather
+ * of result slabs, all-reduce of a summary vector.  Rank 0 obtains an id with
+ * fbx_comm_unique_id, hands the FBX_COMM_ID_BYTES bytes to the other ranks by any host channel,
+ * every rank calls fbx_comm_init (collective).  Collectives are enqueued on the calling thread's
+ * stream (the *_dev forms are asynchronous like every other *_dev entry point).  librccl.so is
+ * opened on first use. */
+#define FBX_COMM_ID_BYTES 128
+#define FBX_COMM_SUM 0
+#define FBX_COMM_MAX 1
+#define FBX_COMM_MIN 2
+int fbx_comm_unique_id(uint8_t* id_out /* [FBX_COMM_ID_BYTES] */);
+int fbx_comm_init(const uint8_t* id, int rank, int world);
+int fbx_comm_info(int* rank, int* world, int* rccl_version);   /* world = 0 without a communicator */
+int fbx_comm_destroy(void);
+int fbx_comm_allgather_dev(const void* d_send, void* d_recv /* [world][bytes_per_rank] */,
+                           size_t bytes_per_rank);
+int fbx_comm_broadcast_dev(void* d_buf, size_t bytes, int root);
+int fbx_comm_allreduce_f64_dev(const double* d_send, double* d_recv, size_t n, int op);
+int fbx_comm_allreduce_f64(double* host_inout, size_t n, int op);   /* summary vectors, n <= 4096; synchronises */
+int fbx_comm_barrier(void);   /* all ranks' work enqueued by the calling threads is complete */
 
 /* device memory helpers so callers can keep batches resident in HBM */
 int fbx_malloc(void** dev_ptr, size_t bytes);
@@ -102,16 +136,19 @@ int fbx_design_info(const fbx_design* design, int* n_qubits, int* kind, int* m,
  *   choi_out[B][D][D] complex128, D = 4^n
  *   iters_out / dykstra_out / backtracks_out [B] (may be NULL): outer iterations, total
  *   Dykstra (= eigendecomposition) iterations, total step halvings; cost_out[B] (may be
- *   NULL): final negative log-likelihood. */
+ *   NULL): final negative log-likelihood; work_out[B][4] (may be NULL): work accounting --
+ *   Jacobi sweeps of the eigensolver, eigenvalue terms rebuilt by the CP projections, cost
+ *   evaluations over all outcomes, power-sum reductions of the small-step line search
+ *   (bench.py derives the executed flops from these counters). */
 int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
                      const double* counts, int trace_preserving, int mode, int max_iters,
                      double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
-                     int32_t* backtracks_out, double* cost_out);
+                     int32_t* backtracks_out, double* cost_out, int32_t* work_out);
 int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
                          const double* d_counts, int trace_preserving, int mode,
                          int max_iters, double* d_choi_out, int32_t* d_iters_out,
                          int32_t* d_dykstra_out, int32_t* d_backtracks_out,
-                         double* d_cost_out);
+                         double* d_cost_out, int32_t* d_work_out);
 
 /* linear_inv_process_estimate (tomography.py:459-491): choi_out[B][D][D]. */
 int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect,
@@ -240,6 +277,34 @@ int fbx_beta_resample(int64_t n, int64_t R, const double* expect, const double* 
                       double prior_counts, uint64_t seed, double* out);
 int fbx_beta_resample_dev(int64_t n, int64_t R, const double* d_expect, const double* d_counts,
                           double prior_counts, uint64_t seed, double* d_out, double* d_counts_out);
+
+/* ---------------------------------------------------------------- random operators
+ * operator_tools/random_operators.py:21-157 for batches, generated on the device.  Item b (global id
+ * first_item + b) owns a counter-based Philox4x32-10 stream keyed by `seed`, so an item's matrices
+ * depend on (seed, item id) only -- not on B, the launch shape or the split over GPUs.  The
+ * reference draws from numpy's global Mersenne-Twister stream: parity is distributional (the
+ * host generators of the Python shim keep the reference's draw order for seeded reproduction).
+ *   FBX_RAND_GINIBRE        out[B][dim][cols]  ginibre_matrix_complex(dim, cols)           :21-46
+ *   FBX_RAND_UNITARY        out[B][dim][dim]   haar_rand_unitary(dim)                      :49-72
+ *   FBX_RAND_STATE_VECTOR   out[B][dim]        haar_rand_state(dim)                        :75-89
+ *   FBX_RAND_GINIBRE_STATE  out[B][dim][dim]   ginibre_state_matrix(dim, rank)             :92-112
+ *   FBX_RAND_BURES_STATE    out[B][dim][dim]   bures_measure_state_matrix(dim)             :115-132
+ * dim in {2, 4, 8} except for FBX_RAND_GINIBRE (any shape); complex128 outputs.
+ * fbx_random_kraus: CPTP Kraus sets out[B][K][d][d], K_j = G_j S^{-1/2}, S = sum_j G_j^H G_j with
+ * Ginibre G_j -- kraus2choi of a set is a rand_map_with_BCSZ_dist(d, K) draw (:135-157). */
+#define FBX_RAND_GINIBRE        0
+#define FBX_RAND_UNITARY        1
+#define FBX_RAND_STATE_VECTOR   2
+#define FBX_RAND_GINIBRE_STATE  3
+#define FBX_RAND_BURES_STATE    4
+int fbx_random_operators(int kind, int dim, int cols_or_rank, int64_t B, uint64_t seed,
+                         int64_t first_item, double* out);
+int fbx_random_operators_dev(int kind, int dim, int cols_or_rank, int64_t B, uint64_t seed,
+                             int64_t first_item, double* d_out);
+int fbx_random_kraus(int n_qubits, int64_t B, int K, uint64_t seed, int64_t first_item,
+                     double* kraus_out);
+int fbx_random_kraus_dev(int n_qubits, int64_t B, int K, uint64_t seed, int64_t first_item,
+                         double* d_kraus_out);
 
 /* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
  * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16, 32, 64}.  This is the

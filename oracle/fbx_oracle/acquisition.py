@@ -134,3 +134,57 @@ def beta_resample(expectations, total_counts, n_resamples, prior_counts=1.0, see
     gb = _gamma(b[good], idx[good], draw, seed)
     out[good] = 2.0 * (ga / (ga + gb)) - 1.0
     return out.reshape((n_resamples,) + e.shape)
+
+
+# --------------------------------------------------------------------------------------------------
+# Device random operators (csrc/fbx_random.hip): the same Philox stream -- counter = (item id low, high,
+# element index, stream tag), key = seed -- and the reference's arithmetic after the normals
+# (operator_tools/random_operators.py:21-157).
+# --------------------------------------------------------------------------------------------------
+def ginibre_entries(seed, item, n_elems, tag=0):
+    """n_elems complex standard normals of item `item` (Box-Muller on the first two words of each block)."""
+    elem = np.arange(n_elems, dtype=np.int64)
+    ctr = np.stack([np.full_like(elem, item & 0xFFFFFFFF), np.full_like(elem, item >> 32), elem,
+                    np.full_like(elem, tag)], axis=-1).astype(np.uint32)
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32), (n_elems, 2))
+    x = philox4x32_10(ctr, key).astype(np.float64)
+    u1, u2 = (x[:, 0] + 0.5) * 2.0 ** -32, (x[:, 1] + 0.5) * 2.0 ** -32
+    mag = np.sqrt(-2.0 * np.log(u1))
+    ang = 6.283185307179586476925 * u2
+    return mag * np.cos(ang) + 1j * mag * np.sin(ang)
+
+
+def ginibre_matrix(seed, item, dim, k, tag=0):
+    return ginibre_entries(seed, item, dim * k, tag).reshape(dim, k)
+
+
+def haar_unitary(seed, item, dim, tag=0):
+    """random_operators.py:49-72 on the device's Ginibre matrix."""
+    z = ginibre_matrix(seed, item, dim, dim, tag)
+    q, r = np.linalg.qr(z)
+    dr = np.diagonal(r)
+    return q @ (np.diag(dr) / np.absolute(dr))
+
+
+def ginibre_state(seed, item, dim, rank):
+    a = ginibre_matrix(seed, item, dim, rank)
+    m = a @ a.conj().T
+    return m / np.trace(m)
+
+
+def bures_state(seed, item, dim):
+    a = ginibre_matrix(seed, item, dim, dim, 0)
+    u = haar_unitary(seed, item, dim, 1)
+    w = np.eye(dim) + u
+    p = w @ (a @ a.conj().T) @ w.conj().T
+    return p / np.trace(p)
+
+
+def random_kraus(seed, item, dim, k):
+    """K_j = G_j S^{-1/2}; kraus2choi of it is the reference's rand_map_with_BCSZ_dist construction
+    (random_operators.py:149-157) for X with columns vec(G_j)."""
+    g = ginibre_entries(seed, item, k * dim * dim).reshape(k, dim, dim)
+    s = sum(x.conj().T @ x for x in g)
+    w, v = np.linalg.eigh(s)
+    s_inv_half = (v / np.sqrt(w)) @ v.conj().T
+    return np.array([x @ s_inv_half for x in g])

@@ -17,7 +17,7 @@ for B in (1024, 8192):
         best = 1e9
         for rep in range(3):
             _lib.check(lib.fbx_timer_begin())
-            _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, mode, mi, d_choi.ptr, d_it.ptr, None, None, None))
+            _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, mode, mi, d_choi.ptr, d_it.ptr, None, None, None, None))
             _lib.check(lib.fbx_timer_end(ctypes.byref(ms)))
             best = min(best, ms.value)
         it = d_it.to_array(np.int32, (B,))

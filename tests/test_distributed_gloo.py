@@ -1,12 +1,14 @@
-"""world_size-2 gloo run of the sharded batch path on CPU: contiguous partition, no data-path
-collective, one all-gather of result slabs.  The per-shard compute is the CPU oracle (the HIP
-library needs a GPU); what is under test is the N > 1 plumbing bench.py and fbx.parallel use."""
+"""world_size-2 runs of the sharded batch path on CPU: contiguous partition, no data-path collective,
+one all-gather of result slabs, the summary all-reduce.  On a GPU node the communicator is libfbx's
+RCCL one (fbx.parallel.RcclComm); here the SAME partition / gather / summary code (fbx.parallel.
+run_sharded, reduce_summary) runs over (a) a gloo-backed stand-in with the communicator interface
+and (b) the file rendezvous that hands the RCCL id around (and is bench.py's barrier of last resort).
+The per-shard compute is the CPU oracle (the HIP library needs a GPU)."""
 import os
 import socket
 import sys
 
 import numpy as np
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -16,14 +18,32 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
-    for p in (os.path.join(ROOT, "forest-benchmarking_amd"), os.path.join(ROOT, "oracle")):
-        sys.path.insert(0, p)
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+class GlooComm:
+    """torch.distributed(gloo) behind the communicator interface of fbx.parallel (test stand-in for RcclComm)."""
+    backend = "gloo"
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr)
+        t = self.torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
+        outs = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return np.stack([o.numpy().view(a.dtype).reshape(a.shape) for o in outs])
+
+    def allreduce(self, vec, op="sum"):
+        t = self.torch.from_numpy(np.array(vec, dtype=np.float64, copy=True))
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX,
+                                    "min": self.dist.ReduceOp.MIN}[op])
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def _check_sharded(comm, out_dir):
     from fbx import synthetic
     from fbx.parallel import reduce_summary, run_sharded, shard_bounds
     from fbx_oracle import design as od, estimators as oe
@@ -33,31 +53,84 @@ def _worker(rank, world, port, out_dir):
     def estimate(eb, cb):
         return np.array([oe.linear_inv_process_estimate(o, eb[i]) for i in range(eb.shape[0])]).reshape(-1, 4, 4)
 
-    full, (lo, hi) = run_sharded(estimate, [e, c], rank, world, dist=dist)
-    assert (lo, hi) == shard_bounds(7, rank, world)
+    full, (lo, hi) = run_sharded(estimate, [e, c], comm)
+    assert (lo, hi) == shard_bounds(7, comm.rank, comm.world)
     # max-over-ranks timing reduction as in bench.py
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    assert t.item() == world
+    assert comm.allreduce([float(comm.rank + 1)], "max")[0] == comm.world
     # whole-job summary: sum of the local item counts and traces, max of the local block length
     local = full[lo:hi]
-    sums, maxima = reduce_summary([hi - lo, float(np.trace(local, axis1=1, axis2=2).real.sum())], [hi - lo], dist)
+    sums, maxima = reduce_summary([hi - lo, float(np.trace(local, axis1=1, axis2=2).real.sum())], [hi - lo], comm)
     assert sums[0] == 7 and abs(sums[1] - np.trace(full, axis1=1, axis2=2).real.sum()) < 1e-12 and maxima[0] == 4
-    np.save(os.path.join(out_dir, f"full_{rank}.npy"), full)
-    dist.barrier()
+    # without the gather every rank keeps its block only
+    part, _ = run_sharded(estimate, [e, c], comm, gather=False)
+    assert part.shape[0] == hi - lo and np.array_equal(part, local)
+    np.save(os.path.join(out_dir, f"full_{comm.backend}_{comm.rank}.npy"), full)
+    comm.barrier()
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "forest-benchmarking_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _check_sharded(GlooComm(dist, torch), out_dir)
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding(tmp_path):
-    import torch.multiprocessing as mp
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a = np.load(tmp_path / "full_0.npy"); b = np.load(tmp_path / "full_1.npy")
-    assert a.shape == (7, 4, 4) and np.array_equal(a, b)
+def _files_worker(rank, world, rdzv_dir, out_dir):
+    for p in (os.path.join(ROOT, "forest-benchmarking_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    from fbx.parallel import FileRendezvous, HostComm
+    r = FileRendezvous(rank, world, directory=rdzv_dir, timeout=60)
+    # the hand-off RcclComm needs: rank 0's 128-byte id reaches everybody
+    ident = bytes(range(128)) if rank == 0 else b""
+    assert r.allgather(ident, tag="rccl_id")[0] == bytes(range(128))
+    comm = HostComm(r)
+    comm.barrier = r.barrier                    # (HostComm.barrier also synchronises the GPU stream)
+    _check_sharded(comm, out_dir)
+    r.close()
+
+
+def _expected():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from fbx import synthetic
     from fbx_oracle import design as od, estimators as oe
     _, _, e, _ = synthetic.process_batch(1, "sic", 7)
     o = od.process_design(1, "sic")
-    want = np.array([oe.linear_inv_process_estimate(o, e[i]) for i in range(7)])
-    assert np.allclose(a, want, atol=1e-14)
+    return np.array([oe.linear_inv_process_estimate(o, e[i]) for i in range(7)])
+
+
+def test_two_rank_sharding_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_gloo_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "full_gloo_0.npy"); b = np.load(tmp_path / "full_gloo_1.npy")
+    assert a.shape == (7, 4, 4) and np.array_equal(a, b)
+    assert np.allclose(a, _expected(), atol=1e-14)
+
+
+def test_two_rank_sharding_file_rendezvous(tmp_path):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    rd = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_files_worker, args=(r, 2, rd, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    a = np.load(tmp_path / "full_host-files_0.npy"); b = np.load(tmp_path / "full_host-files_1.npy")
+    assert np.array_equal(a, b) and np.allclose(a, _expected(), atol=1e-14)
+    assert not os.path.exists(rd)               # every rank removed what it published
+
+
+def test_shard_bounds_cover_the_batch_exactly():
+    from fbx.parallel import shard_bounds
+    for n in (0, 1, 7, 1024, 65536, 65537):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [shard_bounds(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(b[1] == nb[0] for b, nb in zip(blocks, blocks[1:]))
+            assert max(hi - lo for lo, hi in blocks) == -(-n // world)

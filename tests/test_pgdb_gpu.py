@@ -191,21 +191,6 @@ def test_bad_arguments_and_empty_batch(gpu):
         tomography.pgdb_process_estimate_batch(state_design(1), np.zeros((1, 3)), np.ones((1, 3)))
 
 
-def test_device_log_is_accurate_to_an_ulp(gpu):
-    """The line search uses its own natural log (argument reduction + minimax polynomial)."""
-    import ctypes
-    lib = gpu.lib()
-    rs = np.random.RandomState(0)
-    x = np.concatenate([10.0 ** rs.uniform(-6, 0.31, 200000), [1e-6, 1.0, 0.5, 0.70710678118654752, 2.0, 1.5]])
-    out = np.empty_like(x)
-    lib.fbx_debug_log.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
-    gpu.check(lib.fbx_debug_log(x.ctypes.data, out.ctypes.data, x.size))
-    want = np.log(x)
-    ulp = np.spacing(np.abs(want)) + 1e-300
-    assert np.max(np.abs(out - want) / np.maximum(ulp, 2.3e-16 * np.abs(x - 1))) <= 1.5
-    assert out[-5] == 0.0
-
-
 def test_config5_shard_size_properties(gpu):
     """BASELINE config 5 per-GPU share (8192 two-qubit tomographies): Hermitian and trace preserving
     to rounding, 100 iterations everywhere, the eight tiles of 1024 distinct items bit-identical."""

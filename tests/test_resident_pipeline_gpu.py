@@ -36,7 +36,7 @@ def test_shots_to_fidelity_without_leaving_hbm(gpu):
     d_choi, d_proj, d_ptm = (_lib.DeviceBuffer(B * D * D * 16) for _ in range(3))
     d_it = _lib.DeviceBuffer(B * 4)
     _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_mean.ptr, d_counts.ptr, 1, _lib.MODE_CONVERGE, 0,
-                                        d_choi.ptr, d_it.ptr, None, None, None))
+                                        d_choi.ptr, d_it.ptr, None, None, None, None))
     _lib.check(lib.fbx_proj_choi_dev(_lib.PROJ_PHYSICAL_TP, n, B, d_choi.ptr, d_proj.ptr, None))
     _lib.check(lib.fbx_convert_dev(_lib.REP_CHOI, _lib.REP_PAULI_LIOUVILLE, n, B, d_proj.ptr, 0, d_ptm.ptr))
     ideal = convert_batch("kraus", "pauli_liouville", us[:, None])           # [B, D, D]
