@@ -83,7 +83,27 @@ def build_guard_test(verbose=True):
     return out
 
 
+def build_variant(name, extra_flags, verbose=True):
+    """Experiment builds: libfbx_<name>.so = the product objects with fbx_pgdb.hip recompiled with extra
+    -D flags (e.g. `python build.py --variant nosmall -DFBX_NO_SMALL_STEP`).  Not shipped, not loaded by tests."""
+    out = os.path.join(HERE, f"libfbx_{name}.so")
+    build(verbose=verbose)
+    src = os.path.join(CSRC, "fbx_pgdb.hip")
+    obj = os.path.join(HERE, "build", f"fbx_pgdb.hip.{name}.o")
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs = [obj] + [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if s != src]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + MAP, "-ldl"] + objs + ["-o", out])
+    return out
+
+
 if __name__ == "__main__":
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        sys.exit(0)
     if "--guard-test" in sys.argv:
         build_guard_test()
     else:

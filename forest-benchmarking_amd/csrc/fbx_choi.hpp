@@ -22,8 +22,8 @@ template <int NQ>
 struct ChoiLds {
     static constexpr int d = 1 << NQ, D = d * d, LD = D + 1, LDs = d + 1;
     cplx* Mw;      // [D * LD]   row-major staging matrix (partial trace, Pauli transforms)
-    cplx* Ms;      // [D * D]    Jacobi work matrix, element-major block layout
-    cplx* Vs;      // [D * D]    eigenvectors, same layout
+    cplx* Ms;      // [sys_elems<D>()]  Jacobi work matrix, element-major block layout (fbx_eigh.hpp)
+    cplx* Vs;      // [sys_elems<D>()]  eigenvectors, same layout
     double* lam;   // [D]
     JRec* rec;     // [D / 2 + 1] rotation records (scratch)
     cplx* pt;      // [d * LDs]  partial trace (d x d), row-major
@@ -32,12 +32,12 @@ struct ChoiLds {
     PhaseClock* pc = nullptr;   // diagnostics (FBX_PHASE_TIMERS builds)
     int terms = 0;              // work accounting: eigenvalue terms rebuilt by the CP projections (wave-uniform)
     static constexpr size_t bytes() {
-        return sizeof(cplx) * (D * LD + 2 * D * D + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
+        return sizeof(cplx) * (D * LD + 2 * sys_elems<D>() + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
     }
     __device__ void carve(char*& p) {
         Mw = (cplx*)p; p += sizeof(cplx) * D * LD;
-        Ms = (cplx*)p; p += sizeof(cplx) * D * D;
-        Vs = (cplx*)p; p += sizeof(cplx) * D * D;
+        Ms = (cplx*)p; p += sizeof(cplx) * sys_elems<D>();
+        Vs = (cplx*)p; p += sizeof(cplx) * sys_elems<D>();
         pt = (cplx*)p; p += sizeof(cplx) * d * LDs;
         pts = (cplx*)p; p += sizeof(cplx) * d * d;
         ptV = (cplx*)p; p += sizeof(cplx) * d * d;
@@ -88,11 +88,11 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
 #endif
     {
         if (warm && check_basis) {
-            constexpr int LS = (D / 2) * (D / 2);
+            constexpr int LS = (D / 2) * (D / 2), PS = sys_plane<D>();
             double mn2 = 0.0;
             if (lane < LS) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * LS + lane]; mn2 = fma(v.re, v.re, fma(v.im, v.im, mn2)); }
+                for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * PS + lane]; mn2 = fma(v.re, v.re, fma(v.im, v.im, mn2)); }
             }
             mn2 = uniform(wave_sum(mn2));
             sw = (fabs(mn2 - hn2) <= FBX_BASIS_NORM_TOL * hn2) ? jacobi_eigh_lds<D>(L.Ms, L.Vs, L.rec, lane, false) : -1;
@@ -255,14 +255,14 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int idx = lane + 64 * u;
-                if (idx < DD) L.Vs[idx] = store->pf[u];
+                if (idx < DD) L.Vs[sys_linear<ChoiLds<NQ>::D>(idx)] = store->pf[u];
             }
             store->pf_slot = -1;
 #ifdef FBX_DBG_WAITPHASE
             PH_STOP(*L.pc, 7);
 #endif
 #ifdef FBX_DBG_CORRUPT_BASIS                   // test hook: damage every basis loaded for Dykstra iteration 1
-            if (it == 1 && lane < 3) L.Vs[17 * lane].re += 0.25;
+            if (it == 1 && lane < 3) L.Vs[sys_linear<ChoiLds<NQ>::D>(17 * lane)].re += 0.25;
 #endif
             warm = true;
         }
@@ -280,7 +280,7 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int idx = lane + 64 * u;
-                    if (idx < DD) { const cplx w = L.Vs[idx]; dst[idx] = fbx_v2d{w.re, w.im}; }
+                    if (idx < DD) { const cplx w = L.Vs[sys_linear<ChoiLds<NQ>::D>(idx)]; dst[idx] = fbx_v2d{w.re, w.im}; }
                 }
             }
         }

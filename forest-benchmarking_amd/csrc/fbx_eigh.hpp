@@ -118,41 +118,60 @@ __device__ __forceinline__ int jacobi_seat(int s) {       // pi: slot -> next sl
     return 2 * (k - 1) + 1;                                // b_k -> b_{k-1}
 }
 
+// Plane stride of the element-major layout: plane e = 2a + b (position inside the 2 x 2 block) starts at
+// e * sys_plane<N>() and holds one entry per block, block (I, J) at I * NB + J.  For N = 16 the planes
+// are 66 entries apart instead of 64: the tournament permutation sends two of the eight blocks a
+// ds_write_b128 lane group (8 consecutive lanes = one block row) owns to the same pair, into the two
+// different b-planes; with a stride that is 2 (mod 8) sixteen-byte slots those two land on different
+// banks, so the permuted writes of a Jacobi round are conflict-free (they were 2-way in every lane group:
+// 36 % of the kernel's LDS cycles were bank-conflict cycles, profiles/r02).
+template <int N>
+__host__ __device__ constexpr int sys_plane() { return N == 16 ? 66 : (N / 2) * (N / 2); }
+// number of cplx entries a matrix in this layout occupies
+template <int N>
+__host__ __device__ constexpr int sys_elems() { return 4 * sys_plane<N>(); }
+
 // element (r, c) of an N x N matrix in the element-major block layout
 template <int N>
 __device__ __forceinline__ int sys_index(int r, int c) {
-    constexpr int NB = N / 2, LS = NB * NB;
-    return ((r & 1) * 2 + (c & 1)) * LS + (r >> 1) * NB + (c >> 1);
+    constexpr int NB = N / 2, PS = sys_plane<N>();
+    return ((r & 1) * 2 + (c & 1)) * PS + (r >> 1) * NB + (c >> 1);
+}
+// linear entry index (0 .. N*N-1, plane-major as stored without padding) -> offset in the layout
+template <int N>
+__device__ __forceinline__ int sys_linear(int idx) {
+    constexpr int LS = (N / 2) * (N / 2), PS = sys_plane<N>();
+    return (idx / LS) * PS + (idx % LS);
 }
 
 template <int N>
 __device__ __forceinline__ void sys_store(cplx* Ms, int lane, const Blk& v) {
-    constexpr int NB = N / 2, LS = NB * NB;
+    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     if (lane < LS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { cplx c; c.re = v.re[e]; c.im = v.im[e]; Ms[e * LS + lane] = c; }
+        for (int e = 0; e < 4; ++e) { cplx c; c.re = v.re[e]; c.im = v.im[e]; Ms[e * PS + lane] = c; }
     }
 }
 template <int N>
 __device__ __forceinline__ Blk sys_load(const cplx* Ms, int lane) {
-    constexpr int NB = N / 2, LS = NB * NB;
+    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     Blk v = blk_zero();
     if (lane < LS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const cplx c = Ms[e * LS + lane]; v.re[e] = c.re; v.im[e] = c.im; }
+        for (int e = 0; e < 4; ++e) { const cplx c = Ms[e * PS + lane]; v.re[e] = c.re; v.im[e] = c.im; }
     }
     return v;
 }
 // conjugate-transpose block: element (a, b) of block (I, J) <- conj of element (b, a) of block (J, I)
 template <int N>
 __device__ __forceinline__ Blk sys_load_adjoint(const cplx* Ms, int lane) {
-    constexpr int NB = N / 2, LS = NB * NB;
+    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     Blk v = blk_zero();
     if (lane < LS) {
         const int I = lane / NB, J = lane % NB;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const cplx c = Ms[((e & 1) * 2 + (e >> 1)) * LS + J * NB + I];
+            const cplx c = Ms[((e & 1) * 2 + (e >> 1)) * PS + J * NB + I];
             v.re[e] = c.re; v.im[e] = -c.im;
         }
     }
@@ -252,7 +271,7 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 template <int N>
 __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
                                 double expect_n2 = -1.0) {
-    constexpr int NB = N / 2, LS = NB * NB;
+    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(LS == 64, "every lane of the wavefront owns one 2x2 block");
     const int I = lane / NB, J = lane % NB;
     const int me = lane;
@@ -260,8 +279,8 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
-        wm[e] = ((sa & 1) * 2 + (sb & 1)) * LS + (sa >> 1) * NB + (sb >> 1);
-        wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
+        wm[e] = ((sa & 1) * 2 + (sb & 1)) * PS + (sa >> 1) * NB + (sb >> 1);
+        wv[e] = ((e >> 1) * 2 + (sb & 1)) * PS + I * NB + (sb >> 1);
     }
     const int dJ = J * NB + J;
     const int src_lane = (lane & 63) - J + I;
@@ -286,7 +305,7 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
             double o2 = 0.0, a_all = 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const cplx v = Ms[e * LS + me];
+                const cplx v = Ms[e * PS + me];
                 const double a2 = v.re * v.re + v.im * v.im;
                 a_all += a2;
                 if (!(I == J && (e == 0 || e == 3))) o2 += a2;
@@ -299,15 +318,15 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
             if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
-            const double aJ = Ms[0 * LS + dJ].re, dJ_ = Ms[3 * LS + dJ].re;
-            const cplx bJ = Ms[1 * LS + dJ];
-            cplx m00 = Ms[0 * LS + me], m01 = Ms[1 * LS + me];
-            cplx m10 = Ms[2 * LS + me], m11 = Ms[3 * LS + me];
+            const double aJ = Ms[0 * PS + dJ].re, dJ_ = Ms[3 * PS + dJ].re;
+            const cplx bJ = Ms[1 * PS + dJ];
+            cplx m00 = Ms[0 * PS + me], m01 = Ms[1 * PS + me];
+            cplx m10 = Ms[2 * PS + me], m11 = Ms[3 * PS + me];
             // pending eigenvector update of the previous round (identity the very first time), written
             // to its seats and read back as this round's block -- independent of the chain below
             jacobi_apply_v(pc, psr, psi, v0p, v0q, v1p, v1q);
             Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
-            v0p = Vs[0 * LS + me]; v0q = Vs[1 * LS + me]; v1p = Vs[2 * LS + me]; v1q = Vs[3 * LS + me];
+            v0p = Vs[0 * PS + me]; v0q = Vs[1 * PS + me]; v1p = Vs[2 * PS + me]; v1q = Vs[3 * PS + me];
             const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
             JRot rI;
             rI.c = __shfl(rJ.c, src_lane); rI.sr = __shfl(rJ.sr, src_lane); rI.si = __shfl(rJ.si, src_lane);
@@ -330,7 +349,7 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
 template <int N, int NT = 64>
 __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true,
                                   double* red = nullptr) {
-    constexpr int NB = N / 2, LS = NB * NB;
+    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(LS <= NT, "one lane per 2x2 block");
 #ifndef FBX_JACOBI_NO_PIPELINE
     if constexpr (NT <= 64 && N == 16) { (void)red; return jacobi_eigh_wave<N>(Ms, Vs, lane, init_identity); }
@@ -342,8 +361,8 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
-        wm[e] = ((sa & 1) * 2 + (sb & 1)) * LS + (sa >> 1) * NB + (sb >> 1);
-        wv[e] = ((e >> 1) * 2 + (sb & 1)) * LS + I * NB + (sb >> 1);
+        wm[e] = ((sa & 1) * 2 + (sb & 1)) * PS + (sa >> 1) * NB + (sb >> 1);
+        wv[e] = ((e >> 1) * 2 + (sb & 1)) * PS + I * NB + (sb >> 1);
     }
     const int dI = I * NB + I, dJ = J * NB + J;            // lanes owning the pivot blocks
     const int src_lane = (lane & 63) - J + I;              // lane (I, I): same row, NB | 64 keeps rows inside a wave
@@ -352,7 +371,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cplx v; v.re = (2 * I + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; v.im = 0.0;
-            Vs[e * LS + me] = v;
+            Vs[e * PS + me] = v;
         }
     }
     if constexpr (NT > 64) __syncthreads(); else FBX_WAVE_SYNC();
@@ -362,7 +381,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             double o2 = 0.0, n2 = 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const cplx v = Ms[e * LS + me];
+                const cplx v = Ms[e * PS + me];
                 const double a2 = v.re * v.re + v.im * v.im;
                 n2 += a2;
                 if (!(I == J && (e == 0 || e == 3))) o2 += a2;
@@ -374,15 +393,15 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
         }
         for (int r = 0; r < N - 1; ++r) {
 #ifdef FBX_JACOBI_TWO_CHAINS
-            const double aI = Ms[0 * LS + dI].re, dI_ = Ms[3 * LS + dI].re;
-            const cplx bI = Ms[1 * LS + dI];
+            const double aI = Ms[0 * PS + dI].re, dI_ = Ms[3 * PS + dI].re;
+            const cplx bI = Ms[1 * PS + dI];
 #endif
-            const double aJ = Ms[0 * LS + dJ].re, dJ_ = Ms[3 * LS + dJ].re;
-            const cplx bJ = Ms[1 * LS + dJ];
-            cplx m00 = Ms[0 * LS + me], m01 = Ms[1 * LS + me];
-            cplx m10 = Ms[2 * LS + me], m11 = Ms[3 * LS + me];
-            cplx v0p = Vs[0 * LS + me], v0q = Vs[1 * LS + me];
-            cplx v1p = Vs[2 * LS + me], v1q = Vs[3 * LS + me];
+            const double aJ = Ms[0 * PS + dJ].re, dJ_ = Ms[3 * PS + dJ].re;
+            const cplx bJ = Ms[1 * PS + dJ];
+            cplx m00 = Ms[0 * PS + me], m01 = Ms[1 * PS + me];
+            cplx m10 = Ms[2 * PS + me], m11 = Ms[3 * PS + me];
+            cplx v0p = Vs[0 * PS + me], v0q = Vs[1 * PS + me];
+            cplx v1p = Vs[2 * PS + me], v1q = Vs[3 * PS + me];
             // everything read before anyone overwrites it.  A single wavefront needs no barrier and no
             // wait here or after the writes: its LDS instructions execute in program order, so the
             // reads above see the previous round and the next round's reads see the writes below.
@@ -420,7 +439,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
 // cplx of scratch.  All three arrays use the element-major block layout.
 template <int N>
 __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int lane) {
-    constexpr int NB = N / 2, LS = NB * NB;
+    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0, me = act ? lane : 0;
     cplx t[4];
@@ -429,8 +448,8 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int ke = 0; ke < 2; ++ke) {
-            const cplx h0 = Ms[(0 + ke) * LS + I * NB + kb], h1 = Ms[(2 + ke) * LS + I * NB + kb];   // H[2I+a][k]
-            const cplx v0 = Vs[(ke * 2 + 0) * LS + kb * NB + J], v1 = Vs[(ke * 2 + 1) * LS + kb * NB + J]; // V[k][2J+b]
+            const cplx h0 = Ms[(0 + ke) * PS + I * NB + kb], h1 = Ms[(2 + ke) * PS + I * NB + kb];   // H[2I+a][k]
+            const cplx v0 = Vs[(ke * 2 + 0) * PS + kb * NB + J], v1 = Vs[(ke * 2 + 1) * PS + kb * NB + J]; // V[k][2J+b]
             t[0].re += h0.re * v0.re - h0.im * v0.im; t[0].im += h0.re * v0.im + h0.im * v0.re;
             t[1].re += h0.re * v1.re - h0.im * v1.im; t[1].im += h0.re * v1.im + h0.im * v1.re;
             t[2].re += h1.re * v0.re - h1.im * v0.im; t[2].im += h1.re * v0.im + h1.im * v0.re;
@@ -439,7 +458,7 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     }
     if (act) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ts[e * LS + me] = t[e];
+        for (int e = 0; e < 4; ++e) Ts[e * PS + me] = t[e];
     }
     FBX_WAVE_SYNC();
 #pragma unroll
@@ -447,8 +466,8 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int ke = 0; ke < 2; ++ke) {
-            const cplx u0 = Vs[(ke * 2 + 0) * LS + kb * NB + I], u1 = Vs[(ke * 2 + 1) * LS + kb * NB + I]; // V[k][2I+a]
-            const cplx w0 = Ts[(ke * 2 + 0) * LS + kb * NB + J], w1 = Ts[(ke * 2 + 1) * LS + kb * NB + J]; // T[k][2J+b]
+            const cplx u0 = Vs[(ke * 2 + 0) * PS + kb * NB + I], u1 = Vs[(ke * 2 + 1) * PS + kb * NB + I]; // V[k][2I+a]
+            const cplx w0 = Ts[(ke * 2 + 0) * PS + kb * NB + J], w1 = Ts[(ke * 2 + 1) * PS + kb * NB + J]; // T[k][2J+b]
             // conj(u) * w
             t[0].re += u0.re * w0.re + u0.im * w0.im; t[0].im += u0.re * w0.im - u0.im * w0.re;
             t[1].re += u0.re * w1.re + u0.im * w1.im; t[1].im += u0.re * w1.im - u0.im * w1.re;
@@ -460,7 +479,7 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     if (act) {
         if (I == J) { t[0].im = 0.0; t[3].im = 0.0; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ms[e * LS + me] = t[e];
+        for (int e = 0; e < 4; ++e) Ms[e * PS + me] = t[e];
     }
     FBX_WAVE_SYNC();
 }
@@ -475,9 +494,9 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
 #ifndef FBX_ROTATE_VALU
 typedef double fbx_v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void jacobi_rotate_into_basis_mfma16(cplx* Ms, const cplx* Vs, int lane) {
-    constexpr int NB = 8, LS = 64;
+    constexpr int NB = 8, PS = sys_plane<16>();
     const int c = lane & 15, g = lane >> 4;
-    auto at = [](int r, int cc) { return ((r & 1) * 2 + (cc & 1)) * LS + (r >> 1) * NB + (cc >> 1); };
+    auto at = [](int r, int cc) { return ((r & 1) * 2 + (cc & 1)) * PS + (r >> 1) * NB + (cc >> 1); };
     cplx h[4], v[4];
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
@@ -522,7 +541,7 @@ __device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, in
 // terms with lam[k] == 0 are skipped (wave-uniform branch).
 template <int N>
 __device__ __forceinline__ Blk reconstruct_blk(const cplx* Vs, const double* lam, int lane) {
-    constexpr int NB = N / 2, LS = NB * NB;
+    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     Blk out = blk_zero();
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
@@ -536,8 +555,8 @@ __device__ __forceinline__ Blk reconstruct_blk(const cplx* Vs, const double* lam
         todo &= todo - 1;
         const double l = readlane_f64(mine, k);
         const int kb = k >> 1, ke = k & 1;
-        const cplx r0 = Vs[(0 + ke) * LS + I * NB + kb], r1 = Vs[(2 + ke) * LS + I * NB + kb];
-        const cplx c0 = Vs[(0 + ke) * LS + J * NB + kb], c1 = Vs[(2 + ke) * LS + J * NB + kb];
+        const cplx r0 = Vs[(0 + ke) * PS + I * NB + kb], r1 = Vs[(2 + ke) * PS + I * NB + kb];
+        const cplx c0 = Vs[(0 + ke) * PS + J * NB + kb], c1 = Vs[(2 + ke) * PS + J * NB + kb];
         const double w0r = l * r0.re, w0i = l * r0.im, w1r = l * r1.re, w1i = l * r1.im;
         // w * conj(c)
         out.re[0] += w0r * c0.re + w0i * c0.im; out.im[0] += w0i * c0.re - w0r * c0.im;

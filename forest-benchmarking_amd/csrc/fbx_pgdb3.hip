@@ -532,7 +532,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         double change = GAMMA * alpha * ipr;
         while (new_cost > old_cost + change) {
             alpha *= 0.5; change *= 0.5;
-            new_cost = cost_at(alpha); ++cost_evals; ++cost_evals;
+            new_cost = cost_at(alpha); ++cost_evals;
             ++backtracks;
             if (alpha < ALPHA_MIN) break;
         }

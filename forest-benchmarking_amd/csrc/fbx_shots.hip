@@ -195,11 +195,82 @@ beta_resample_kernel(long long n, long long R, const double* __restrict__ expect
     }
 }
 
+// Readout-calibration rescale (observable_estimation.py:1028-1037 + ratio_variance :1052-1090):
+// corrected mean = e / c and its standard error sqrt(se^2 / c^2 + e^2 var_c / c^4), element-wise over
+// B experiments x m settings; the calibration (c, var_c) of a setting's observable is shared by the batch
+// (cal index [m], or NULL for one calibration per setting in order).  16 B in, 16 B out per element.
+__global__ void __launch_bounds__(256)
+calibrate_kernel(long long B, long long m, const double* __restrict__ expect, const double* __restrict__ std_err,
+                 const int* __restrict__ cal_index, const double* __restrict__ cal_mean, const double* __restrict__ cal_var,
+                 double* __restrict__ mean_out, double* __restrict__ err_out) {
+    const long long total = B * m;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long k = idx % m;
+        const int ci = cal_index ? cal_index[k] : (int)k;
+        const double a = expect[idx], se = std_err[idx], b = cal_mean[ci], vb = cal_var[ci];
+        const double va = se * se;
+        const double b2 = b * b;
+        mean_out[idx] = a / b;
+        err_out[idx] = sqrt(va / b2 + (a * a * vb) / (b2 * b2));
+    }
+}
+
 }  // namespace fbx
 
 using namespace fbx;
 
 extern "C" {
+
+int fbx_calibrate_expectations_dev(int64_t B, int64_t m, const double* d_expect, const double* d_std_err,
+                                   const int32_t* d_cal_index, int64_t n_cal, const double* d_cal_mean,
+                                   const double* d_cal_var, double* d_mean_out, double* d_err_out) {
+    FBX_REQUIRE(B >= 0 && m >= 0 && n_cal >= 0, "fbx_calibrate_expectations: negative size");
+    FBX_REQUIRE(B * m == 0 || (d_expect && d_std_err && d_cal_mean && d_cal_var && d_mean_out && d_err_out),
+                "fbx_calibrate_expectations: NULL buffer");
+    FBX_REQUIRE(d_cal_index != nullptr || n_cal == m, "fbx_calibrate_expectations: without cal_index there must be one calibration per setting");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B * m == 0) return FBX_OK;
+    const long long total = (long long)B * m, want = (total + 255) / 256;
+    hipLaunchKernelGGL(calibrate_kernel, dim3((unsigned)(want < 256 * 32 ? want : 256 * 32)), dim3(256), 0, stream(),
+                       (long long)B, (long long)m, d_expect, d_std_err, (const int*)d_cal_index, d_cal_mean, d_cal_var,
+                       d_mean_out, d_err_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_calibrate_expectations(int64_t B, int64_t m, const double* expect, const double* std_err,
+                               const int32_t* cal_index, int64_t n_cal, const double* cal_mean,
+                               const double* cal_var, double* mean_out, double* err_out) {
+    FBX_REQUIRE(B >= 0 && m >= 0 && n_cal >= 0, "fbx_calibrate_expectations: negative size");
+    FBX_REQUIRE(B * m == 0 || (expect && std_err && cal_mean && cal_var && mean_out && err_out),
+                "fbx_calibrate_expectations: NULL buffer");
+    FBX_REQUIRE(cal_index != nullptr || n_cal == m, "fbx_calibrate_expectations: without cal_index there must be one calibration per setting");
+    if (cal_index)
+        for (int64_t k = 0; k < m; ++k)
+            FBX_REQUIRE(cal_index[k] >= 0 && cal_index[k] < n_cal, "fbx_calibrate_expectations: calibration index out of range");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B * m == 0) return FBX_OK;
+    const size_t n = (size_t)B * m;
+    DevBuf de, ds, di, dcm, dcv, dm, dr;
+    if ((rc = de.alloc(sizeof(double) * n)) || (rc = ds.alloc(sizeof(double) * n)) || (rc = di.alloc(sizeof(int32_t) * (m ? m : 1))) ||
+        (rc = dcm.alloc(sizeof(double) * (n_cal ? n_cal : 1))) || (rc = dcv.alloc(sizeof(double) * (n_cal ? n_cal : 1))) ||
+        (rc = dm.alloc(sizeof(double) * n)) || (rc = dr.alloc(sizeof(double) * n)))
+        return rc;
+    FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(ds.p, std_err, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
+    if (cal_index) FBX_HIP(hipMemcpyAsync(di.p, cal_index, sizeof(int32_t) * m, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(dcm.p, cal_mean, sizeof(double) * n_cal, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(dcv.p, cal_var, sizeof(double) * n_cal, hipMemcpyHostToDevice, stream()));
+    rc = fbx_calibrate_expectations_dev(B, m, de.as<double>(), ds.as<double>(), cal_index ? di.as<int32_t>() : nullptr, n_cal,
+                                        dcm.as<double>(), dcv.as<double>(), dm.as<double>(), dr.as<double>());
+    if (rc) return rc;
+    FBX_HIP(hipMemcpyAsync(mean_out, dm.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipMemcpyAsync(err_out, dr.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
 
 int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, const uint8_t* d_bits,
                              const uint8_t* d_obs_mask, const double* d_coefs, int beta_prior,

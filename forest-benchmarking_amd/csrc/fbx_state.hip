@@ -547,8 +547,8 @@ eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_ou
     constexpr int NB = N / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* Ms = (cplx*)smem;
-    cplx* Vs = Ms + N * N;
-    double* lam = (double*)(Vs + N * N);
+    cplx* Vs = Ms + sys_elems<N>();
+    double* lam = (double*)(Vs + sys_elems<N>());
     double* red = lam + N;
     int* pos = (int*)(red + 64);
     const int lane = threadIdx.x;
@@ -590,7 +590,7 @@ eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_ou
 template <int N>
 static int launch_eigh(int64_t B, const double* da, double* dw, double* dv) {
     constexpr int NT = (N / 2) * (N / 2) > 64 ? (N / 2) * (N / 2) : 64;
-    const size_t lds = 2 * sizeof(cplx) * N * N + sizeof(double) * (N + 64) + sizeof(int) * N;
+    const size_t lds = 2 * sizeof(cplx) * sys_elems<N>() + sizeof(double) * (N + 64) + sizeof(int) * N;
     auto kern = eigh_kernel<N, NT>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(NT), lds, stream(), (long long)B, da, dw, dv);
@@ -799,17 +799,60 @@ int fbx_eigh_dev(int N, int64_t B, const double* d_a, double* d_w_out, double* d
 }
 
 int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
-    FBX_REQUIRE(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "fbx_eigh: N must be a power of two in 2..64");
+    FBX_REQUIRE(N >= 1 && N <= 64, "fbx_eigh: N must be in 1..64");
     FBX_REQUIRE(B >= 0 && (B == 0 || (a && w_out)), "fbx_eigh: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    const size_t nn = (size_t)N * N * 2 * B;
-    HostIO io; double *da, *dw, *dv = nullptr;
-    FBX_TRY(io.in(a, nn, &da)); FBX_TRY(io.out((size_t)N * B, &dw));
-    if (v_out) FBX_TRY(io.out(nn, &dv));
-    FBX_TRY(fbx_eigh_dev(N, B, da, dw, dv));
-    FBX_TRY(io.back(w_out, dw, (size_t)N * B)); FBX_TRY(io.back(v_out, dv, nn));
-    return io.sync();
+    int Np = 2;
+    while (Np < N) Np *= 2;
+    if (Np == N) {
+        const size_t nn = (size_t)N * N * 2 * B;
+        HostIO io; double *da, *dw, *dv = nullptr;
+        FBX_TRY(io.in(a, nn, &da)); FBX_TRY(io.out((size_t)N * B, &dw));
+        if (v_out) FBX_TRY(io.out(nn, &dv));
+        FBX_TRY(fbx_eigh_dev(N, B, da, dw, dv));
+        FBX_TRY(io.back(w_out, dw, (size_t)N * B)); FBX_TRY(io.back(v_out, dv, nn));
+        return io.sync();
+    }
+    // Any other size (e.g. a qutrit's 3 x 3, a 9 x 9 Choi matrix): embedded in the next power of two
+    // with zero rows / columns.  The padding coordinates are decoupled and stay so exactly (a pivot
+    // with a zero off-diagonal entry gets the identity rotation), so their eigenvectors come back as
+    // unit vectors on the padding coordinates and are dropped here; the rest is the decomposition
+    // of the N x N matrix, still ascending.
+    const size_t np2 = (size_t)Np * Np;
+    std::vector<double> ap(np2 * 2 * B, 0.0), wp((size_t)Np * B), vp(np2 * 2 * B);
+    for (int64_t b = 0; b < B; ++b)
+        for (int r = 0; r < N; ++r)
+            memcpy(&ap[(b * np2 + (size_t)r * Np) * 2], &a[((size_t)b * N * N + (size_t)r * N) * 2], sizeof(double) * 2 * N);
+    {
+        HostIO io; double *da, *dw, *dv;
+        FBX_TRY(io.in(ap.data(), ap.size(), &da)); FBX_TRY(io.out(wp.size(), &dw)); FBX_TRY(io.out(vp.size(), &dv));
+        FBX_TRY(fbx_eigh_dev(Np, B, da, dw, dv));
+        FBX_TRY(io.back(wp.data(), dw, wp.size())); FBX_TRY(io.back(vp.data(), dv, vp.size()));
+        FBX_TRY(io.sync());
+    }
+    for (int64_t b = 0; b < B; ++b) {
+        int kept = 0;
+        for (int k = 0; k < Np; ++k) {
+            bool padding = false;
+            for (int r = N; r < Np && !padding; ++r) {
+                const double* e = &vp[(b * np2 + (size_t)r * Np + k) * 2];
+                padding = e[0] != 0.0 || e[1] != 0.0;
+            }
+            if (padding) continue;
+            if (kept < N) {
+                w_out[b * N + kept] = wp[b * Np + k];
+                if (v_out)
+                    for (int r = 0; r < N; ++r) {
+                        v_out[((size_t)b * N * N + (size_t)r * N + kept) * 2] = vp[(b * np2 + (size_t)r * Np + k) * 2];
+                        v_out[((size_t)b * N * N + (size_t)r * N + kept) * 2 + 1] = vp[(b * np2 + (size_t)r * Np + k) * 2 + 1];
+                    }
+            }
+            ++kept;
+        }
+        if (kept != N) { set_error("fbx_eigh: internal error separating the padding of a non-power-of-two matrix"); return FBX_ERR_HIP; }
+    }
+    return FBX_OK;
 }
 
 int fbx_proj_state_physical_dev(int n_qubits, int64_t B, const double* d_rho, double* d_out) {

@@ -980,7 +980,109 @@ struct HostIO {     // host <-> device staging for the host-pointer entry points
 #define FBX_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 }  // namespace
 
+// ---- Kraus bookkeeping for batches (operator_tools/compose_superoperators.py:7-44) and the Pauli twirl
+// (channel_approximation.py:31-49).  Output operator p = j * K2 + l (the reference's list order: k1 outer,
+// k2 inner) is kron(k2[l], k1[j]) for the tensor form, k2[l] . k1[j] for the composition; one output
+// element per thread, inputs read through L2 (every input element is used K times).
+namespace fbx {
+__global__ void __launch_bounds__(256)
+kraus_pairs_kernel(int tensor, long long B, int K2, int r2, int c2, int K1, int r1, int c1,
+                   const cplx* __restrict__ k2, const cplx* __restrict__ k1, cplx* __restrict__ out) {
+    const int ro = tensor ? r2 * r1 : r2, co = tensor ? c2 * c1 : c1;
+    const long long per = (long long)K1 * K2 * ro * co, total = B * per;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / per;
+        long long rem = idx - b * per;
+        const int p = (int)(rem / ((long long)ro * co)); rem -= (long long)p * ro * co;
+        const int r = (int)(rem / co), c = (int)(rem % co);
+        const int j = p / K2, l = p % K2;
+        const cplx* A = k2 + ((size_t)b * K2 + l) * r2 * c2;
+        const cplx* Bm = k1 + ((size_t)b * K1 + j) * r1 * c1;
+        cplx o; o.re = 0.0; o.im = 0.0;
+        if (tensor) {
+            const cplx x = A[(r / r1) * c2 + (c / c1)], y = Bm[(r % r1) * c1 + (c % c1)];
+            o.re = x.re * y.re - x.im * y.im; o.im = x.re * y.im + x.im * y.re;
+        } else {
+            for (int t = 0; t < c2; ++t) {
+                const cplx x = A[r * c2 + t], y = Bm[t * c1 + c];
+                o.re += x.re * y.re - x.im * y.im; o.im += x.re * y.im + x.im * y.re;
+            }
+        }
+        out[idx] = o;
+    }
+}
+__global__ void __launch_bounds__(256)
+twirl_kernel(long long B, int D, const cplx* __restrict__ chi, cplx* __restrict__ out) {
+    const long long total = B * D * D;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx % ((long long)D * D));
+        cplx o; o.re = 0.0; o.im = 0.0;
+        if (e / D == e % D) o = chi[idx];
+        out[idx] = o;
+    }
+}
+}  // namespace fbx
+
 extern "C" {
+
+int fbx_kraus_pairs_dev(int tensor, int64_t B, int K2, int rows2, int cols2, int K1, int rows1, int cols1,
+                        const double* d_k2, const double* d_k1, double* d_out) {
+    FBX_REQUIRE(B >= 0 && K1 >= 1 && K2 >= 1 && rows1 >= 1 && cols1 >= 1 && rows2 >= 1 && cols2 >= 1,
+                "fbx_kraus_pairs: sizes must be positive");
+    FBX_REQUIRE(tensor || cols2 == rows1, "fbx_kraus_pairs: composition needs cols(k2) == rows(k1)");
+    FBX_REQUIRE(B == 0 || (d_k2 && d_k1 && d_out), "fbx_kraus_pairs: NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const long long ro = tensor ? (long long)rows2 * rows1 : rows2, co = tensor ? (long long)cols2 * cols1 : cols1;
+    const long long total = (long long)B * K1 * K2 * ro * co, want = (total + 255) / 256;
+    hipLaunchKernelGGL(kraus_pairs_kernel, dim3((unsigned)(want < 256 * 32 ? want : 256 * 32)), dim3(256), 0, stream(),
+                       tensor, (long long)B, K2, rows2, cols2, K1, rows1, cols1, (const cplx*)d_k2, (const cplx*)d_k1, (cplx*)d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_kraus_pairs(int tensor, int64_t B, int K2, int rows2, int cols2, int K1, int rows1, int cols1,
+                    const double* k2, const double* k1, double* out) {
+    FBX_REQUIRE(B >= 0 && K1 >= 1 && K2 >= 1 && rows1 >= 1 && cols1 >= 1 && rows2 >= 1 && cols2 >= 1,
+                "fbx_kraus_pairs: sizes must be positive");
+    FBX_REQUIRE(tensor || cols2 == rows1, "fbx_kraus_pairs: composition needs cols(k2) == rows(k1)");
+    FBX_REQUIRE(B == 0 || (k2 && k1 && out), "fbx_kraus_pairs: NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t n2 = (size_t)B * K2 * rows2 * cols2 * 2, n1 = (size_t)B * K1 * rows1 * cols1 * 2;
+    const size_t ro = tensor ? (size_t)rows2 * rows1 : rows2, co = tensor ? (size_t)cols2 * cols1 : cols1;
+    const size_t no = (size_t)B * K1 * K2 * ro * co * 2;
+    HostIO io; double *d2, *d1, *dout;
+    FBX_TRY(io.in(k2, n2, &d2)); FBX_TRY(io.in(k1, n1, &d1)); FBX_TRY(io.out(no, &dout));
+    FBX_TRY(fbx_kraus_pairs_dev(tensor, B, K2, rows2, cols2, K1, rows1, cols1, d2, d1, dout));
+    FBX_TRY(io.back(out, dout, no));
+    return io.sync();
+}
+
+int fbx_pauli_twirl_chi_dev(int64_t B, int D, const double* d_chi, double* d_out) {
+    FBX_REQUIRE(B >= 0 && D >= 1, "fbx_pauli_twirl_chi: bad size");
+    FBX_REQUIRE(B == 0 || (d_chi && d_out), "fbx_pauli_twirl_chi: NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const long long total = (long long)B * D * D, want = (total + 255) / 256;
+    hipLaunchKernelGGL(twirl_kernel, dim3((unsigned)(want < 256 * 32 ? want : 256 * 32)), dim3(256), 0, stream(),
+                       (long long)B, D, (const cplx*)d_chi, (cplx*)d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_pauli_twirl_chi(int64_t B, int D, const double* chi, double* out) {
+    FBX_REQUIRE(B >= 0 && D >= 1, "fbx_pauli_twirl_chi: bad size");
+    FBX_REQUIRE(B == 0 || (chi && out), "fbx_pauli_twirl_chi: NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t n = (size_t)B * D * D * 2;
+    HostIO io; double *dc, *dout;
+    FBX_TRY(io.in(chi, n, &dc)); FBX_TRY(io.out(n, &dout));
+    FBX_TRY(fbx_pauli_twirl_chi_dev(B, D, dc, dout));
+    FBX_TRY(io.back(out, dout, n));
+    return io.sync();
+}
 
 int fbx_linv_process_dev(const fbx_design* design, int64_t B, const double* d_expect, double* d_choi_out) {
     FBX_TRY(check_design(design, "fbx_linv_process"));

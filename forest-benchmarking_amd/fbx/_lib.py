@@ -84,6 +84,12 @@ PROTOTYPES = {
     "fbx_eigh": [C.c_int, _i64, _dp, _dp, _dp],
     "fbx_shots_to_moments": [C.c_int, _i64, _i64, _u8p, _u8p, _dp, C.c_int, _dp, _dp],
     "fbx_shots_to_moments_dev": [C.c_int, _i64, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp],
+    "fbx_calibrate_expectations": [_i64, _i64, _dp, _dp, _ip, _i64, _dp, _dp, _dp, _dp],
+    "fbx_calibrate_expectations_dev": [_i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "fbx_kraus_pairs": [C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp],
+    "fbx_kraus_pairs_dev": [C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp],
+    "fbx_pauli_twirl_chi": [_i64, C.c_int, _dp, _dp],
+    "fbx_pauli_twirl_chi_dev": [_i64, C.c_int, _vp, _vp],
     "fbx_dfe_estimate": [C.c_int, C.c_int, _i64, _i64, _dp, _dp, _dp, _dp],
     "fbx_convert_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
     "fbx_proj_choi_dev": [C.c_int, C.c_int, _i64, _vp, _vp, _vp],
@@ -187,12 +193,17 @@ def iptr(a):
 
 
 def eigh_batch(a, eigenvectors=True):
-    """numpy.linalg.eigh semantics (lower triangle, ascending) for stacked [B, N, N], N in {2,4,8,16,32,64}."""
+    """numpy.linalg.eigh semantics (lower triangle, ascending) for stacked [B, N, N], any N in 1..64
+    (the hot sizes are the powers of two; other sizes are zero-padded inside fbx_eigh).  Larger
+    matrices are outside this build: FbxError(FBX_ERR_UNSUPPORTED) -- there is no host fallback."""
     a = c128(a)
     a = a.reshape((-1,) + a.shape[-2:])
     B, N = a.shape[0], a.shape[-1]
     if a.shape[-2] != N:
         raise ValueError("matrices must be square")
+    if N > 64:
+        raise FbxError(FBX_ERR_UNSUPPORTED, f"fbx_eigh handles N <= 64 (got {N}): matrices of more than 3 qubits "
+                                            f"are outside this build, and there is no host fallback")
     w = np.empty((B, N))
     v = np.empty((B, N, N), dtype=np.complex128) if eigenvectors else None
     check(lib().fbx_eigh(N, B, dptr(a.view(np.float64)), dptr(w), dptr(v.view(np.float64)) if eigenvectors else None))

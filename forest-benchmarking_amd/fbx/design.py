@@ -110,6 +110,8 @@ def flatten_results(results, qubits, kind):
     c = np.zeros(m)
     for k, r in enumerate(results):
         obs = r.setting.observable
+        if not set(obs.get_qubits()) <= set(qubits):
+            raise ValueError(f"observable {obs} acts on qubits outside {qubits}")
         for pos, q in enumerate(qubits):
             outs[k, pos] = PAULI_CODES[obs[q]]
         coef = complex(getattr(obs, "coefficient", 1.0))

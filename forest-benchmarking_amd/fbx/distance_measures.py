@@ -26,6 +26,23 @@ def state_measures_batch(rho, sigma=None, which=("purity", "fidelity", "trace_di
     rho = rho.reshape((-1,) + rho.shape[-2:])
     B, d = rho.shape[0], rho.shape[-1]
     sig = rho if sigma is None else _lib.c128(sigma).reshape(rho.shape)
+    if d & (d - 1) or d < 2:
+        # not a power of two (e.g. a qutrit): embedded with zero padding, which leaves all four
+        # measures unchanged (tr, spectra of products and column sums only gain zeros)
+        p = 2
+        while p < d:
+            p *= 2
+
+        def pad(x):
+            y = np.zeros((B, p, p), dtype=np.complex128)
+            y[:, :d, :d] = x
+            return y
+        same = sig is rho
+        rho = pad(rho)
+        sig = rho if same else pad(sig)
+        d = p
+    if d > 8:
+        raise _lib.FbxError(_lib.FBX_ERR_UNSUPPORTED, "state measures: dimensions above 8 (3 qubits) are outside this build")
     outs = {k: np.empty(B) for k in which}
     _lib.check(_lib.lib().fbx_state_measures(
         _nq(d), B, _lib.dptr(rho.view(np.float64)), _lib.dptr(sig.view(np.float64)),
@@ -99,9 +116,16 @@ def quantum_chernoff_bound(rho: np.ndarray, sigma: np.ndarray, tol: float = 1000
     return np.real_if_close(res.fun, tol), np.real_if_close(res.x, tol)
 
 
-def hilbert_schmidt_ip(A: np.ndarray, B: np.ndarray, tol: float = 1000) -> float:
-    """distance_measures.py:198-216 (real part; the reference returns a real for Hermitian input)."""
-    return float(state_measures_batch(A, B, ("hs_ip",))["hs_ip"][0])
+def hilbert_schmidt_ip(A: np.ndarray, B: np.ndarray, tol: float = 1000):
+    """distance_measures.py:198-216: tr(A^H B) through ``np.real_if_close`` -- a float when the
+    imaginary part is negligible (always for Hermitian operands), else the complex value.  The kernel
+    reduces Re tr(X^H Y); Im tr(A^H B) = Re tr((iA)^H B) is a second reduction of the same kernel."""
+    A, B = np.asarray(A), np.asarray(B)
+    re = float(state_measures_batch(A, B, ("hs_ip",))["hs_ip"][0])
+    if not (np.iscomplexobj(A) or np.iscomplexobj(B)):
+        return re
+    im = float(state_measures_batch(1j * A, B, ("hs_ip",))["hs_ip"][0])
+    return np.real_if_close(complex(re, im), tol).item()
 
 
 def smith_fidelity(rho: np.ndarray, sigma: np.ndarray, power) -> float:

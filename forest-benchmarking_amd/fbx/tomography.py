@@ -14,61 +14,38 @@ from . import _lib
 from . import distance_measures as dm
 from .design import Design, flatten_results, process_design, state_design  # noqa: F401
 from .observable_estimation import (ExperimentResult, ExperimentSetting, PauliTerm,
-                                    TensorProductState, zeros_state, SIC0, SIC1, SIC2, SIC3,
-                                    plusX, minusX, plusY, minusY, plusZ, minusZ)
-from .design import traceless_pauli_codes, PAULI_LABELS
+                                    TensorProductState, zeros_state, SIC0, SIC1, SIC2, SIC3,  # noqa: F401
+                                    plusX, minusX, plusY, minusY, plusZ, minusZ)  # noqa: F401
+from .observable_estimation import _OneQState
+from .design import PAULI_LABELS, STATE_LABELS
 
 import functools
-import itertools
-from operator import mul
 
 
 # ==================================================================================================
-# Experiment settings (tomography.py:31-123) -- pure bookkeeping, no pyquil Program needed
+# Experiment settings (tomography.py:31-123) -- read off the design tables (fbx.design), which hold
+# the canonical order: input states outer, traceless Pauli observables inner.  No pyquil Program.
 # ==================================================================================================
-def _traceless_pauli_terms(qubits):
-    terms = []
-    for codes in traceless_pauli_codes(len(qubits)):
-        terms.append(PauliTerm({q: PAULI_LABELS[c] for q, c in zip(qubits, codes)}))
-    return terms
-
-
-def _state_tomo_settings(qubits: Sequence[int]):
-    for obs in _traceless_pauli_terms(qubits):
-        yield ExperimentSetting(in_state=zeros_state(qubits), observable=obs)
-
-
-def _sic_process_tomo_settings(qubits: Sequence[int]):
-    for in_sics in itertools.product([SIC0, SIC1, SIC2, SIC3], repeat=len(qubits)):
-        i_state = functools.reduce(mul, (state(q) for state, q in zip(in_sics, qubits)),
-                                   TensorProductState())
-        for obs in _traceless_pauli_terms(qubits):
-            yield ExperimentSetting(in_state=i_state, observable=obs)
-
-
-def _pauli_process_tomo_settings(qubits):
-    for states in itertools.product([plusX, minusX, plusY, minusY, plusZ, minusZ],
-                                    repeat=len(qubits)):
-        i_state = functools.reduce(mul, (state(q) for state, q in zip(states, qubits)),
-                                   TensorProductState())
-        for obs in _traceless_pauli_terms(qubits):
-            yield ExperimentSetting(in_state=i_state, observable=obs)
+def _settings_of(design: Design, qubits: Sequence[int]) -> List[ExperimentSetting]:
+    qubits = list(qubits)
+    out = []
+    for prep_codes, pauli_codes in zip(design.in_labels, design.paulis):
+        prepared = TensorProductState(_OneQState(*STATE_LABELS[int(c)], q) for c, q in zip(prep_codes, qubits))
+        measured = PauliTerm({q: PAULI_LABELS[int(c)] for c, q in zip(pauli_codes, qubits)})
+        out.append(ExperimentSetting(in_state=prepared, observable=measured))
+    return out
 
 
 def generate_state_tomography_settings(qubits: List[int]) -> List[ExperimentSetting]:
-    """The settings of generate_state_tomography_experiment (tomography.py:46-60)."""
-    return list(_state_tomo_settings(qubits))
+    """The settings of generate_state_tomography_experiment (tomography.py:46-60): |0..0> in, every
+    traceless Pauli out."""
+    return _settings_of(state_design(len(qubits)), qubits)
 
 
 def generate_process_tomography_settings(qubits: List[int], in_basis='pauli') -> List[ExperimentSetting]:
-    """The settings of generate_process_tomography_experiment (tomography.py:100-123)."""
-    if in_basis.upper() == 'SIC':
-        func = _sic_process_tomo_settings
-    elif in_basis.upper() == 'PAULI':
-        func = _pauli_process_tomo_settings
-    else:
-        raise ValueError(f"Unknown basis {in_basis}")
-    return list(func(qubits))
+    """The settings of generate_process_tomography_experiment (tomography.py:100-123); an unknown
+    ``in_basis`` raises the reference's ``ValueError``."""
+    return _settings_of(process_design(len(qubits), in_basis), qubits)
 
 
 def _batch_arrays(design, expectations, total_counts=None):
@@ -174,16 +151,13 @@ def state_log_likelihood(state: np.ndarray, results, qubits: Sequence[int]) -> f
 
 
 def _resample_expectations_with_beta(results, prior_counts=1):
-    """tomography.py:378-409 -- host RNG (np.random global stream, as in the reference)."""
-    resampled = []
-    for result in results:
-        num_plus = ((result.expectation + 1) / 2) * result.total_counts
-        num_minus = result.total_counts - num_plus
-        resampled_expect = 2 * np.random.beta(num_plus + prior_counts, num_minus + prior_counts) - 1
-        resampled.append(ExperimentResult(setting=result.setting, expectation=resampled_expect,
-                                          std_err=result.std_err,
-                                          total_counts=result.total_counts))
-    return resampled
+    """tomography.py:378-409: one Beta-posterior redraw of every expectation, from numpy's global
+    stream in result order (one vectorised ``np.random.beta`` call draws in exactly that order)."""
+    e = np.array([np.real(r.expectation) for r in results], dtype=float)
+    c = np.array([r.total_counts for r in results], dtype=float)
+    redrawn = resample_expectations_with_beta_batch(e, c, 1, prior_counts)[0]
+    return [ExperimentResult(setting=r.setting, expectation=float(x), std_err=r.std_err, total_counts=r.total_counts)
+            for r, x in zip(results, redrawn)]
 
 
 def resample_expectations_with_beta_batch(expectations, total_counts, n_resamples, prior_counts=1, seed=None):
@@ -266,17 +240,16 @@ def estimate_variance(results: List[ExperimentResult], qubits: List[int], tomo_e
             if functional == dm.infidelity:
                 vals = 1 - vals
         return np.mean(vals), np.var(vals)
-    sample_estimate = []
-    for _ in range(n_resamples):
-        resampled_results = _resample_expectations_with_beta(results)
-        rho = tomo_estimator(resampled_results, qubits)
+    # opaque callables: one reconstruction per resample, through whatever the caller passed in
+    def one_sample():
+        rho = tomo_estimator(_resample_expectations_with_beta(results), qubits)
         if project_to_physical:
             rho = project_state_matrix_to_physical(rho)
-        if functional == dm.purity:
-            sample_estimate.append(np.real(dm.purity(rho, dim_renorm=False)))
-        else:
-            sample_estimate.append(np.real(functional(target_state, rho)))
-    return np.mean(sample_estimate), np.var(sample_estimate)
+        value = dm.purity(rho, dim_renorm=False) if functional == dm.purity else functional(target_state, rho)
+        return np.real(value)
+
+    values = np.array([one_sample() for _ in range(n_resamples)])
+    return np.mean(values), np.var(values)
 
 
 _BATCHED_ESTIMATORS[linear_inv_state_estimate] = lambda design, e, c: linear_inv_state_estimate_batch(design, e)

@@ -225,6 +225,20 @@ int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rh
 int fbx_apply_choi_dev(int n_qubits, int64_t B, const double* d_choi, const double* d_rho,
                        double* d_out);
 
+/* tensor_channel_kraus / compose_channel_kraus (operator_tools/compose_superoperators.py:7-44) for
+ * batches: k2[B][K2][rows2][cols2], k1[B][K1][rows1][cols1]; out[B][K1*K2][.][.] with operator
+ * p = j*K2 + l (the reference's list order) = kron(k2[l], k1[j]) when tensor != 0, else k2[l] . k1[j]
+ * (needs cols2 == rows1). */
+int fbx_kraus_pairs(int tensor, int64_t B, int K2, int rows2, int cols2, int K1, int rows1, int cols1,
+                    const double* k2, const double* k1, double* out);
+int fbx_kraus_pairs_dev(int tensor, int64_t B, int K2, int rows2, int cols2, int K1, int rows1,
+                        int cols1, const double* d_k2, const double* d_k1, double* d_out);
+
+/* pauli_twirl_chi_matrix (operator_tools/channel_approximation.py:31-49): out[B][D][D] keeps the
+ * diagonal of chi[B][D][D]. */
+int fbx_pauli_twirl_chi(int64_t B, int D, const double* chi, double* out);
+int fbx_pauli_twirl_chi_dev(int64_t B, int D, const double* d_chi, double* d_out);
+
 /* entanglement_fidelity / process_fidelity (distance_measures.py:271-359) on
  * Pauli-Liouville matrices [B][D][D] (real parts of tr(A^H B) / d^2): fe_out, fp_out may be
  * NULL. */
@@ -257,6 +271,20 @@ int fbx_shots_to_moments(int n_qubits, int64_t n_settings, int64_t n_shots, cons
 int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, const uint8_t* d_bits,
                              const uint8_t* d_obs_mask, const double* d_coefs, int beta_prior,
                              double* d_mean_out, double* d_var_out);
+
+/* Readout-calibration rescale, the arithmetic of calibrate_observable_estimates
+ * (observable_estimation.py:1028-1037) with ratio_variance (:1052-1090), for B experiments x m settings:
+ * mean_out = expect / cal_mean[c], err_out = sqrt(std_err^2 / cal_mean[c]^2 + expect^2 cal_var[c] /
+ * cal_mean[c]^4) with c = cal_index[k] (the calibration of setting k's observable; cal_index NULL =
+ * one calibration per setting, n_cal == m).  cal_mean / cal_var are the shots_to_obs_moments of the
+ * calibration runs (fbx_shots_to_moments). */
+int fbx_calibrate_expectations(int64_t B, int64_t m, const double* expect, const double* std_err,
+                               const int32_t* cal_index, int64_t n_cal, const double* cal_mean,
+                               const double* cal_var, double* mean_out, double* err_out);
+int fbx_calibrate_expectations_dev(int64_t B, int64_t m, const double* d_expect,
+                                   const double* d_std_err, const int32_t* d_cal_index, int64_t n_cal,
+                                   const double* d_cal_mean, const double* d_cal_var,
+                                   double* d_mean_out, double* d_err_out);
 
 /* estimate_dfe (direct_fidelity_estimation.py:224-307), batched: for each of B experiments with m
  * settings on n_qubits, expect[B][m] and std_err[B][m] -> the direct fidelity estimate and its standard
@@ -307,7 +335,9 @@ int fbx_random_kraus_dev(int n_qubits, int64_t B, int K, uint64_t seed, int64_t 
                          double* d_kraus_out);
 
 /* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
- * LOWER triangle of a[B][N][N] is read, eigenvalues ascending), N in {2, 4, 8, 16, 32, 64}.  This is the
+ * LOWER triangle of a[B][N][N] is read, eigenvalues ascending).  The host form takes any N in 1..64
+ * (sizes that are not a power of two -- a qutrit, a 9 x 9 Choi matrix -- are embedded in the next
+ * power of two with decoupled zero padding); the _dev form N in {2, 4, 8, 16, 32, 64}.  This is the
  * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators
  * (validate_operator.py:118-150), proj_choi_to_unitary (project_superoperators.py:147-175),
  * sqrtm_psd (calculational.py:77-91) and the spectral distance measures (distance_measures.py:153-195,440-460).

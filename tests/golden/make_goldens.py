@@ -58,18 +58,21 @@ def make_process(n, basis, batch, tni_items):
     print("process", n, basis, "done")
 
 
-def make_process_3q():
-    """BASELINE config 4 shape: 3 qubits, SIC in-basis (4032 settings), one item -- the reference's
-    pgdb_process_estimate run to convergence (about a minute here)."""
+def make_process_3q(batch=4):
+    """BASELINE config 4 shape: 3 qubits, SIC in-basis (4032 settings), `batch` items -- the reference's
+    pgdb_process_estimate run to convergence (about a minute per item here)."""
     qubits = [0, 1, 2]
-    design, us, e, c = synthetic.process_batch(3, "sic", 1)
+    design, us, e, c = synthetic.process_batch(3, "sic", batch)
     settings = process_settings(qubits, "sic")
     assert len(settings) == design.m
-    res = ref_results(settings, e[0], c[0])
-    est = T.pgdb_process_estimate(res, qubits)
-    linv = T.linear_inv_process_estimate(res, qubits)
+    est, linv = [], []
+    for b in range(batch):
+        res = ref_results(settings, e[b], c[b])
+        est.append(T.pgdb_process_estimate(res, qubits))
+        linv.append(T.linear_inv_process_estimate(res, qubits))
+        print("process 3 sic item", b, "done", flush=True)
     np.savez_compressed(os.path.join(HERE, "process_3q_sic.npz"), n_qubits=3, unitaries=us,
-                        expectations=e, counts=c, pgdb=est[None], linv=linv[None])
+                        expectations=e, counts=c, pgdb=np.array(est), linv=np.array(linv))
     print("process 3 sic done")
 
 
@@ -238,8 +241,73 @@ def make_extras():
     print("extras done")
 
 
+def make_round2():
+    """Rows a24 / a25 / a26 / a28 / f2 added in round 2: Kraus composition and tensoring, Pauli twirl,
+    Kraus application (square and non-square, apply_superoperator.py:33-57), the calibration rescale
+    (observable_estimation.py:1028-1037) and operators whose dimension is not a power of two."""
+    CS = __import__("forest.benchmarking.operator_tools.compose_superoperators", fromlist=["x"])
+    CA = __import__("forest.benchmarking.operator_tools.channel_approximation", fromlist=["x"])
+    AS = __import__("forest.benchmarking.operator_tools.apply_superoperator", fromlist=["x"])
+    VO = __import__("forest.benchmarking.operator_tools.validate_operator", fromlist=["x"])
+    CALC = ref.calculational
+    rs = np.random.RandomState(2024)
+    out = {}
+
+    def cset(K, r, c):
+        return rs.randn(K, r, c) + 1j * rs.randn(K, r, c)
+    cases = [(2, 2, 2, 3, 2, 2), (1, 4, 4, 4, 4, 4), (3, 2, 4, 2, 4, 2), (2, 3, 3, 2, 3, 3)]   # K2, r2, c2, K1, r1, c1
+    for k, (K2, r2, c2, K1, r1, c1) in enumerate(cases):
+        a, b = cset(K2, r2, c2), cset(K1, r1, c1)
+        out[f"pairs{k}_k2"], out[f"pairs{k}_k1"] = a, b
+        out[f"pairs{k}_tensor"] = np.array(CS.tensor_channel_kraus(list(a), list(b)))
+        if c2 == r1:
+            out[f"pairs{k}_compose"] = np.array(CS.compose_channel_kraus(list(a), list(b)))
+    for D in (4, 16):
+        chi = rs.randn(3, D, D) + 1j * rs.randn(3, D, D)
+        out[f"twirl{D}_in"] = chi
+        out[f"twirl{D}_out"] = np.array([CA.pauli_twirl_chi_matrix(x) for x in chi])
+    # real Kraus sets on real states (the only operands the reference's real accumulator accepts)
+    for k, (K, rows, cols) in enumerate([(2, 2, 2), (3, 4, 4), (2, 2, 4), (2, 3, 3), (1, 8, 8), (2, 4, 8)]):
+        ks = rs.randn(K, rows, cols)
+        g = rs.randn(cols, cols)
+        st = g @ g.T / np.trace(g @ g.T)
+        out[f"applyk{k}_kraus"], out[f"applyk{k}_state"] = ks, st
+        out[f"applyk{k}_out"] = AS.apply_kraus_ops_2_state(list(ks), st)
+    # calibration rescale: the two lines of observable_estimation.py:1033-1034 on random inputs
+    e, se = rs.uniform(-1, 1, size=(5, 12)), rs.uniform(0.001, 0.1, size=(5, 12))
+    cm, cv = rs.uniform(0.6, 0.99, size=4), rs.uniform(1e-5, 1e-3, size=4)
+    idx = rs.randint(0, 4, size=12)
+    out["cal_e"], out["cal_se"], out["cal_mean"], out["cal_var"], out["cal_index"] = e, se, cm, cv, idx
+    out["cal_out_mean"] = e / cm[idx][None]
+    out["cal_out_err"] = np.sqrt(OE.ratio_variance(e, se ** 2, cm[idx][None], cv[idx][None]))
+    # dimensions that are not powers of two
+    for d in (3, 5, 6):
+        g1, g2 = rs.randn(d, d) + 1j * rs.randn(d, d), rs.randn(d, d) + 1j * rs.randn(d, d)
+        r1, r2 = g1 @ g1.conj().T, g2 @ g2.conj().T
+        r1, r2 = r1 / np.trace(r1).real, r2 / np.trace(r2).real
+        out[f"gd{d}_rho"], out[f"gd{d}_sigma"] = r1, r2
+        out[f"gd{d}_measures"] = np.array([DM.purity(r1), DM.fidelity(r1, r2), DM.trace_distance(r1, r2),
+                                           DM.hilbert_schmidt_ip(r1, r2)])
+        out[f"gd{d}_sqrtm"] = CALC.sqrtm_psd(r1)
+        out[f"gd{d}_eigvals"] = np.linalg.eigvalsh(r1 - r2)
+        out[f"gd{d}_psd"] = np.array([VO.is_positive_semidefinite_matrix(r1), VO.is_positive_semidefinite_matrix(r1 - r2),
+                                      VO.is_positive_definite_matrix(r1)])
+    u = synthetic.haar_unitary(4, np.random.RandomState(3))
+    v = synthetic.haar_unitary(4, np.random.RandomState(4))
+    out["hs_u"], out["hs_v"] = u, v
+    out["hs_uv"] = np.array([DM.hilbert_schmidt_ip(u, v)])             # complex: the operands are not Hermitian
+    qutrit_choi = OT.kraus2choi([np.diag([1.0, np.exp(0.3j), np.exp(-0.7j)])])
+    out["qutrit_choi"] = qutrit_choi
+    out["qutrit_apply"] = AS.apply_choi_matrix_2_state(qutrit_choi, out["gd3_rho"])
+    np.savez_compressed(os.path.join(HERE, "round2.npz"), **out)
+    print("round2 done")
+
+
 if __name__ == "__main__":
     np.random.seed(0)
+    if "--round2" in sys.argv:
+        make_round2()
+        sys.exit(0)
     if "--extras" in sys.argv:
         make_extras()
         sys.exit(0)
@@ -247,10 +315,14 @@ if __name__ == "__main__":
         make_process_3q()
         make_superops(3, 1)
         sys.exit(0)
+    if "--2q" in sys.argv:
+        make_process(2, "sic", 16, 2)
+        make_process(2, "pauli", 16, 1)
+        sys.exit(0)
     make_process(1, "pauli", 6, 3)
     make_process(1, "sic", 6, 3)
-    make_process(2, "sic", 4, 2)
-    make_process(2, "pauli", 4, 1)
+    make_process(2, "sic", 16, 2)
+    make_process(2, "pauli", 16, 1)
     make_state(1, 6)
     make_state(2, 4)
     make_superops(1, 6)

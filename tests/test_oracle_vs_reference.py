@@ -131,3 +131,58 @@ def test_shots_to_obs_moments(ref):
             got = oa.shots_to_obs_moments(bits, mask, coef, prior)
             assert np.allclose(want, got, rtol=0, atol=1e-15)
     assert OE.ratio_variance(1.0, 0.1, 2.0, 0.05) == oa.ratio_variance(1.0, 0.1, 2.0, 0.05) == 0.028125
+
+
+def test_setting_generators_and_text_forms_match_the_reference(ref):
+    """The shim's settings come from its design tables and its record classes are its own code; what must
+    agree with the reference is the ORDER of the settings and every text form (the interchange schema)."""
+    from fbx import tomography as T, observable_estimation as oe
+    RT, ROE = ref.tomography, ref.observable_estimation
+    for qubits in ([0], [3, 1], [2, 0, 1]):
+        mine = T.generate_state_tomography_settings(qubits)
+        theirs = list(RT._state_tomo_settings(qubits))
+        assert [str(s) for s in mine] == [str(s) for s in theirs]
+        if len(qubits) == 3:
+            continue
+        for basis, gen in (("pauli", RT._pauli_process_tomo_settings), ("sic", RT._sic_process_tomo_settings)):
+            mine = T.generate_process_tomography_settings(qubits, basis)
+            theirs = list(gen(qubits))
+            assert [str(s) for s in mine] == [str(s) for s in theirs]
+            # text -> object -> text through both implementations
+            for s in theirs[:: max(1, len(theirs) // 7)]:
+                assert str(oe.ExperimentSetting.from_str(str(s))) == str(s)
+                assert str(ROE.ExperimentSetting.from_str(str(oe.ExperimentSetting.from_str(str(s))))) == str(s)
+    with pytest.raises(ValueError):
+        T.generate_process_tomography_settings([0], "bogus")
+    # record serialisation: same keys and values as the reference's
+    rs = ROE.ExperimentSetting(ROE.plusX(0) * ROE.SIC2(1), ref.PauliTerm.from_list([("X", 0), ("Z", 1)]))
+    ms = oe.ExperimentSetting.from_str(str(rs))
+    rr = ROE.ExperimentResult(setting=rs, expectation=0.25, std_err=0.01, total_counts=500, raw_expectation=0.2)
+    mr = oe.ExperimentResult(setting=ms, expectation=0.25, std_err=0.01, total_counts=500, raw_expectation=0.2)
+    import json
+    assert json.loads(json.dumps(mr, cls=oe.OperatorEncoder)) == json.loads(json.dumps(rr, cls=ROE.OperatorEncoder))
+    for text in ("X+_0", "Y-_12", "SIC3_7", " Z+_1 "):
+        assert str(oe._OneQState.from_str(text)) == str(ROE._OneQState.from_str(text))
+    for bad in ("X+", "nonsense", "X?_1"):
+        with pytest.raises(ValueError):
+            oe._OneQState.from_str(bad)
+        with pytest.raises(ValueError):
+            ROE._OneQState.from_str(bad)
+    assert oe.plusX(0) * oe.minusZ(1) == oe.minusZ(1) * oe.plusX(0)
+    assert hash(oe.zeros_state([0, 1])) == hash(oe.plusZ(1) * oe.plusZ(0))
+
+
+def test_beta_resampling_keeps_the_reference_draw_order(ref):
+    from fbx import tomography as T, observable_estimation as oe
+    RT, ROE = ref.tomography, ref.observable_estimation
+    settings_r = list(RT._state_tomo_settings([0, 1]))
+    settings_m = T.generate_state_tomography_settings([0, 1])
+    rs = np.random.RandomState(3)
+    e = rs.uniform(-0.9, 0.9, size=len(settings_r))
+    res_r = [ROE.ExperimentResult(setting=s, expectation=float(x), std_err=0.0, total_counts=300) for s, x in zip(settings_r, e)]
+    res_m = [oe.ExperimentResult(setting=s, expectation=float(x), std_err=0.0, total_counts=300) for s, x in zip(settings_m, e)]
+    np.random.seed(77)
+    want = [r.expectation for r in RT._resample_expectations_with_beta(res_r)]
+    np.random.seed(77)
+    got = [r.expectation for r in T._resample_expectations_with_beta(res_m)]
+    assert got == want

