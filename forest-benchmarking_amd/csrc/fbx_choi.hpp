@@ -17,11 +17,17 @@
 
 namespace fbx {
 
-// LDS work area shared by the routines below (carved by the kernel)
-template <int NQ>
+// LDS work area shared by the routines below (carved by the kernel).  LEAN (the 2-waves-per-SIMD PGDB
+// variant, 16.5 KB per reconstruction instead of 39 KB): no separate staging matrix -- the Pauli transforms
+// stage through Ms and spill into Vs (both dead outside a projection), the partial trace inside a projection
+// through Ms alone (dead once the eigenvalues are read) with an unpadded leading dimension.
+template <int NQ, bool LEAN = false>
 struct ChoiLds {
     static constexpr int d = 1 << NQ, D = d * d, LD = D + 1, LDs = d + 1;
-    cplx* Mw;      // [D * LD]   row-major staging matrix (partial trace, Pauli transforms)
+    static constexpr int LDpt = LEAN ? D : LD;     // leading dimension of the partial-trace staging
+    static constexpr bool lean = LEAN;
+    cplx* Mw;      // [D * LD]   row-major staging matrix (Pauli transforms); LEAN: = Ms, running into Vs
+    cplx* Mpt;     // partial-trace staging: Mw, or Ms (LEAN)
     cplx* Ms;      // [sys_elems<D>()]  Jacobi work matrix, element-major block layout (fbx_eigh.hpp)
     cplx* Vs;      // [sys_elems<D>()]  eigenvectors, same layout
     double* lam;   // [D]
@@ -32,12 +38,14 @@ struct ChoiLds {
     PhaseClock* pc = nullptr;   // diagnostics (FBX_PHASE_TIMERS builds)
     int terms = 0;              // work accounting: eigenvalue terms rebuilt by the CP projections (wave-uniform)
     static constexpr size_t bytes() {
-        return sizeof(cplx) * (D * LD + 2 * sys_elems<D>() + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
+        static_assert(!LEAN || 2 * sys_elems<D>() >= D * LD, "the transforms' staging matrix must fit into Ms + Vs");
+        return sizeof(cplx) * ((LEAN ? 0 : D * LD) + 2 * sys_elems<D>() + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
     }
     __device__ void carve(char*& p) {
-        Mw = (cplx*)p; p += sizeof(cplx) * D * LD;
+        if constexpr (!LEAN) { Mw = (cplx*)p; p += sizeof(cplx) * D * LD; }
         Ms = (cplx*)p; p += sizeof(cplx) * sys_elems<D>();
         Vs = (cplx*)p; p += sizeof(cplx) * sys_elems<D>();
+        if constexpr (LEAN) { Mw = Ms; Mpt = Ms; } else { Mpt = Mw; }
         pt = (cplx*)p; p += sizeof(cplx) * d * LDs;
         pts = (cplx*)p; p += sizeof(cplx) * d * d;
         ptV = (cplx*)p; p += sizeof(cplx) * d * d;
@@ -49,10 +57,10 @@ struct ChoiLds {
 // ---- CP projection: Hermitise, eigh, clamp negative eigenvalues, rebuild -----------------
 // project_superoperators.py:19-34.  `x` need not be Hermitian.  `sweeps` accumulates Jacobi
 // sweeps (diagnostics).
-template <int NQ>
-__device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, bool warm = false,
+template <int NQ, class LdsT>
+__device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool warm = false,
                        bool check_basis = false) {
-    constexpr int D = ChoiLds<NQ>::D;
+    constexpr int D = LdsT::D;
     FBX_WAVE_SYNC();                       // previous readers of Ms / Vs are done
     sys_store<D>(L.Ms, lane, x);
     FBX_WAVE_SYNC();
@@ -78,7 +86,10 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
         if constexpr (D == 16) jacobi_rotate_into_basis_mfma16(L.Ms, L.Vs, lane);
         else
 #endif
+        {
+            static_assert(D == 16 || !LdsT::lean, "the lean layout has no scratch for the generic basis change");
             jacobi_rotate_into_basis<D>(L.Ms, L.Vs, (cplx*)L.Mw, lane);
+        }
     }
     int sw;
 #ifndef FBX_JACOBI_NO_PIPELINE
@@ -122,18 +133,18 @@ __device__ Blk proj_cp_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps, 
 
 // ---- partial trace over the output space into L.pt (d x d): calculational.py:5-35 with
 // keep=[0], dims=[d, d].  Stages `x` through Mw.
-template <int NQ>
-__device__ void partial_trace_out(const Blk& x, ChoiLds<NQ>& L, int lane) {
-    constexpr int d = ChoiLds<NQ>::d, D = ChoiLds<NQ>::D, LD = ChoiLds<NQ>::LD, LDs = ChoiLds<NQ>::LDs;
+template <int NQ, class LdsT>
+__device__ void partial_trace_out(const Blk& x, LdsT& L, int lane) {
+    constexpr int d = LdsT::d, D = LdsT::D, LD = LdsT::LDpt, LDs = LdsT::LDs;
     FBX_WAVE_SYNC();
-    blk_store<D, LD>(L.Mw, lane, x);
+    blk_store<D, LD>(L.Mpt, lane, x);
     FBX_WAVE_SYNC();
     if (lane < d * d) {
         const int i = lane / d, ip = lane % d;
         cplx s; s.re = 0.0; s.im = 0.0;
 #pragma unroll
         for (int o = 0; o < d; ++o) {
-            const cplx v = L.Mw[(i * d + o) * LD + ip * d + o];
+            const cplx v = L.Mpt[(i * d + o) * LD + ip * d + o];
             s.re += v.re; s.im += v.im;
         }
         L.pt[i * LDs + ip] = s;
@@ -142,9 +153,9 @@ __device__ void partial_trace_out(const Blk& x, ChoiLds<NQ>& L, int lane) {
 }
 
 // subtract kron(corr / d, I_d) where corr (d x d) is in L.pt
-template <int NQ>
-__device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const ChoiLds<NQ>& L, int lane) {
-    constexpr int d = ChoiLds<NQ>::d, D = ChoiLds<NQ>::D, LDs = ChoiLds<NQ>::LDs, NB = D / 2;
+template <int NQ, class LdsT>
+__device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const LdsT& L, int lane) {
+    constexpr int d = LdsT::d, D = LdsT::D, LDs = LdsT::LDs, NB = D / 2;
     Blk r = x;
     if (lane < NB * NB) {
         const int I = lane / NB, J = lane % NB;
@@ -161,9 +172,9 @@ __device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const ChoiLds<NQ>&
 }
 
 // ---- TP projection: project_superoperators.py:62-84
-template <int NQ>
-__device__ Blk proj_tp_blk(const Blk& x, ChoiLds<NQ>& L, int lane) {
-    constexpr int d = ChoiLds<NQ>::d, LDs = ChoiLds<NQ>::LDs;
+template <int NQ, class LdsT>
+__device__ Blk proj_tp_blk(const Blk& x, LdsT& L, int lane) {
+    constexpr int d = LdsT::d, LDs = LdsT::LDs;
     partial_trace_out<NQ>(x, L, lane);
     if (lane < d) L.pt[lane * LDs + lane].re -= 1.0;       // pt - I
     FBX_WAVE_SYNC();
@@ -172,9 +183,9 @@ __device__ Blk proj_tp_blk(const Blk& x, ChoiLds<NQ>& L, int lane) {
 
 // ---- TNI projection: project_superoperators.py:37-59 (d x d eigh of the partial trace,
 // eigenvalues above 1 clamped to 1)
-template <int NQ>
-__device__ Blk proj_tni_blk(const Blk& x, ChoiLds<NQ>& L, int lane, int& sweeps) {
-    constexpr int d = ChoiLds<NQ>::d, LDs = ChoiLds<NQ>::LDs;
+template <int NQ, class LdsT>
+__device__ Blk proj_tni_blk(const Blk& x, LdsT& L, int lane, int& sweeps) {
+    constexpr int d = LdsT::d, LDs = LdsT::LDs;
     partial_trace_out<NQ>(x, L, lane);
     // keep pt in registers, Hermitise a copy for the eigensolver
     const Blk ptb = blk_load<d, LDs>(L.pt, lane);
@@ -229,11 +240,11 @@ struct BasisStore {
     }
 };
 
-template <int NQ>
-__device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ>& L, int lane,
+template <int NQ, class LdsT>
+__device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, int lane,
                                  int& iters, int& sweeps, int max_iter = 100000,
                                  BasisStore* store = nullptr) {
-    constexpr int DD = ChoiLds<NQ>::D * ChoiLds<NQ>::D;
+    constexpr int DD = LdsT::D * LdsT::D;
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
     // (the caller passes the address of a local BasisStore unconditionally -- a pointer chosen at run time
@@ -255,14 +266,14 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int idx = lane + 64 * u;
-                if (idx < DD) L.Vs[sys_linear<ChoiLds<NQ>::D>(idx)] = store->pf[u];
+                if (idx < DD) L.Vs[sys_linear<LdsT::D>(idx)] = store->pf[u];
             }
             store->pf_slot = -1;
 #ifdef FBX_DBG_WAITPHASE
             PH_STOP(*L.pc, 7);
 #endif
 #ifdef FBX_DBG_CORRUPT_BASIS                   // test hook: damage every basis loaded for Dykstra iteration 1
-            if (it == 1 && lane < 3) L.Vs[sys_linear<ChoiLds<NQ>::D>(17 * lane)].re += 0.25;
+            if (it == 1 && lane < 3) L.Vs[sys_linear<LdsT::D>(17 * lane)].re += 0.25;
 #endif
             warm = true;
         }
@@ -280,7 +291,7 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, ChoiLds<NQ
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int idx = lane + 64 * u;
-                    if (idx < DD) { const cplx w = L.Vs[sys_linear<ChoiLds<NQ>::D>(idx)]; dst[idx] = fbx_v2d{w.re, w.im}; }
+                    if (idx < DD) { const cplx w = L.Vs[sys_linear<LdsT::D>(idx)]; dst[idx] = fbx_v2d{w.re, w.im}; }
                 }
             }
         }

@@ -62,6 +62,7 @@ struct DesignDev {
     const double* coef;      // [m] (grouped)
     const int* sptr;         // [S+1] grouped ranges per distinct input state
     const double* C;         // [D][S] Bloch coefficients c_j(s) = tr(P_j rho_s)
+    const double* Ct;        // [S][D] the same, one state per row (read from L2 by the lean PGDB kernel)
     // linear inversion of process designs: settings grouped by observable, and the rows of the
     // block pseudo-inverses (data independent; replaces pinv of tomography.py:482-488)
     const int* porder;       // [m] position grouped by Pauli index -> caller's setting index

@@ -16,6 +16,9 @@
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
 #include "fbx_choi.hpp"
 #include <cstdlib>
+#ifndef FBX_LEAN_MIN_BATCH
+#define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
+#endif
 #ifndef FBX_BASIS_RESET_MASK
 #define FBX_BASIS_RESET_MASK 15
 #endif
@@ -39,22 +42,27 @@ constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
 #define FBX_SMALL_STEP_LIMIT 0x1p-3      // alpha * max |pu / pe| below which the line search uses the power-sum series
 #endif
 
-template <int NQ>
+// LEAN (2 waves per SIMD at large batches): 16.5 KB instead of 39 KB per reconstruction -- the Bloch matrix is
+// read from L2 (DesignDev::Ct), the normalised counts are recomputed from the inputs (L2) wherever they are
+// used, and ONE prediction table serves the estimate and the update direction in turn (the estimate's table
+// is rebuilt after the projection).
+template <int NQ, bool LEAN = false>
 struct PgdbLds {
-    ChoiLds<NQ> choi;
+    ChoiLds<NQ, LEAN> choi;
     double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time), TRANSPOSED: Rb[j * D + i] = R[i][j]
-    double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
+    double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate           (LEAN: = Tupd)
     double* Tupd;   // [S*D]  same for the update direction; reused as Wt[S][D] in the gradient
-    double* Cl;     // [S*D]  Bloch coefficients of the input states, one state per row: Cl[s * D + j] = C[j][s]
+    double* Cl;     // [S*D]  Bloch coefficients of the input states, one state per row: Cl[s * D + j] = C[j][s]   (LEAN: none)
     double* Ln;     // [2*ceil(m/64)][64]  normalised counts n+ / n- of this lane's outcomes (row 2 j + sign): item
-                    // constants that are only read by the cost / gradient passes -- kept here, not in 36 registers
+                    // constants that are only read by the cost / gradient passes -- kept here, not in 36 registers (LEAN: none)
     // Rb and Tupd are adjacent: both are dead while the projection runs, and together (>= 16 D^2 bytes,
     // Tupd is sized for at least D states) they park the gradient block of every lane meanwhile
     static size_t bytes(int S, int m) {
         constexpr int D = ChoiLds<NQ>::D;
         const size_t Su = S > D ? S : D;
-        return ((ChoiLds<NQ>::bytes() + 15) & ~(size_t)15) +
-               sizeof(double) * ((size_t)D * D + (Su + 2 * (size_t)S) * D + 2 * (size_t)((m + 63) / 64) * 64) + 64;
+        const size_t base = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
+        if (LEAN) return base + sizeof(double) * ((size_t)D * D + Su * D) + 64;
+        return base + sizeof(double) * ((size_t)D * D + (Su + 2 * (size_t)S) * D + 2 * (size_t)((m + 63) / 64) * 64) + 64;
     }
     // every pointer is a plain offset from the start of the dynamic LDS segment (no conditional
     // layout), so the compiler keeps them in the LDS address space (ds_* instead of flat_*)
@@ -64,13 +72,16 @@ struct PgdbLds {
         choi.carve(q);
         // (rounding the POINTER up through an integer cast would turn everything behind it into
         // generic-address-space pointers: flat_load / flat_store instead of ds_read / ds_write)
-        constexpr size_t aligned = (ChoiLds<NQ>::bytes() + 15) & ~(size_t)15;
+        constexpr size_t aligned = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
         p += aligned;
         Rb = (double*)p; p += sizeof(double) * D * D;
         Tupd = (double*)p; p += sizeof(double) * (S > D ? S : D) * D;
-        Test = (double*)p; p += sizeof(double) * S * D;
-        Cl = (double*)p; p += sizeof(double) * D * S;
-        Ln = (double*)p; p += sizeof(double) * 2 * ((m + 63) / 64) * 64;
+        if constexpr (LEAN) { Test = Tupd; Cl = nullptr; Ln = nullptr; }
+        else {
+            Test = (double*)p; p += sizeof(double) * S * D;
+            Cl = (double*)p; p += sizeof(double) * D * S;
+            Ln = (double*)p; p += sizeof(double) * 2 * ((m + 63) / 64) * 64;
+        }
     }
 };
 
@@ -99,23 +110,28 @@ __device__ void predict_table(const double* Rb, const double* Ct, double* T, int
     }
 }
 
-template <int NQ, int MAXJ>
-__global__ void __launch_bounds__(64)
-pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
-            const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
-            double* __restrict__ choi_out, int* __restrict__ iters_out,
-            int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-            double* __restrict__ cost_out, int* __restrict__ work_out,
-            long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
+template <int NQ, int MAXJ, bool LEAN>
+__device__ __forceinline__ void
+pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restrict__ expect,
+          const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
+          double* __restrict__ choi_out, int* __restrict__ iters_out,
+          int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
+          double* __restrict__ cost_out, int* __restrict__ work_out,
+          long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
     const int m = des.m, S = des.S;
-    PgdbLds<NQ> L;
+    PgdbLds<NQ, LEAN> L;
     L.carve(smem, S, 64 * MAXJ);
 
-    for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
+    // Bloch coefficients, one state per row: an LDS copy, or (LEAN) the design's own table through L2
+    const double* Ct;
+    if constexpr (LEAN) Ct = des.Ct;
+    else {
+        for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
+        Ct = L.Cl;
+    }
 
     // ---- data: n+-[k] = counts * (1 +- e)/2 / grand_total   (tomography.py:528-538)
     double tot = 0.0;
@@ -134,14 +150,29 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             }
         }
         tot = uniform(wave_sum(tot));
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
+            for (int j = 0; j < MAXJ; ++j) {
+                L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
+            }
         }
     }
     FBX_WAVE_SYNC();
-#define NPL(j) (L.Ln[(2 * (j)) * 64 + lane])
-#define NMI(j) (L.Ln[(2 * (j) + 1) * 64 + lane])
+    // normalised counts of slot j: from LDS, or (LEAN) recomputed from the inputs with the same expressions
+    auto counts_of = [&](int j, double& np_, double& nm_) __attribute__((always_inline)) {
+        if constexpr (LEAN) {
+            const int g = lane + 64 * j;
+            np_ = 0.0; nm_ = 0.0;
+            if (g < m) {
+                const int k = des.order[g];
+                const double e = expect[item * m + k], c = counts[item * m + k];
+                const double plus = (1.0 + e) / 2.0;
+                np_ = (c * plus) / tot; nm_ = (c * (1.0 - plus)) / tot;
+            }
+        } else {
+            np_ = L.Ln[(2 * j) * 64 + lane]; nm_ = L.Ln[(2 * j + 1) * 64 + lane];
+        }
+    };
 
     const double half_dd = 0.5 / (double)(d * d);      // 1 / (2 d^2)
     const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
@@ -185,7 +216,9 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 double pp = fma(alpha, pup[j], pep[j]), pm = fma(alpha, pum[j], pem[j]);
                 pp = pp < PGDB_EPS ? PGDB_EPS : pp;
                 pm = pm < PGDB_EPS ? PGDB_EPS : pm;
-                acc -= NPL(j) * fast_log_pos(pp) + NMI(j) * fast_log_pos(pm);
+                double np_, nm_;
+                counts_of(j, np_, nm_);
+                acc -= np_ * fast_log_pos(pp) + nm_ * fast_log_pos(pm);
             }
         }
         return uniform(wave_sum(acc));
@@ -227,7 +260,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
         FBX_WAVE_SYNC();
         PH_STOP(pc, 3);
-        predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
+        predict_table<NQ>(L.Rb, Ct, L.Test, S, lane);
         FBX_WAVE_SYNC();
         PH_STOP(pc, 7);
         load_probs(L.Test, pep, pem, 1.0);
@@ -246,7 +279,9 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             if (g < m) {
                 const double pp = pep[j] < PGDB_EPS ? PGDB_EPS : pep[j];
                 const double pm = pem[j] < PGDB_EPS ? PGDB_EPS : pem[j];
-                const double ep = NPL(j) / pp, em = NMI(j) / pm;
+                double np_, nm_;
+                counts_of(j, np_, nm_);
+                const double ep = np_ / pp, em = nm_ / pm;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
                 const int st = spw[j] >> 16, p = spw[j] & 0xffff;
                 atomicAdd(&Wt[st * D], 0.5 * (ep + em));
@@ -267,7 +302,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 for (int st = 0; st < S; ++st) {
                     const double w = Wt[st * D + i];
 #pragma unroll
-                    for (int r = 0; r < JB; ++r) acc[r] = fma(w, L.Cl[st * D + j0 + r], acc[r]);
+                    for (int r = 0; r < JB; ++r) acc[r] = fma(w, Ct[st * D + j0 + r], acc[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < JB; ++r) L.Rb[(j0 + r) * D + i] = -acc[r] / (double)(d * d);
@@ -309,15 +344,28 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
         ipr = uniform(wave_sum(ipr));
         PH_STOP(pc, 2);
 
-        // ---- prediction table of the update direction
+        // ---- prediction tables for the line search
+        if constexpr (LEAN) {
+            // one table buffer: the estimate's table was overwritten by the gradient weights -- rebuilt here
+            // (one more transform + table product per outer iteration, ~1 % of it) and read, before the
+            // update direction's takes its place
+            FBX_WAVE_SYNC();
+            blk_store<D, LD>(L.choi.Mw, lane, est);
+            FBX_WAVE_SYNC();
+            choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
+            FBX_WAVE_SYNC();
+            predict_table<NQ>(L.Rb, Ct, L.Test, S, lane);
+            FBX_WAVE_SYNC();
+            load_probs(L.Test, pep, pem, 1.0);
+        }
         FBX_WAVE_SYNC();
         blk_store<D, LD>(L.choi.Mw, lane, upd);
         FBX_WAVE_SYNC();
         choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
         FBX_WAVE_SYNC();
-        predict_table<NQ>(L.Rb, L.Cl, L.Tupd, S, lane);
+        predict_table<NQ>(L.Rb, Ct, L.Tupd, S, lane);
         FBX_WAVE_SYNC();
-        load_probs(L.Test, pep, pem, 1.0);      // again: not kept in registers across the projection
+        if constexpr (!LEAN) load_probs(L.Test, pep, pem, 1.0);      // again: not kept in registers across the projection
         load_probs(L.Tupd, pup, pum, 0.0);
         PH_STOP(pc, 3);
         // ---- backtracking line search (tomography.py:575-585)
@@ -366,7 +414,9 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
                     if (near_clip & ((1u + sg) << (2 * j))) {
-                        const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? NMI(j) : NPL(j);
+                        double np_, nm_;
+                        counts_of(j, np_, nm_);
+                        const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? nm_ : np_;
                         const bool f = exact(pu, pe);
                         const unsigned long long mk = __ballot(f);
                         const int pos = n_clip + __popcll(mk & below);
@@ -409,10 +459,12 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                 for (int k = 0; k < NS; ++k) Sk[k] = 0.0;
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) {
+                    double np_, nm_;
+                    counts_of(j, np_, nm_);
 #pragma unroll
                     for (int sg = 0; sg < 2; ++sg) {
                         const double x = sg ? ratio(pum[j], pem[j]) : ratio(pup[j], pep[j]);   // recomputed: not kept live
-                        double t = (sg ? NMI(j) : NPL(j)) * x;
+                        double t = (sg ? nm_ : np_) * x;
 #pragma unroll
                         for (int k = 0; k < NS; ++k) { Sk[k] += t; t *= x; }
                     }
@@ -506,6 +558,38 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 #endif
 }
 
+// The product kernel: one wavefront per SIMD (up to 512 registers, 39 KB of LDS) -- the fastest form while
+// there are no more reconstructions in flight than SIMDs (B <= 1024 on 256 CUs).
+template <int NQ, int MAXJ>
+__global__ void __launch_bounds__(64)
+pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
+            const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
+            double* __restrict__ choi_out, int* __restrict__ iters_out,
+            int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
+            double* __restrict__ cost_out, int* __restrict__ work_out,
+            long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    pgdb_body<NQ, MAXJ, false>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+                               dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap);
+}
+
+// The same reconstruction with the lean LDS layout (16.5 KB) and at most 256 registers: TWO wavefronts per
+// SIMD, i.e. two dependent Jacobi chains interleaved on every SIMD -- for batches that put more than one
+// reconstruction on a SIMD anyway (BASELINE configs[4]: 8192 per GPU).  Results are bit-identical to
+// pgdb_kernel's (same arithmetic; only where operands are kept differs).
+template <int NQ, int MAXJ>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
+                 const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
+                 double* __restrict__ choi_out, int* __restrict__ iters_out,
+                 int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
+                 double* __restrict__ cost_out, int* __restrict__ work_out,
+                 long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    pgdb_body<NQ, MAXJ, true>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+                              dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap);
+}
+
 #ifdef FBX_DIAGNOSTICS
 __global__ void debug_log_kernel(const double* x, double* out, long long n) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -526,12 +610,16 @@ template <int NQ, int MAXJ>
 static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                        int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
                        double* cost, int32_t* sw) {
-    const size_t lds = PgdbLds<NQ>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
+    // batches that put several reconstructions on a SIMD take the lean two-waves-per-SIMD kernel (2 qubits)
+    const bool lean = NQ == 2 && B >= FBX_LEAN_MIN_BATCH;
+    size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
+    if constexpr (NQ == 2) { if (lean) lds = PgdbLds<NQ, true>::bytes(des->dev.S, 64 * MAXJ); }
     if (lds > 160 * 1024) {
         set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
         return FBX_ERR_UNSUPPORTED;
     }
     auto kern = pgdb_kernel<NQ, MAXJ>;
+    if constexpr (NQ == 2) { if (lean) kern = pgdb_lean_kernel<NQ, MAXJ>; }
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each = 128 KiB per 2-qubit
     // item, at most 1 GiB): a grow-only workspace of the calling thread (released by

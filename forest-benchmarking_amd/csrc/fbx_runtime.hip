@@ -399,12 +399,16 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
         if (des->coef_host[g] != 1.0) unit = 0;
     }
 
-    // one slab: C | coef | order | sp | sptr
-    size_t oC = 0, oCoef = oC + sizeof(double) * D * S, oOrder = oCoef + sizeof(double) * m;
+    // one slab: C | Ct | coef | order | sp | sptr
+    size_t oC = 0, oCt = oC + sizeof(double) * D * S, oCoef = oCt + sizeof(double) * D * S, oOrder = oCoef + sizeof(double) * m;
     size_t oSp = oOrder + sizeof(int) * m, oPtr = oSp + sizeof(uint32_t) * m;
     size_t total = oPtr + sizeof(int) * (S + 1);
     std::vector<char> host(total);
     memcpy(&host[oC], des->C_host.data(), sizeof(double) * D * S);
+    {
+        double* ct = reinterpret_cast<double*>(&host[oCt]);
+        for (int j = 0; j < D; ++j) for (int s = 0; s < S; ++s) ct[(size_t)s * D + j] = des->C_host[(size_t)j * S + s];
+    }
     memcpy(&host[oCoef], des->coef_host.data(), sizeof(double) * m);
     memcpy(&host[oOrder], order.data(), sizeof(int) * m);
     memcpy(&host[oSp], des->sp_host.data(), sizeof(uint32_t) * m);
@@ -420,6 +424,7 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
     des->dev.n = n; des->dev.kind = kind; des->dev.m = m; des->dev.S = S; des->dev.d = d;
     des->dev.D = D; des->dev.unit_coefs = unit;
     des->dev.C = (const double*)(base + oC);
+    des->dev.Ct = (const double*)(base + oCt);
     des->dev.coef = (const double*)(base + oCoef);
     des->dev.order = (const int*)(base + oOrder);
     des->dev.sp = (const uint32_t*)(base + oSp);

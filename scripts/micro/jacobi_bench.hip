@@ -11,8 +11,8 @@ using namespace fbx;
 template <int N>
 __global__ void __launch_bounds__(64) k_eigh(const double* A, double* W, double* Vout, long long* cyc, int* sw, int reps) {
     constexpr int LD = N + 1;
-    __shared__ cplx M[N * N];
-    __shared__ cplx V[N * N];
+    __shared__ cplx M[sys_elems<N>()];
+    __shared__ cplx V[sys_elems<N>()];
     __shared__ JRec rot[N];
     const int lane = threadIdx.x, item = blockIdx.x;
     long long total = 0; int sweeps = 0;
@@ -111,8 +111,8 @@ __device__ int jacobi_eigh_2w(cplx* Ms, cplx* Vs, volatile int* flag, int tid, b
 
 template <int N>
 __global__ void __launch_bounds__(128) k_eigh2w(const double* A, double* W, double* Vout, long long* cyc, int* sw, int reps, int* simd) {
-    __shared__ cplx M[N * N];
-    __shared__ cplx V[N * N];
+    __shared__ cplx M[sys_elems<N>()];
+    __shared__ cplx V[sys_elems<N>()];
     __shared__ int flag;
     const int tid = threadIdx.x, item = blockIdx.x;
     if ((tid & 63) == 0) simd[item * 2 + (tid >> 6)] = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);

@@ -7,7 +7,7 @@ from fbx import synthetic, _lib
 _lib.set_device(0)
 lib = _lib.lib()
 ms = ctypes.c_double()
-for B in (1024, 8192):
+for B in (1024, 2048, 4096, 8192, 16384):
     design, _, e, c = synthetic.process_batch(2, 'pauli', min(B, 4096))
     if B > 4096:
         e = np.tile(e, (B // 4096, 1)); c = np.tile(c, (B // 4096, 1))

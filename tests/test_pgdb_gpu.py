@@ -216,3 +216,21 @@ def test_config5_shard_size_properties(gpu):
     for k in range(1, 8):
         assert np.array_equal(got[:1024], got[1024 * k:1024 * (k + 1)])
         assert np.array_equal(st["dykstra"][:1024], st["dykstra"][1024 * k:1024 * (k + 1)])
+
+
+@pytest.mark.parametrize("basis", ["pauli", "sic"])
+def test_lean_two_waves_per_simd_kernel_is_bit_identical(gpu, basis):
+    """Batches of >= 2048 two-qubit reconstructions run pgdb_lean_kernel (16.5 KB of LDS, <= 256 registers,
+    two wavefronts per SIMD): same arithmetic, different operand placement -- every output
+    and every counter must equal the one-wave-per-SIMD kernel's bit for bit, in both modes and for the
+    trace-non-increasing projection."""
+    from fbx import synthetic, tomography
+    design, _, e, c = synthetic.process_batch(2, basis, 128)
+    reps = 2048 // 128
+    eb, cb = np.tile(e, (reps, 1)), np.tile(c, (reps, 1))
+    for kw in (dict(mode="converge"), dict(mode="fixed", max_iters=60), dict(mode="converge", trace_preserving=False)):
+        small, ss = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, **kw)
+        big, sb = tomography.pgdb_process_estimate_batch(design, eb, cb, return_stats=True, **kw)
+        assert np.array_equal(big[:128], small) and np.array_equal(big[-128:], small)
+        for key in ("iterations", "dykstra", "backtracks", "cost", "jacobi_sweeps", "eig_terms", "cost_evals"):
+            assert np.array_equal(sb[key][:128], ss[key]), key
