@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--in-basis", default=None, choices=["pauli", "sic"],
                     help="input-state basis of the process design (default: pauli for pgdb, sic for pgdb3)")
-    ap.add_argument("--cpu-sample", type=int, default=12,
+    ap.add_argument("--cpu-sample", type=int, default=6,
                     help="items run through the oracle for cpu_baseline and the parity self-check (0 = skip)")
     ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "pgdb3"],
                     help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "

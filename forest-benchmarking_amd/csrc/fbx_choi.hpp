@@ -225,6 +225,8 @@ struct BasisStore {
     int cap;          // slots
     int nprev;        // slots that hold a basis of the previous call
     bool use_prev;    // outer step small: prefer the previous call's basis over the previous iteration's
+    bool write_all;   // the next call is expected to want every slot (outer step within a small factor of the
+                      // use_prev threshold): otherwise only slot 0 -- which every call starts from -- is written back
     // one basis in flight from HBM to registers (single-wavefront kernels, D <= 16: 16 B per lane and u)
     cplx pf[4];
     int pf_slot = -1; // slot the registers hold / are waiting for, -1: none
@@ -282,10 +284,11 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, i
         if (FBX_WARM_START && have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
             store->template prefetch<DD>(it + 1, lane);
         const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm, from_slot);
-        if (FBX_WARM_START && have_store && it < store->cap) {
-            // every basis is written back (4 KB per decomposition, ~2 GB per 1024-item launch = 1 % of
-            // the HBM bandwidth): writing only the slots the next call is predicted to use measured
-            // 2 % slower, the first small step then finds part of its trajectory without a basis
+        if (FBX_WARM_START && have_store && it < store->cap && (it == 0 || store->write_all)) {
+            // Write-back of the basis (4 KB per decomposition).  Slot j > 0 is only read by a call whose outer
+            // step is below FBX_BASIS_STEP, and the outer step shrinks by ~1.2x per iteration: the slots are
+            // written from FBX_BASIS_WRITE_STEP (30x the threshold; 4x and 10x measured 1.3 % slower at B = 1024, 30x is free) on -- before that only
+            // slot 0.  (Writing every basis of every call was 0.9 GB of write-back per 1024-item launch.)
             if (!(from_slot && sweeps == sweeps_before)) {       // no sweep on the slot's own basis: nothing changed
                 fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * DD);
 #pragma unroll
@@ -316,7 +319,11 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, i
         if (!(crit >= 1e-4)) { ++it; break; }        // converged -- or not finite (NaN input): never spin
         old_cp = new_cp; old_tp = new_tp; last_cp = cp; last_state = new_state;
     }
-    if (have_store) { store->nprev = it < store->cap ? it : store->cap; store->pf_slot = -1; }
+    if (have_store) {
+        const int written = store->write_all ? it : 1;           // slots of this call that hold a basis now
+        store->nprev = written < store->cap ? written : store->cap;
+        store->pf_slot = -1;
+    }
     return new_state;
 }
 

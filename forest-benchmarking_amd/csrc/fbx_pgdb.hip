@@ -25,6 +25,9 @@
 #ifndef FBX_BASIS_STEP
 #define FBX_BASIS_STEP 1e-3
 #endif
+#ifndef FBX_BASIS_WRITE_STEP
+#define FBX_BASIS_WRITE_STEP 3e-2     // outer step below which every Dykstra basis is written back (fbx_choi.hpp BasisStore)
+#endif
 #ifndef FBX_DBG_NOVALID
 #define FBX_DBG_NOVALID 0
 #endif
@@ -237,7 +240,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
     // eigenvector bases of the previous outer iteration's Dykstra run (fbx_choi.hpp BasisStore)
     BasisStore basis;
     basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
-    basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false;
+    basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false; basis.write_all = false;
     double outer_step = 1.0;                       // alpha * ||update||_F of the previous outer iteration
     PhaseClock pc; pc.reset(); L.choi.pc = &pc;
     PH_START(pc);
@@ -327,6 +330,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
         // below a step of 1e-3 the previous run's trajectory is closer to this one than consecutive
         // Dykstra iterates are to each other (those stop at ~1e-2)
         basis.use_prev = outer_step < FBX_BASIS_STEP;
+        basis.write_all = outer_step < FBX_BASIS_WRITE_STEP;
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
 #ifdef FBX_NO_VFIRST
                                                nullptr);

@@ -244,7 +244,7 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
             warm = true;
         }
         const Blk cp = proj_cp(pre_cp, L, t, sweeps, warm, Tg, from_slot);
-        if (store && it < store->cap) {
+        if (store && it < store->cap && (it == 0 || store->write_all)) {      // write-back policy: BasisStore, fbx_choi.hpp
             fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const cplx v = L.Vs[e * NT + t]; dst[e * NT + t] = fbx_v2d{v.re, v.im}; }
@@ -269,7 +269,10 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         const double crit = s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
         if (!(crit >= 1e-4)) { ++it; break; }        // converged -- or not finite (NaN input): never spin
     }
-    if (store) store->nprev = it < store->cap ? it : store->cap;
+    if (store) {
+        const int written = store->write_all ? it : 1;
+        store->nprev = written < store->cap ? written : store->cap;
+    }
     return new_state;
 }
 
@@ -435,7 +438,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
     bool have_cost = false;
     BasisStore basis;
     basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
-    basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false;
+    basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false; basis.write_all = false;
     double outer_step = 1.0;
 
     PH_START(pc);
@@ -512,6 +515,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         const Blk x = blk_axpy(est, -inv_mu, grad);
         if ((iters & 15) == 0) basis.nprev = 0;       // bounds the accumulated loss of unitarity
         basis.use_prev = outer_step < 1e-3;
+        basis.write_all = outer_step < 3e-2;
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch,
                                        basis.g ? &basis : nullptr);

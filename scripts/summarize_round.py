@@ -15,23 +15,27 @@ def short(name):
 
 
 lines = []
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    lines.append(f"# {os.path.relpath(f, out)}")
-    lines += [l.rstrip() for l in open(f)]
-    open(os.path.join(dst, "rocprofv3_kernel_stats.csv"), "w").write(open(f).read())
-trace = glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)
-if trace:
-    byk = {}
-    for r in csv.DictReader(open(trace[0])):
-        byk.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r))
-    lines.append("# per-kernel dispatch summary from kernel_trace.csv")
-    for k, v in byk.items():
-        ds = [x[0] for x in v]
-        r = v[0][1]
-        lines.append(f"{k[:110]}: calls={len(ds)} avg_ms={sum(ds)/len(ds)/1e6:.3f} min_ms={min(ds)/1e6:.3f} "
-                     f"max_ms={max(ds)/1e6:.3f} grid={r.get('Grid_Size','?')} wg={r.get('Workgroup_Size','?')} "
-                     f"lds={r.get('LDS_Block_Size','?')} vgpr={r.get('VGPR_Count','?')} accum_vgpr={r.get('Accum_VGPR_Count','?')} "
-                     f"sgpr={r.get('SGPR_Count','?')} scratch={r.get('Scratch_Size', r.get('Private_Segment_Size','?'))}")
+for wl in ("pgdb", "sweep", "pgdb3"):
+    for f in glob.glob(os.path.join(out, f"trace_{wl}", "**", "*kernel_stats.csv"), recursive=True):
+        lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --cpu-sample 0 --steps 5 --warmup 1")
+        lines += [l.rstrip() for l in open(f)]
+        open(os.path.join(dst, f"{wl}_rocprofv3_kernel_stats.csv"), "w").write(open(f).read())
+    for f in glob.glob(os.path.join(out, f"trace_{wl}", "**", "*kernel_trace.csv"), recursive=True):
+        byk = {}
+        for r in csv.DictReader(open(f)):
+            byk.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r))
+        lines.append(f"# per-kernel dispatch summary ({wl})")
+        for k, v in byk.items():
+            ds = [x[0] for x in v]
+            r = v[0][1]
+            lines.append(f"{k[:110]}: calls={len(ds)} avg_ms={sum(ds)/len(ds)/1e6:.3f} min_ms={min(ds)/1e6:.3f} "
+                         f"max_ms={max(ds)/1e6:.3f} lds={r.get('LDS_Block_Size','?')} vgpr={r.get('VGPR_Count','?')} "
+                         f"accum_vgpr={r.get('Accum_VGPR_Count','?')} sgpr={r.get('SGPR_Count','?')} scratch={r.get('Scratch_Size', r.get('Private_Segment_Size','?'))}")
+    p = os.path.join(out, f"bench_trace_{wl}.log")
+    if os.path.exists(p):
+        js = [l for l in open(p) if l.startswith("{")]
+        if js:
+            open(os.path.join(dst, f"bench_{wl}_line_under_rocprof.json"), "w").write(js[-1])
 open(os.path.join(dst, "kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
 
 pmc = {}
@@ -59,11 +63,13 @@ for k, cs in pmc.items():
         e["lds_bank_conflict_over_lds_active"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
     summary["kernels"][k] = e
 json.dump(summary, open(os.path.join(dst, "pmc_counters.json"), "w"), indent=1)
-for name in ("bench_trace.log",):
-    p = os.path.join(out, name)
-    if os.path.exists(p):
-        js = [l for l in open(p) if l.startswith("{")]
-        if js:
-            open(os.path.join(dst, "bench_line_under_rocprof.json"), "w").write(js[-1])
+traffic = {"tag": tag, "note": "FETCH_SIZE(KiB) x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section) + "
+                                "WRITE_SIZE(KiB) x 1024; separate --pmc passes; per launch of the bench workload"}
+for k, key in (("pgdb", "pgdb_kernel_hbm_bytes_per_launch"), ("sweep", "sweep_kernel_hbm_bytes_per_launch"), ("pgdb3", "pgdb3_kernel_hbm_bytes_per_launch")):
+    if k in summary["kernels"] and "hbm_bytes_per_launch" in summary["kernels"][k]:
+        traffic[key] = summary["kernels"][k]["hbm_bytes_per_launch"]
+        traffic[k + "_FETCH_SIZE_KiB"] = summary["kernels"][k]["FETCH_SIZE"]["mean"]
+        traffic[k + "_WRITE_SIZE_KiB"] = summary["kernels"][k]["WRITE_SIZE"]["mean"]
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, "kernel_stats.txt")).read()[:4000])
 print(json.dumps(summary, indent=1)[:6000])
