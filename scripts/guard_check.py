@@ -5,14 +5,13 @@ import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
     os.environ["FBX_LIBRARY"] = os.path.join(ROOT, "forest-benchmarking_amd", sys.argv[1])
-    if sys.argv[1] != "libfbx.so": os.environ["FBX_DEBUG_SWEEPS"] = "1"
     sys.path.insert(0, os.path.join(ROOT, 'forest-benchmarking_amd'))
     import numpy as np
     from fbx import synthetic, tomography, _lib
     _lib.set_device(0)
     design, us, e, c = synthetic.process_batch(2, 'pauli', 256)
     choi, st = tomography.pgdb_process_estimate_batch(design, e, c, mode='converge', return_stats=True)
-    np.savez(sys.argv[2], choi=choi, dyk=st['dykstra'], it=st['iterations'], bt=st['backtracks'])
+    np.savez(sys.argv[2], choi=choi, dyk=st['dykstra'], it=st['iterations'], bt=st['jacobi_sweeps'])
 else:
     import numpy as np
     for lib, f in (("libfbx.so", "/tmp/p.npz"), ("libfbx_cor.so", "/tmp/q.npz")):

@@ -1,5 +1,4 @@
 import sys, os
-os.environ["FBX_DEBUG_SWEEPS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'forest-benchmarking_amd'))
 import numpy as np
@@ -10,9 +9,9 @@ for mode, mi in (('fixed', 100), ('converge', 0)):
     choi, st = tomography.pgdb_process_estimate_batch(design, e, c, mode=mode, max_iters=mi, return_stats=True)
     k = int(st['dykstra'].argmax())
     order = np.argsort(-st['dykstra'])[:6]
-    print(mode, 'top items', order, 'dyk', st['dykstra'][order], 'iters', st['iterations'][order], 'sweeps', st['backtracks'][order],
-          'sweeps/eigh', (st['backtracks'][order] / st['dykstra'][order]).round(2))
-    print('  median dyk', np.median(st['dykstra']), 'median sweeps/eigh', np.median(st['backtracks'] / st['dykstra']).round(2))
+    print(mode, 'top items', order, 'dyk', st['dykstra'][order], 'iters', st['iterations'][order], 'sweeps', st['jacobi_sweeps'][order],
+          'sweeps/eigh', (st['jacobi_sweeps'][order] / st['dykstra'][order]).round(2))
+    print('  median dyk', np.median(st['dykstra']), 'median sweeps/eigh', np.median(st['jacobi_sweeps'] / st['dykstra']).round(2))
     u = us[k]
     ev = np.linalg.eigvals(u)
     print('  outlier', k, 'unitary eigenphases', np.sort(np.angle(ev)).round(3), 'min |e|', np.abs(e[k]).min().round(4), 'max |e|', np.abs(e[k]).max().round(4),

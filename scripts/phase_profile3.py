@@ -2,7 +2,6 @@
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["FBX_LIBRARY"] = os.path.join(ROOT, "forest-benchmarking_amd", "libfbx_prof.so")
-os.environ["FBX_DEBUG_SWEEPS"] = "1"
 sys.path.insert(0, os.path.join(ROOT, 'forest-benchmarking_amd'))
 import numpy as np
 from fbx import synthetic, tomography, _lib
@@ -27,7 +26,7 @@ print('3q', basis, 'B', B, mode, 'time %.1f ms' % (1e3 * dt), 'recon/s %.0f' % (
 print('cycles/item mean %.3e max %.3e' % (tot.mean(), tot.max()))
 for i, n in enumerate(names):
     print('  %-14s mean %.3e (%.1f%%)' % (n, ph[:, i].mean(), 100 * ph[:, i].sum() / tot.sum()))
-sweeps = st['backtracks']          # FBX_DEBUG_SWEEPS: the backtrack slot carries the sweep count
+sweeps = st['jacobi_sweeps']
 print('dykstra iters mean %.1f; sweeps per eigh %.2f; jacobi cycles per eigh %.0f, per round %.0f; warm rotate per eigh %.0f' % (
     st['dykstra'].mean(), sweeps.sum() / st['dykstra'].sum(), ph[:, 0].sum() / st['dykstra'].sum(),
     ph[:, 0].sum() / (sweeps.sum() * 63.0), ph[:, 6].sum() / st['dykstra'].sum()))

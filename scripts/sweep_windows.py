@@ -1,6 +1,5 @@
-"""Jacobi sweeps per eigendecomposition in windows of 10 outer iterations (diagnostic, FBX_DEBUG_SWEEPS)."""
+"""Jacobi sweeps per eigendecomposition in windows of 10 outer iterations (diagnostic)."""
 import sys, os
-os.environ["FBX_DEBUG_SWEEPS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'forest-benchmarking_amd'))
 import numpy as np
@@ -12,7 +11,7 @@ conv = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True)[1
 print('converged at (first 8 items):', conv[:8], 'median', np.median(conv))
 for K in range(10, 101, 10):
     st = tomography.pgdb_process_estimate_batch(design, e, c, mode='fixed', max_iters=K, return_stats=True)[1]
-    s, d = st['backtracks'].astype(float), st['dykstra'].astype(float)
+    s, d = st['jacobi_sweeps'].astype(float), st['dykstra'].astype(float)
     w = (s - prev_s) / np.maximum(d - prev_d, 1)
     print('iters %3d-%3d: dykstra/iter %.1f  sweeps/eigh median %.2f  (items 0..5: %s)' % (K - 10, K, np.median(d - prev_d) / 10, np.median(w), np.round(w[:6], 2)))
     prev_s, prev_d = s, d
