@@ -428,7 +428,8 @@ def pgdb_roofline(batch, st, kernel_s, iters):
     return {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
             "traffic": _profiled("pgdb_kernel_hbm_bytes_per_launch") if B == 1024 else None,
-            "kernel": "pgdb_kernel<2,9>" if m > 256 else "pgdb_kernel<2,4>", "kernel_ms": 1e3 * kernel_s,
+            "kernel": ("pgdb_lean_kernel" if B >= 2048 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>"),
+            "kernel_ms": 1e3 * kernel_s,
             "executed_flop": ex, "executed_tflops": B * ex / kernel_s / 1e12,
             "executed_frac": B * ex / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
             "executed_breakdown": {k: round(v) for k, v in parts.items()},

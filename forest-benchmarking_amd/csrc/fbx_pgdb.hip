@@ -120,7 +120,8 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
           double* __restrict__ choi_out, int* __restrict__ iters_out,
           int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
           double* __restrict__ cost_out, int* __restrict__ work_out,
-          long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
+          long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
+          double* __restrict__ ncounts) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
@@ -158,12 +159,23 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
             for (int j = 0; j < MAXJ; ++j) {
                 L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
             }
+        } else if (ncounts) {
+            // LEAN: the same table in the item's slice of an L2-resident workspace (lane-contiguous rows)
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                ncounts[(2 * j) * 64 + lane] = npl[j] / tot; ncounts[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
+            }
         }
     }
     FBX_WAVE_SYNC();
-    // normalised counts of slot j: from LDS, or (LEAN) recomputed from the inputs with the same expressions
+    // normalised counts of slot j: from LDS; LEAN: from the L2 workspace (written above by this very lane, so
+    // program order is all the ordering needed), or recomputed from the inputs with the same expressions
     auto counts_of = [&](int j, double& np_, double& nm_) __attribute__((always_inline)) {
         if constexpr (LEAN) {
+            if (ncounts) {
+                np_ = ncounts[(2 * j) * 64 + lane]; nm_ = ncounts[(2 * j + 1) * 64 + lane];
+                return;
+            }
             const int g = lane + 64 * j;
             np_ = 0.0; nm_ = 0.0;
             if (g < m) {
@@ -571,10 +583,12 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             double* __restrict__ choi_out, int* __restrict__ iters_out,
             int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
             double* __restrict__ cost_out, int* __restrict__ work_out,
-            long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
+            long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
+            double* __restrict__ ncounts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)ncounts;
     pgdb_body<NQ, MAXJ, false>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
-                               dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap);
+                               dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, nullptr);
 }
 
 // The same reconstruction with the lean LDS layout (16.5 KB) and at most 256 registers: TWO wavefronts per
@@ -588,10 +602,12 @@ pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                  double* __restrict__ choi_out, int* __restrict__ iters_out,
                  int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
                  double* __restrict__ cost_out, int* __restrict__ work_out,
-                 long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap) {
+                 long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
+                 double* __restrict__ ncounts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     pgdb_body<NQ, MAXJ, true>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
-                              dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap);
+                              dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
+                              ncounts ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr);
 }
 
 #ifdef FBX_DIAGNOSTICS
@@ -633,11 +649,22 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     constexpr int64_t CHUNK = 8192;
     const int64_t in_flight = B < CHUNK ? B : CHUNK;
     cplx* basis = nullptr;
-    if (!(mode == FBX_MODE_FIXED && max_iters <= 1) && !(mode == FBX_MODE_CONVERGE && max_iters == 1)) {
-        void* w = nullptr;
-        const int rc = workspace(WS_PGDB_BASIS, sizeof(cplx) * D * D * BASIS_CAP * (size_t)in_flight, &w);
-        if (rc) return rc;
-        basis = (cplx*)w;
+    double* ncounts = nullptr;
+    {
+        // one workspace: [basis store | normalised counts of the lean kernel (2 x MAXJ x 64 doubles per item)]
+        const bool want_basis = !(mode == FBX_MODE_FIXED && max_iters <= 1) && !(mode == FBX_MODE_CONVERGE && max_iters == 1);
+        const size_t basis_bytes = want_basis ? sizeof(cplx) * D * D * BASIS_CAP * (size_t)in_flight : 0;
+        const size_t counts_bytes = lean ? sizeof(double) * 2 * MAXJ * 64 * (size_t)in_flight : 0;
+        if (basis_bytes + counts_bytes) {
+            void* w = nullptr;
+            const int rc = workspace(WS_PGDB_BASIS, basis_bytes + counts_bytes, &w);
+            if (rc) return rc;
+            if (want_basis) basis = (cplx*)w;
+            if (lean) ncounts = (double*)((char*)w + basis_bytes);
+        }
+#ifdef FBX_LEAN_RECOUNT      // experiment: the lean kernel recomputes the counts from the inputs at every use
+        ncounts = nullptr;
+#endif
     }
     const size_t m = des->dev.m;
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
@@ -646,7 +673,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2,
                            it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr,
                            cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr,
-                           FBX_PHASE_OUT(b0), basis, BASIS_CAP);
+                           FBX_PHASE_OUT(b0), basis, BASIS_CAP, ncounts);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
