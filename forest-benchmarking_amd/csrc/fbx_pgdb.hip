@@ -16,6 +16,9 @@
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
 #include "fbx_choi.hpp"
 #include <cstdlib>
+#ifndef FBX_LEAN_CL_LDS
+#define FBX_LEAN_CL_LDS 0           // experiment: the lean kernel keeps its own LDS copy of the Bloch matrix (7 instead of 8 waves per CU)
+#endif
 #ifndef FBX_LEAN_MIN_BATCH
 #define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
 #endif
@@ -64,7 +67,7 @@ struct PgdbLds {
         constexpr int D = ChoiLds<NQ>::D;
         const size_t Su = S > D ? S : D;
         const size_t base = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
-        if (LEAN) return base + sizeof(double) * ((size_t)D * D + Su * D) + 64;
+        if (LEAN) return base + sizeof(double) * ((size_t)D * D + Su * D + (FBX_LEAN_CL_LDS ? (size_t)S * D : 0)) + 64;
         return base + sizeof(double) * ((size_t)D * D + (Su + 2 * (size_t)S) * D + 2 * (size_t)((m + 63) / 64) * 64) + 64;
     }
     // every pointer is a plain offset from the start of the dynamic LDS segment (no conditional
@@ -79,7 +82,7 @@ struct PgdbLds {
         p += aligned;
         Rb = (double*)p; p += sizeof(double) * D * D;
         Tupd = (double*)p; p += sizeof(double) * (S > D ? S : D) * D;
-        if constexpr (LEAN) { Test = Tupd; Cl = nullptr; Ln = nullptr; }
+        if constexpr (LEAN) { Test = Tupd; Cl = FBX_LEAN_CL_LDS ? (double*)p : nullptr; Ln = nullptr; }
         else {
             Test = (double*)p; p += sizeof(double) * S * D;
             Cl = (double*)p; p += sizeof(double) * D * S;
@@ -131,7 +134,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
 
     // Bloch coefficients, one state per row: an LDS copy, or (LEAN) the design's own table through L2
     const double* Ct;
-    if constexpr (LEAN) Ct = des.Ct;
+    if constexpr (LEAN && !FBX_LEAN_CL_LDS) Ct = des.Ct;
     else {
         for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
         Ct = L.Cl;
