@@ -471,7 +471,21 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
             for (int k = NS - 2; k >= 0; --k) q = fma(alpha, q, Sk[k]);
             return alpha * q;
         };
+        // The acceptance test of tomography.py:578 is `new_cost > old_cost + change`.  In the small-step regime the
+        // cost DIFFERENCE is known exactly (the series), and the test is made on it: `new - old > change`.  The
+        // two forms differ only where |new - old| and |change| are below the rounding of the cost itself -- the
+        // stalled iterations past convergence, where the projection's inexactness makes the direction an
+        // ASCENT direction (new - old = alpha <update, gradient> > change > 0 for every alpha): there the
+        // reference's rounded test is decided by the noise of its cost sums (it ends up halving 47-50 times
+        // per iteration), the rounded test on an exact difference would accept as soon as both
+        // sides vanish against the cost (~11 halvings, a 3e-8 step along an ascent direction, every stalled
+        // iteration), and the exact test rejects down to alpha < 1e-15 like the reference's late iterations:
+        // the estimate then stays where the reference's stays, to rounding.  -DFBX_LS_ROUNDED restores the
+        // rounded form (round-1 behaviour).
+        bool ls_exact = false;
+        double ls_diff = 0.0;
         auto cost_step = [&](double alpha) __attribute__((always_inline)) -> double {
+            ls_exact = false;
             if (!small_regime(alpha)) { ++ls_full; return cost_at(alpha); }
             if (!have_sums) {
 #pragma unroll
@@ -495,10 +509,17 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
             double acc = series(alpha);
             if (near_clip)                   // the listed outcomes: exact difference of clipped logs
                 acc += uniform(wave_sum(clip_n * clipped_log(fma(alpha, clip_pu, clip_pe)) - clip_base));
+#ifndef FBX_LS_ROUNDED
+            ls_exact = true; ls_diff = -acc;
+#endif
             return old_cost - acc;
+        };
+        auto rejected = [&](double change_) __attribute__((always_inline)) -> bool {
+            return ls_exact ? (ls_diff > change_) : (new_cost > old_cost + change_);
         };
 #else
         auto cost_step = [&](double alpha) -> double { ++ls_full; return cost_at(alpha); };
+        auto rejected = [&](double change_) -> bool { return new_cost > old_cost + change_; };
 #endif
         double alpha = 1.0;
         new_cost = cost_step(alpha);
@@ -506,7 +527,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
 #ifndef FBX_NO_SMALL_STEP
         int small_fails = 0;
 #endif
-        while (new_cost > old_cost + change) {
+        while (rejected(change)) {
 #ifndef FBX_NO_SMALL_STEP
             // Two series evaluations in a row have failed: this is one of the long halving runs of a
             // stalled iteration.  The rest of the ladder alpha 2^-L, L = 1, 2, ... is evaluated in ONE pass,
@@ -524,7 +545,12 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
                     }
                 }
                 const double val = old_cost - acc;
-                const unsigned long long stop = __ballot(lane >= 1 && (a_l < PGDB_ALPHA_MIN || !(val > old_cost + c_l)));
+#ifndef FBX_LS_ROUNDED
+                const bool rej_l = -acc > c_l;
+#else
+                const bool rej_l = val > old_cost + c_l;
+#endif
+                const unsigned long long stop = __ballot(lane >= 1 && (a_l < PGDB_ALPHA_MIN || !rej_l));
                 const int Ls = __builtin_ctzll(stop);          // alpha <= 1: lane 50 is below the floor at the latest
                 alpha = __builtin_ldexp(alpha, -Ls); change = __builtin_ldexp(change, -Ls);
                 new_cost = uniform(__shfl(val, Ls));

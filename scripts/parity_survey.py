@@ -1,0 +1,18 @@
+"""Parity survey on the first 256 bench items (2 qubits, Pauli in-basis) against oracle results computed ahead
+(scripts/cache/oracle_pauli.npz: produced in the build container by running the oracle, scripts/make_parity_cache.py).
+Prints the deviation distribution of the Choi matrices and the count mismatches, both modes, for FBX_LIBRARY."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "forest-benchmarking_amd"))
+import numpy as np
+from fbx import synthetic, tomography, _lib
+_lib.set_device(0)
+z = np.load(os.path.join(ROOT, "scripts", "cache", "oracle_pauli.npz"))
+N = z["fixed"].shape[0]
+design, us, e, c = synthetic.process_batch(2, "pauli", N)
+for mode, key, kw in (("fixed-100", "fixed", dict(mode="fixed", max_iters=100)), ("converge", "conv", {})):
+    got, st = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, **kw)
+    d = np.abs(got - z[key]).reshape(N, -1).max(axis=1)
+    print(f"{os.path.basename(os.environ.get('FBX_LIBRARY', 'libfbx.so')):20s} {mode:9s} max {d.max():.1e}  >1e-9: {(d > 1e-9).sum()}  >1e-10: {(d > 1e-10).sum()}  >1e-8: {(d > 1e-8).sum()}  "
+          f"dykstra mismatches {(st['dykstra'] != z[key + '_dyk']).sum()}  halving-count mismatches {(st['backtracks'] != z[key + '_bt']).sum()}"
+          + (f"  iteration mismatches {(st['iterations'] != z['conv_it']).sum()}" if key == "conv" else ""))

@@ -64,16 +64,18 @@ def test_pgdb_fixed_100_matches_oracle(gpu, n, basis):
                                                      return_stats=True)
     want, wst = _oracle_pgdb(design, e, c, mode="fixed", max_iters=100)
     assert (st["iterations"] == 100).all()
-    # The fixed mode keeps iterating past convergence (an extension: the reference stops there).
-    # Those iterations are *stalled*: the inexact Dykstra projection gives an ascent direction, the
-    # step is halved ~50 times and the accepted alpha is decided by cost differences at rounding
-    # level, so the estimate moves by alpha * update ~ 1e-7 in a summation-order dependent way.
-    # Outer-iteration and Dykstra counts still agree exactly; the Choi matrices to ~1e-7.
-    assert np.abs(got - want).max() < 2e-6
+    # The fixed mode keeps iterating past convergence (an extension: the reference stops there).  Those
+    # iterations are *stalled*: the inexact Dykstra projection gives an ASCENT direction, the reference halves the
+    # step until the rounding noise of its cost sums lets a step pass (3e-8, 4e-9, ... then < 1e-11), the kernel
+    # -- which knows the cost difference exactly -- rejects every step down to alpha < 1e-15.  The
+    # two estimates differ by the reference's first few noise-accepted steps: <= 1.1e-7 over 256 bench items
+    # (scripts/parity_survey.py), against <= 3e-9 between two summation orders of the reference itself.
+    # Outer-iteration and Dykstra counts agree exactly.
+    assert np.abs(got - want).max() < 5e-7
     for b in range(3):
         assert st["dykstra"][b] == wst[b]["dykstra"]
         assert abs(_process_fidelity_to_truth(got[b], us[b])
-                   - _process_fidelity_to_truth(want[b], us[b])) < 1e-6
+                   - _process_fidelity_to_truth(want[b], us[b])) < 2e-7
 
 
 def test_pgdb_trace_non_increasing(gpu):
