@@ -32,6 +32,7 @@ def build(force=False, verbose=True, profile=False):
     flags = list(FLAGS)
     tag = ""
     if profile:
+        flags += os.environ.get("FBX_PROFILE_FLAGS", "").split()
         out = os.path.join(HERE, "libfbx_prof.so")
         flags += ["-DFBX_PHASE_TIMERS", "-DFBX_DIAGNOSTICS"]
         tag = ".prof"

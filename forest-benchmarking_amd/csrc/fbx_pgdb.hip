@@ -22,8 +22,8 @@
 #ifndef FBX_LEAN_MIN_BATCH
 #define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
 #endif
-#ifndef FBX_BASIS_RESET_MASK
-#define FBX_BASIS_RESET_MASK 15
+#ifndef FBX_BASIS_CHAIN_SWEEPS
+#define FBX_BASIS_CHAIN_SWEEPS 54   // Jacobi sweeps a chain of stored bases may accumulate (per slot, on average) before a cold restart
 #endif
 #ifndef FBX_BASIS_STEP
 #define FBX_BASIS_STEP 1e-3
@@ -256,6 +256,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
     BasisStore basis;
     basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
     basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false; basis.write_all = false;
+    int chain_start = 0;                           // value of `sweeps` at the last cold start of the stored bases
     double outer_step = 1.0;                       // alpha * ||update||_F of the previous outer iteration
     PhaseClock pc; pc.reset(); L.choi.pc = &pc;
     PH_START(pc);
@@ -264,10 +265,21 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
 
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
-        // the cross-iteration bases are dropped every 16 iterations to bound the accumulated loss of
-        // unitarity (~1e-16 per rotation); the first basis of this iteration's projection is requested
-        // now, so that it arrives behind the gradient
+        // A stored basis is the product of all rotations applied to its chain since the last cold start, and every
+        // rotation costs ~1e-16 of unitarity: the chains are dropped once they have absorbed FBX_BASIS_CHAIN_SWEEPS
+        // sweeps per slot (= what 16 converging iterations apply; round 1 dropped them every 16 iterations whatever
+        // had happened, i.e. also in the stalled iterations, whose frozen decompositions apply no rotation at all --
+        // four pointless cold restarts per fixed-100 reconstruction).  The first basis of this iteration's
+        // projection is requested now, so that it arrives behind the gradient.
+#ifdef FBX_BASIS_RESET_MASK      // round-1 rule, for A/B builds: every (MASK + 1) iterations
         if ((iters & FBX_BASIS_RESET_MASK) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
+        (void)chain_start;
+#else
+        if (iters == 0 || FBX_DBG_NOVALID ||
+            sweeps - chain_start >= FBX_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) {
+            basis.nprev = 0; chain_start = sweeps;
+        }
+#endif
 #ifndef FBX_NO_VFIRST
         if (basis.g && basis.nprev > 0 && FBX_WARM_START) basis.template prefetch<D * D>(0, lane);
 #endif

@@ -433,7 +433,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
 
     Blk est = blk_zero();
     { const int I = t / NB, J = t % NB; if (I == J) { est.re[0] = 1.0 / d; est.re[3] = 1.0 / d; } }
-    int iters = 0, dyk = 0, backtracks = 0, sweeps = 0, cost_evals = 0;
+    int iters = 0, dyk = 0, backtracks = 0, sweeps = 0, cost_evals = 0, chain_start = 0;
     double old_cost = 0.0, new_cost = 0.0;
     bool have_cost = false;
     BasisStore basis;
@@ -513,7 +513,9 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         PH_STOP(pc, 3);
 
         const Blk x = blk_axpy(est, -inv_mu, grad);
-        if ((iters & 15) == 0) basis.nprev = 0;       // bounds the accumulated loss of unitarity
+        // bounds the accumulated loss of unitarity of the chained bases: a cold restart once the chains have
+        // absorbed 54 sweeps per slot (what 16 converging iterations apply; see fbx_pgdb.hip)
+        if (iters == 0 || sweeps - chain_start >= 54 * (basis.nprev > 0 ? basis.nprev : 1)) { basis.nprev = 0; chain_start = sweeps; }
         basis.use_prev = outer_step < 1e-3;
         basis.write_all = outer_step < 3e-2;
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
