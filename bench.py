@@ -67,6 +67,8 @@ def parse():
                     help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "
                          "sweep / pgdb3 = that workload as the primary line")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
+    ap.add_argument("--spawn-timeout", type=float, default=1800.0,
+                    help="seconds the self-spawned ranks (--gpus > 1 without a launcher) may take before they are killed")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing: allow more ranks than visible GPUs (ranks share devices; host-file barrier)")
     return ap.parse_args()
@@ -86,8 +88,17 @@ def spawn_ranks(args):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank stuck in a collective (RCCL bootstrap waiting for a peer that died) must not hang the job
+    deadline = time.monotonic() + args.spawn_timeout
+    try:
+        out, _ = procs[0].communicate(timeout=args.spawn_timeout)
+        codes = [procs[0].returncode] + [p.wait(timeout=max(deadline - time.monotonic(), 1.0)) for p in procs[1:]]
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                            # exactly the processes started above
+        sys.exit(f"bench.py: ranks did not finish within {args.spawn_timeout:.0f} s "
+                 f"(exit codes so far {[p.poll() for p in procs]})")
     sys.stdout.write(out)
     sys.stdout.flush()
     try:

@@ -14,6 +14,7 @@ No torch here: the communicator lives in libfbx.so.  A communicator object only 
 the same partition / gather code through a gloo-backed stand-in (tests/test_distributed_gloo.py).
 """
 import os
+import threading
 import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -227,10 +228,24 @@ def init_from_env(allow_host_fallback: bool = False, allow_oversubscribe: bool =
     failure = err.decode() if err else None
     comm = None
     if failure is None and (ndev >= world or not allow_host_fallback):
-        try:
-            comm = RcclComm(rank, world, ident)
-        except Exception as exc:
-            failure = str(exc)
+        # ncclCommInitRank is a collective: it blocks for as long as a peer is missing.  It runs in a
+        # helper thread so that a rank whose peer died reports a failure instead of hanging the job.
+        box: dict = {}
+
+        def _init():
+            try:
+                box["comm"] = RcclComm(rank, world, ident)
+            except Exception as exc:                         # noqa: BLE001 -- reported below
+                box["error"] = str(exc)
+
+        limit = float(os.environ.get("FBX_RCCL_INIT_TIMEOUT", "180"))
+        worker = threading.Thread(target=_init, name="fbx-rccl-init", daemon=True)
+        worker.start()
+        worker.join(limit)
+        if worker.is_alive():
+            failure = f"ncclCommInitRank did not return within {limit:.0f} s"
+        else:
+            comm, failure = box.get("comm"), box.get("error")
     elif failure is None:
         failure = f"{world} ranks share {ndev} GPU(s): RCCL needs one GPU per rank"
     # all ranks must agree on the transport
