@@ -23,7 +23,7 @@
 #define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
 #endif
 #ifndef FBX_BASIS_CHAIN_SWEEPS
-#define FBX_BASIS_CHAIN_SWEEPS 54   // Jacobi sweeps a chain of stored bases may accumulate (per slot, on average) before a cold restart
+#define FBX_BASIS_CHAIN_SWEEPS 216  // Jacobi sweeps a chain of stored bases may accumulate (per slot, on average) before a cold restart
 #endif
 #ifndef FBX_BASIS_STEP
 #define FBX_BASIS_STEP 1e-3
@@ -267,9 +267,10 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
         // A stored basis is the product of all rotations applied to its chain since the last cold start, and every
         // rotation costs ~1e-16 of unitarity: the chains are dropped once they have absorbed FBX_BASIS_CHAIN_SWEEPS
-        // sweeps per slot (= what 16 converging iterations apply; round 1 dropped them every 16 iterations whatever
-        // had happened, i.e. also in the stalled iterations, whose frozen decompositions apply no rotation at all --
-        // four pointless cold restarts per fixed-100 reconstruction).  The first basis of this iteration's
+        // sweeps per slot (216 sweeps x 120 rotations: < 3e-12 even if every rounding error had the same sign; the
+        // norm test of the warm start discards anything beyond 1e-9 anyway.  Round 1 dropped them every 16
+        // iterations whatever had happened, i.e. also in the stalled iterations, whose frozen decompositions apply
+        // no rotation at all, and a cold restart costs ~10 sweeps more than a warm projection).  The first basis of this iteration's
         // projection is requested now, so that it arrives behind the gradient.
 #ifdef FBX_BASIS_RESET_MASK      // round-1 rule, for A/B builds: every (MASK + 1) iterations
         if ((iters & FBX_BASIS_RESET_MASK) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;

@@ -21,6 +21,9 @@ extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
 #else
 #define FBX_PHASE_OUT3(b0) ((long long*)nullptr)
 #endif
+#ifndef FBX3_BASIS_CHAIN_SWEEPS
+#define FBX3_BASIS_CHAIN_SWEEPS 216   // as FBX_BASIS_CHAIN_SWEEPS of the 2-qubit kernel (fbx_pgdb.hip)
+#endif
 
 namespace p3 {
 constexpr int NQ = 3, d = 8, D = 64, NB = 32, NT = 1024, LD = 64, LDs = d + 1;
@@ -515,7 +518,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         const Blk x = blk_axpy(est, -inv_mu, grad);
         // bounds the accumulated loss of unitarity of the chained bases: a cold restart once the chains have
         // absorbed 54 sweeps per slot (what 16 converging iterations apply; see fbx_pgdb.hip)
-        if (iters == 0 || sweeps - chain_start >= 54 * (basis.nprev > 0 ? basis.nprev : 1)) { basis.nprev = 0; chain_start = sweeps; }
+        if (iters == 0 || sweeps - chain_start >= FBX3_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) { basis.nprev = 0; chain_start = sweeps; }
         basis.use_prev = outer_step < 1e-3;
         basis.write_all = outer_step < 3e-2;
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
