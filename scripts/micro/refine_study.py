@@ -63,6 +63,14 @@ def refine(H, V, kappa):
     return V @ W, ok.sum() / (N * N - N)
 
 
+VARIANTS = ("plain", "same-slot", "best-of-two")
+
+
+def off_of(H, V):
+    M = V.conj().T @ H @ V
+    return np.sum(np.abs(M - np.diag(np.diag(M))) ** 2)
+
+
 def main():
     items = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     kappa = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
@@ -70,7 +78,7 @@ def main():
     odesign = process_design(2, "pauli")
     A = estimators.design_matrix_A(odesign)
     tot = dict(plain=0, refined=0, refine_calls=0, decomp=0, frozen=0, unit=0.0)
-    hist_plain, hist_ref = np.zeros(12, int), np.zeros(12, int)
+    hists, byit = {}, {}
     for b in range(items):
         log = []                     # (outer iteration, slot, H)
         state = dict(it=-1, slot=0)
@@ -94,7 +102,7 @@ def main():
             superops.proj_choi_to_completely_positive = real_cp
             estimators.proj_choi_to_physical = real_phys
         # replay
-        for variant in ("plain", "refined"):
+        for variant in VARIANTS:
             store = {}
             prev_first = None
             for it, slot, H in log:
@@ -102,7 +110,16 @@ def main():
                     step = np.inf if prev_first is None else np.linalg.norm(H - prev_first)
                     prev_first = H
                     use_prev = step < 1e-3
-                if use_prev and slot in store:
+                cands = []
+                if slot in store:
+                    cands.append(store[slot])
+                if slot > 0 and (slot - 1) in store:
+                    cands.append(store[slot - 1])
+                if variant == "same-slot":
+                    V = cands[0] if cands else None
+                elif variant == "best-of-two":
+                    V = min(cands, key=lambda X: off_of(H, X)) if cands else None
+                elif use_prev and slot in store:
                     V = store[slot]
                 elif slot > 0 and (slot - 1) in store:
                     V = store[slot - 1]
@@ -122,17 +139,18 @@ def main():
                         M0 = V.conj().T @ H @ V
                     sw, M, V2 = jacobi_sweeps(M0, V)
                 store[slot] = V2
-                tot[variant] += sw
-                (hist_plain if variant == "plain" else hist_ref)[min(sw, 11)] += 1
+                tot[variant] = tot.get(variant, 0) + sw
+                hists.setdefault(variant, np.zeros(12, int))[min(sw, 11)] += 1
+                byit.setdefault(variant, np.zeros(100))[it] += sw
                 if variant == "plain":
                     tot["decomp"] += 1
-                else:
+                if variant == "refined":
                     tot["unit"] = max(tot["unit"], np.linalg.norm(V2.conj().T @ V2 - np.eye(N)))
         print(f"item {b}: decompositions {len(log)} dykstra {st['dykstra']}", flush=True)
-    print(f"items {items} kappa {kappa}: decompositions {tot['decomp']}  sweeps plain {tot['plain']}  "
-          f"refined {tot['refined']} (+{tot['refine_calls']} refinements)  max ||V'V - 1|| {tot['unit']:.1e}")
-    print("sweeps histogram plain  :", hist_plain)
-    print("sweeps histogram refined:", hist_ref)
+    print(f"items {items} kappa {kappa}: decompositions {tot['decomp']}  refinements {tot['refine_calls']}  max ||V'V - 1|| {tot['unit']:.1e}")
+    for v in VARIANTS:
+        print(f"{v:12s} sweeps {tot[v]:6d}  histogram {hists[v]}")
+        print("   sweeps per outer iteration (x10 iterations):", byit[v].reshape(10, 10).sum(1).astype(int))
 
 
 if __name__ == "__main__":
