@@ -655,6 +655,41 @@ int check_state_design(const fbx_design* des, const char* who) {
 }
 }  // namespace
 
+
+// ---- Pauli-Liouville vector of a state: c2p vec(rho) = tr[P_k rho] / d, k in the order of
+// itertools.product('IXYZ', repeat=n) (first letter = most significant qubit), the input of
+// plotting/state_process.py:10-87 (computational2pauli_basis_matrix, superoperator_transformations.py:413-424).
+// One thread per coefficient: P_k has one non-zero per row, P_k[i][i ^ x] = prod_q (I, X: 1; Y: -i / +i for row
+// bit 0 / 1; Z: +1 / -1), so tr[P_k rho] = sum_i P_k[i][i ^ x] rho[i ^ x][i].
+__global__ void __launch_bounds__(256)
+pauli_vector_kernel(int n, long long total, const double* __restrict__ rho, double* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int d = 1 << n, DD = d * d;
+    const long long item = gid / DD;
+    const int k = (int)(gid % DD);
+    int x = 0, z = 0, ny = 0;                   // X/Y positions, Z/Y positions, number of Y
+    for (int q = 0; q < n; ++q) {
+        const int op = (k >> (2 * (n - 1 - q))) & 3, bit = 1 << (n - 1 - q);
+        if (op == 1 || op == 2) x |= bit;
+        if (op == 2 || op == 3) z |= bit;
+        ny += op == 2;
+    }
+    const double* r = rho + item * (long long)DD * 2;
+    double re = 0.0, im = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const int j = i ^ x;
+        // Y on row bit b contributes -i (b = 0) or +i (b = 1) = -i * (-1)^b; Z contributes (-1)^b
+        const double sgn = (__popc(i & z) & 1) ? -1.0 : 1.0;
+        const double vr = r[2 * (j * d + i)], vi = r[2 * (j * d + i) + 1];
+        re += sgn * vr; im += sgn * vi;
+    }
+    // times (-i)^ny
+    double o;
+    switch (ny & 3) { case 0: o = re; break; case 1: o = im; break; case 2: o = -re; break; default: o = -im; }
+    out[gid] = o / d;
+}
+
 extern "C" {
 
 // Every estimator / measure below comes as a device-pointer form (`_dev`: checks + launch on the library
@@ -906,6 +941,30 @@ int fbx_state_measures(int n_qubits, int64_t B, const double* rho, const double*
     FBX_TRY(fbx_state_measures_dev(n_qubits, B, dr, ds, dp, df, dt, dh));
     FBX_TRY(io.back(purity_out, dp, (size_t)B)); FBX_TRY(io.back(fidelity_out, df, (size_t)B));
     FBX_TRY(io.back(trace_dist_out, dt, (size_t)B)); FBX_TRY(io.back(hs_ip_out, dh, (size_t)B));
+    return io.sync();
+}
+
+int fbx_pauli_vector_dev(int n_qubits, int64_t B, const double* d_rho, double* d_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 5, "fbx_pauli_vector: n_qubits must be 1..5");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_rho && d_out)), "fbx_pauli_vector: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const long long total = (long long)B << (2 * n_qubits);
+    hipLaunchKernelGGL(pauli_vector_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(), n_qubits, total, d_rho, d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_pauli_vector(int n_qubits, int64_t B, const double* rho, double* out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 5, "fbx_pauli_vector: n_qubits must be 1..5");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (rho && out)), "fbx_pauli_vector: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t DD = (size_t)1 << (2 * n_qubits);
+    HostIO io; double *dr, *dout;
+    FBX_TRY(io.in(rho, DD * 2 * B, &dr)); FBX_TRY(io.out(DD * B, &dout));
+    FBX_TRY(fbx_pauli_vector_dev(n_qubits, B, dr, dout));
+    FBX_TRY(io.back(out, dout, DD * B));
     return io.sync();
 }
 

@@ -103,6 +103,8 @@ PROTOTYPES = {
     "fbx_apply_choi_dev": [C.c_int, _i64, _vp, _vp, _vp],
     "fbx_state_measures_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "fbx_eigh_dev": [C.c_int, _i64, _vp, _vp, _vp],
+    "fbx_pauli_vector": [C.c_int, _i64, _dp, _dp],
+    "fbx_pauli_vector_dev": [C.c_int, _i64, _vp, _vp],
     "fbx_random_operators": [C.c_int, C.c_int, C.c_int, _i64, C.c_uint64, _i64, _dp],
     "fbx_random_operators_dev": [C.c_int, C.c_int, C.c_int, _i64, C.c_uint64, _i64, _vp],
     "fbx_random_kraus": [C.c_int, _i64, C.c_int, C.c_uint64, _i64, _dp],

@@ -257,6 +257,15 @@ int fbx_state_measures_dev(int n_qubits, int64_t B, const double* d_rho, const d
                            double* d_purity_out, double* d_fidelity_out,
                            double* d_trace_dist_out, double* d_hs_ip_out);
 
+/* ---------------------------------------------------------------- plot inputs
+ * Pauli-Liouville vector of a state, the input of plotting/state_process.py:10-87:
+ * out[b][k] = (computational2pauli_basis_matrix(2 n) vec(rho_b))[k] = tr[P_k rho_b] / d (real part), P_k in the
+ * order of n_qubit_pauli_basis(n).labels (utils.py:398-409; itertools.product('IXYZ', repeat=n)).
+ * rho is [B][d][d] complex, out [B][d^2] real; n_qubits 1..5.  (The Pauli transfer matrix that
+ * plot_pauli_transfer_matrix (:90) draws is fbx_convert(FBX_REP_CHOI -> FBX_REP_PAULI_LIOUVILLE).) */
+int fbx_pauli_vector(int n_qubits, int64_t B, const double* rho, double* out);
+int fbx_pauli_vector_dev(int n_qubits, int64_t B, const double* d_rho, double* d_out);
+
 /* ---------------------------------------------------------------- shots -> moments
  * shots_to_obs_moments (observable_estimation.py:804-853), the reduction immediately before the
  * estimators: for each of n_settings settings, bits[s] is a [n_shots][n_qubits] array of 0/1 bytes

@@ -67,3 +67,24 @@ def test_shard_bounds_cover_everything_once():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+def test_hinton_geometry_follows_the_reference_formulas():
+    """plotting/hinton.py:12-36 (size, colour angle, automatic max_weight) and :52-118 (sign class, capped area,
+    max_weight from the diagonal); values worked by hand."""
+    from fbx import plotting
+    m = np.array([[0.5, complex(0.0, -0.25)], [complex(0.0, 0.25), 3.0]])
+    g = plotting.hinton_plot_inputs(m, max_weight=None)
+    assert g["max_weight"] == 4.0                                   # next power of two above 3
+    assert np.allclose(g["size"], np.sqrt(np.abs(m) / 4.0))
+    assert np.allclose(g["angle"], [[np.pi / 2, np.pi], [0.0, np.pi / 2]])     # arctan2(re, im)
+    assert g["xlim"] == (-2.0, 0.0) and plotting.hinton_plot_inputs(m)["max_weight"] == 1.0
+    r = plotting.hinton_real_plot_inputs(np.array([[0.4, -0.1], [0.0, 0.2]]))
+    assert r["max_weight"] == 0.5 and r["ticks"] == [-0.25, 0, 0.25]
+    assert np.array_equal(r["sign"], [[1, -1], [-1, 1]])            # zero is drawn with the negative colour
+    assert np.allclose(r["area"], [[0.8, 0.2], [0.0, 0.4]])
+    assert plotting.hinton_real_plot_inputs(np.zeros((2, 2)))["max_weight"] == 1.0
+    assert plotting.hinton_real_plot_inputs(np.eye(2), max_weight=0.5)["area"].max() == 1.0
+    assert plotting.pauli_labels(2)[:6] == ["II", "IX", "IY", "IZ", "XI", "XX"]
+    with pytest.raises(ValueError):
+        plotting.pauli_labels(0)
