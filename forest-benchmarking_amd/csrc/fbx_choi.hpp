@@ -37,6 +37,7 @@ struct ChoiLds {
     cplx* ptV;     // [d * d]    its eigenvectors (TNI only)
     PhaseClock* pc = nullptr;   // diagnostics (FBX_PHASE_TIMERS builds)
     int terms = 0;              // work accounting: eigenvalue terms rebuilt by the CP projections (wave-uniform)
+    double jtol2 = FBX_JACOBI_TOL2;   // off-norm^2 / norm^2 at which the CP projections' eigensolver stops
     static constexpr size_t bytes() {
         static_assert(!LEAN || 2 * sys_elems<D>() >= D * LD, "the transforms' staging matrix must fit into Ms + Vs");
         return sizeof(cplx) * ((LEAN ? 0 : D * LD) + 2 * sys_elems<D>() + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
@@ -94,7 +95,7 @@ __device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool wa
     int sw;
 #ifndef FBX_JACOBI_NO_PIPELINE
     if constexpr (D == 16) {
-        sw = jacobi_eigh_wave<D>(L.Ms, L.Vs, lane, !warm, hn2);
+        sw = jacobi_eigh_wave<D>(L.Ms, L.Vs, lane, !warm, hn2, L.jtol2);
     } else
 #endif
     {

@@ -270,7 +270,7 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 #ifndef FBX_JACOBI_NO_PIPELINE
 template <int N>
 __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
-                                double expect_n2 = -1.0) {
+                                double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(LS == 64, "every lane of the wavefront owns one 2x2 block");
     const int I = lane / NB, J = lane % NB;
@@ -315,7 +315,7 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
             // expect_n2 >= 0: the matrix was brought into a basis loaded from memory; a unitary similarity
             // keeps ||.||_F^2 (here to FBX_BASIS_NORM_TOL), a damaged basis does not -> tell the caller (-1)
             if (sweep == 0 && expect_n2 >= 0.0 && !(fabs(n2 - expect_n2) <= FBX_BASIS_NORM_TOL * expect_n2)) return -1;
-            if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
+            if (!(o2 > tol2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
             const double aJ = Ms[0 * PS + dJ].re, dJ_ = Ms[3 * PS + dJ].re;
@@ -348,11 +348,11 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
 
 template <int N, int NT = 64>
 __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true,
-                                  double* red = nullptr) {
+                                  double* red = nullptr, double tol2 = FBX_JACOBI_TOL2) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(LS <= NT, "one lane per 2x2 block");
 #ifndef FBX_JACOBI_NO_PIPELINE
-    if constexpr (NT <= 64 && N == 16) { (void)red; return jacobi_eigh_wave<N>(Ms, Vs, lane, init_identity); }
+    if constexpr (NT <= 64 && N == 16) { (void)red; return jacobi_eigh_wave<N>(Ms, Vs, lane, init_identity, -1.0, tol2); }
 #endif
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
@@ -389,7 +389,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             if (!act) { o2 = 0.0; n2 = 0.0; }
             block_sum2<NT>(o2, n2, red);
             o2 = uniform(o2); n2 = uniform(n2);
-            if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
+            if (!(o2 > tol2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
 #ifdef FBX_JACOBI_TWO_CHAINS

@@ -21,6 +21,9 @@ extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
 #else
 #define FBX_PHASE_OUT3(b0) ((long long*)nullptr)
 #endif
+#ifndef FBX3_JTOL_REL
+#define FBX3_JTOL_REL 1e-8
+#endif
 #ifndef FBX3_BASIS_CHAIN_SWEEPS
 #define FBX3_BASIS_CHAIN_SWEEPS 216   // as FBX_BASIS_CHAIN_SWEEPS of the 2-qubit kernel (fbx_pgdb.hip)
 #endif
@@ -39,6 +42,7 @@ struct Lds {
     cplx* pt; cplx* pts; cplx* ptV; double* lam; double* red;
     PhaseClock* pc;  // diagnostics (-DFBX_PHASE_TIMERS)
     int terms = 0;   // work accounting: eigenvalue terms rebuilt by the CP projections
+    double jtol2 = FBX_JACOBI_TOL2;   // eigensolver tolerance of the CP projections (see fbx_pgdb.hip, FBX_JTOL_REL)
     __device__ void carve(char* p) {
         Ms = (cplx*)p; Vs = Ms + D * D; Mw = Vs; T = (double*)p;
         Rt = (double*)(p + 2 * sizeof(cplx) * D * D);
@@ -153,7 +157,7 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
         }
     }
     PH_STOP(*L.pc, 6);
-    sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, !warm, L.red);
+    sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, !warm, L.red, L.jtol2);
     PH_STOP(*L.pc, 0);
     if (t < D) {
         const double l = L.Ms[sys_index<D>(t, t)].re;
@@ -521,6 +525,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         if (iters == 0 || sweeps - chain_start >= FBX3_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) { basis.nprev = 0; chain_start = sweeps; }
         basis.use_prev = outer_step < 1e-3;
         basis.write_all = outer_step < 3e-2;
+        { const double tr_ = FBX3_JTOL_REL * outer_step; L.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }   // as in fbx_pgdb.hip
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch,
                                        basis.g ? &basis : nullptr);
