@@ -123,6 +123,58 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
     __syncthreads();
 }
 
+// The same change of basis on the fp64 matrix cores: wavefront w owns the 16 x 16 output tile (w >> 2, w & 3) of
+// each of the two 64^3 complex products, 16 k-steps of four v_mfma_f64_16x16x4_f64 (re.re, -im.im, re.im, im.re).
+// Lane l feeds A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; accumulator r is D[(l >> 4) + 4 r][l & 15].
+// Both A operands are read TRANSPOSED so that the 16 lanes of a group walk along a row of the layout:
+// H[m][k] = conj(H[k][m]) (H is exactly Hermitian: it was just symmetrised) and (V^H)[m][k] = conj(V[k][m]).
+// 2 x 16 x 2 b128 loads and 8 stores per lane instead of 2 x 64 x 4 loads; the products themselves take
+// 128 x 32 cycles per wavefront (the VALU form: 68.7 k cycles per decomposition, this one: see DESIGN.md 2.2).
+#ifndef FBX3_ROTATE_VALU
+__device__ void rotate_into_basis_mfma(Lds& L, int t) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int w = t >> 6, l = t & 63, tm = w >> 2, tn = w & 3, g = l >> 4, c = l & 15;
+    const int colA = 16 * tm + c, colB = 16 * tn + c;
+    v4d tre = {0.0, 0.0, 0.0, 0.0}, tim = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {                   // T = H V
+        const int k = 4 * ks + g;
+        const cplx h = L.Ms[sys_index<D>(k, colA)];     // conj(H[colA][k])
+        const cplx v = L.Vs[sys_index<D>(k, colB)];     // V[k][colB]
+        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(h.re, v.re, tre, 0, 0, 0);
+        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(h.re, v.im, tim, 0, 0, 0);
+        tre = __builtin_amdgcn_mfma_f64_16x16x4f64(h.im, v.im, tre, 0, 0, 0);      // -(-im) im
+        tim = __builtin_amdgcn_mfma_f64_16x16x4f64(-h.im, v.re, tim, 0, 0, 0);
+    }
+    __syncthreads();                                    // H is dead: T takes its place
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cplx o; o.re = tre[r]; o.im = tim[r];
+        L.Ms[sys_index<D>(16 * tm + g + 4 * r, colB)] = o;
+    }
+    __syncthreads();
+    v4d mre = {0.0, 0.0, 0.0, 0.0}, mim = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {                   // M' = V^H T
+        const int k = 4 * ks + g;
+        const cplx v = L.Vs[sys_index<D>(k, colA)];     // conj((V^H)[colA][k])
+        const cplx q = L.Ms[sys_index<D>(k, colB)];     // T[k][colB]
+        mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v.re, q.re, mre, 0, 0, 0);
+        mim = __builtin_amdgcn_mfma_f64_16x16x4f64(v.re, q.im, mim, 0, 0, 0);
+        mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v.im, q.im, mre, 0, 0, 0);
+        mim = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.im, q.re, mim, 0, 0, 0);
+    }
+    __syncthreads();                                    // every wavefront is done reading T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + g + 4 * r;
+        cplx o; o.re = mre[r]; o.im = row == colB ? 0.0 : mim[r];
+        L.Ms[sys_index<D>(row, colB)] = o;
+    }
+    __syncthreads();
+}
+#endif
+
 // ---- CP projection (project_superoperators.py:19-34)
 __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr,
                        bool check_basis = false) {
@@ -143,7 +195,11 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
         // (same guard as proj_cp_blk, fbx_choi.hpp)
         double n2[2] = {0.0, 0.0};
         if (check_basis) n2[0] = blk_norm2(h);
+#ifndef FBX3_ROTATE_VALU
+        (void)Tg; rotate_into_basis_mfma(L, t);
+#else
         rotate_into_basis(L, Tg, t);
+#endif
         if (check_basis) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * NT + t]; n2[1] = fma(v.re, v.re, fma(v.im, v.im, n2[1])); }
