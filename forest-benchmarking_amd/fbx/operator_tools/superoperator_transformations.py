@@ -4,7 +4,8 @@ Mirror of operator_tools/superoperator_transformations.py:33-438.  ``vec`` / ``u
 host-side reshapes exactly as in the reference; every conversion runs in libfbx
 (``fbx_convert``).  ``*_batch`` helpers accept stacked inputs ``[B, ...]``.  Conversions *to*
 Kraus operators are eigenvector-valued (defined only up to phase / degeneracy,
-superoperator_transformations.py:325-336) and are not offered.
+superoperator_transformations.py:325-336): the eigendecomposition runs on the device (``fbx_eigh``),
+the list of operators is assembled on the host with a fixed phase convention (``choi2kraus``).
 """
 from typing import Optional, Tuple
 
@@ -160,12 +161,22 @@ def pauli_liouville2choi(pl_matrix):
 
 def choi2kraus(choi, tol: float = 1e-9):
     """superoperator_transformations.py:325-336: one Kraus operator sqrt(lambda_i) unvec(v_i) per
-    eigenpair of the Choi matrix with |lambda_i| > tol (eigendecomposition on the device; like the
-    reference's, the operators are defined up to the phase of each eigenvector)."""
+    eigenpair of the Choi matrix with |lambda_i| > tol (eigendecomposition on the device).  The operators
+    are defined up to the phase of each eigenvector; the phase is fixed here so that the first non-zero
+    component of every eigenvector is real and positive, which is what LAPACK hands the reference for the
+    operators its tests compare entry by entry (tests/test_superoperator_transformations.py:215-216,
+    IZKraus; probed on Haar unitaries)."""
     choi = np.asarray(choi, dtype=np.complex128)
     w, v = _lib.eigh_batch(choi[None])
-    return [np.lib.scimath.sqrt(ev) * unvec(np.array([evec]).T) for ev, evec in zip(w[0], v[0].T)
-            if abs(ev) > tol]
+    ops = []
+    for ev, evec in zip(w[0], v[0].T):
+        if not abs(ev) > tol:
+            continue
+        big = np.flatnonzero(np.abs(evec) > 1e-12 * np.linalg.norm(evec))
+        if big.size:
+            evec = evec * (abs(evec[big[0]]) / evec[big[0]])
+        ops.append(np.lib.scimath.sqrt(ev) * unvec(np.array([evec]).T))
+    return ops
 
 
 def superop2kraus(superop):
