@@ -6,7 +6,12 @@ reference test (values and thresholds are the reference's; the test bodies are t
                                                  unitary / positive (semi)definite, incl. the ValueErrors and a 3 x 3 matrix
   tests/test_validate_superoperator.py:9-61      Kraus validity, hermiticity / trace preservation / CP (D = 2 and D = 3),
                                                  unital, unitary
-  tests/test_superoperator_transformations.py:117-136,215-224   vec / unvec, Kraus completeness, superop2kraus
+  tests/test_superoperator_transformations.py:117-136,215-224,281-287   vec / unvec, Kraus completeness, superop2kraus,
+                                                 the Choi <-> superoperator reshuffle as an involution
+  tests/test_distance_measures.py:23-46,138-176  purity (dim_renorm, qutrit), QCB of mixed states, Hilbert-Schmidt
+                                                 inner product (Cauchy-Schwarz, linearity)
+  tests/test_random_operators.py:183-441         first / second moments of the Haar unitaries, purity moments of the
+                                                 Ginibre and Bures ensembles, BCSZ maps -- on the DEVICE streams
 """
 import numpy as np
 import pytest
@@ -147,3 +152,92 @@ def test_superop_to_kraus(gpu):
         ops = superop2kraus(amplitude_damping_super(p))
         # eigenvalue order puts the damping operator first; signs are the eigenvectors' (as in the reference)
         assert np.allclose([np.abs(ops[1]), np.abs(ops[0])], amplitude_damping_kraus(p))
+
+
+# ----------------------------------------------------------------------------------------------- more measures
+def test_purity_standard_and_renormalised(gpu):
+    """tests/test_distance_measures.py:23-46, incl. the qutrit."""
+    from fbx import distance_measures as dm
+    r0, r1, r2, r3 = np.diag([1.0, 0]), np.diag([0.9, 0.1]), np.diag([0.5, 0.5]), np.eye(3) / 3
+    assert dm.purity(r0) == 1.0 and np.allclose(dm.purity(r1), 0.82) and dm.purity(r2) == 0.5
+    assert np.isclose(dm.purity(r3), 1 / 3, rtol=0, atol=1e-15)
+    assert dm.purity(r0, dim_renorm=True) == 1.0
+    assert np.allclose(dm.purity(r1, dim_renorm=True), 2 * (0.82 - 0.5))
+    assert dm.purity(r2, dim_renorm=True) == 0.0
+    assert abs(dm.purity(r3, dim_renorm=True)) < 1e-15
+
+
+def test_hilbert_schmidt_ip_cauchy_schwarz_and_linearity(gpu):
+    """tests/test_distance_measures.py:155-176."""
+    from fbx import distance_measures as dm
+    from fbx.operator_tools import haar_rand_unitary
+    ur = haar_rand_unitary(2, np.random.RandomState(7))
+    u = ur + ur.conj().T
+    a, b = np.eye(2), np.eye(2) / 3
+    ip = dm.hilbert_schmidt_ip
+    assert ip(u, u) * ip(a, a) >= abs(ip(a, u)) ** 2 and ip(u, u) * ip(b, b) >= abs(ip(b, u)) ** 2
+    assert np.allclose(0.17 * ip(u, a) + 0.6713 * ip(u, b), ip(u, 0.17 * a + 0.6713 * b))
+
+
+def test_qcb_for_mixed_states(gpu):
+    """tests/test_distance_measures.py:138-149: a 0.9 / 0.1 state against its 90-degree rotation."""
+    from fbx import distance_measures as dm
+    g = np.array([[0.0, -1.0], [1.0, 0.0]])
+    rho = np.diag([0.9, 0.1])
+    qcb, s = dm.quantum_chernoff_bound(rho, g @ rho @ g.T)
+    assert np.allclose(qcb, 0.6)
+
+
+def test_choi_superop_reshuffle_is_an_involution(gpu):
+    """tests/test_superoperator_transformations.py:281-287."""
+    from fbx.operator_tools import choi2superop, kraus2choi, kraus2superop, superop2choi
+    assert np.allclose(choi2superop(choi2superop(np.eye(4))), np.eye(4))
+    assert np.allclose(superop2choi(superop2choi(np.eye(4))), np.eye(4))
+    hc, hs = kraus2choi(H), kraus2superop(H)
+    assert np.allclose(choi2superop(choi2superop(hc)), hc) and np.allclose(superop2choi(superop2choi(hs)), hs)
+
+
+# ----------------------------------------------------------------------------------------------- moments of the streams
+def test_random_unitaries_first_moment(gpu):
+    """tests/test_random_operators.py:183-214 on the DEVICE stream: E[U (x) U^dagger] = SWAP / D
+    (arXiv:0809.3813 p. 2), 200 000 unitaries per dimension instead of 50 000."""
+    from fbx.operator_tools import permute_tensor_factors
+    from fbx.operator_tools.random_operators import haar_rand_unitary_batch
+    for dim in (2, 4):
+        u = haar_rand_unitary_batch(dim, 200_000, seed=21)
+        avg = np.einsum("bij,bkl->ikjl", u, u.conj().transpose(0, 2, 1)).reshape(dim * dim, dim * dim) / u.shape[0]
+        swap = permute_tensor_factors(dim, [1, 0])
+        assert np.linalg.norm(avg - swap / dim) <= 0.02
+
+
+def test_random_unitaries_second_moment(gpu):
+    """tests/test_random_operators.py:218-285 on the device stream: E[U (x) U (x) U^dagger (x) U^dagger] for D = 2,
+    eq. 5.17 of arXiv:0711.1017."""
+    from fbx.operator_tools import permute_tensor_factors
+    from fbx.operator_tools.random_operators import haar_rand_unitary_batch
+    u = haar_rand_unitary_batch(2, 200_000, seed=22)
+    ud = u.conj().transpose(0, 2, 1)
+    var = np.einsum("bai,bcj,bek,bgl->acegijkl", u, u, ud, ud, optimize=True).reshape(16, 16) / u.shape[0]
+    p = {name: permute_tensor_factors(2, perm) for name, perm in
+         (("3412", [2, 3, 0, 1]), ("4321", [3, 2, 1, 0]), ("4312", [3, 2, 0, 1]), ("3421", [2, 3, 1, 0]))}
+    want = (p["3412"] + p["4321"]) / 3 - (p["4312"] + p["3421"]) / 6
+    assert np.allclose(np.around(want, 2), np.around(var.real, 2), atol=0.01)
+
+
+def test_ginibre_and_bures_second_moments(gpu):
+    """tests/test_random_operators.py:352-420 on the device streams: <tr rho^2> = (D + K) / (D K + 1)
+    (Zyczkowski & Sommers 2001, eq. 3.20) and (5 D^2 + 1) / (2 D (D^2 + 2)) (Sommers & Zyczkowski 2004, eq. 3.1)."""
+    from fbx.operator_tools.random_operators import bures_measure_state_matrix_batch, ginibre_state_matrix_batch
+    for dim in (2, 4):
+        rho = ginibre_state_matrix_batch(dim, 2, 20_000, seed=23)
+        assert abs(np.einsum("bij,bji->b", rho, rho).real.mean() - (dim + 2) / (dim * 2 + 1)) < 1e-2
+        rho = bures_measure_state_matrix_batch(dim, 20_000, seed=24)
+        assert abs(np.einsum("bij,bji->b", rho, rho).real.mean() - (5 * dim ** 2 + 1) / (2 * dim * (dim ** 2 + 2))) < 1e-2
+
+
+def test_bcsz_maps_from_the_device_are_cptp(gpu):
+    """tests/test_random_operators.py:425-441 for a batch from the device stream."""
+    from fbx.operator_tools import choi_is_completely_positive, choi_is_trace_preserving
+    from fbx.operator_tools.random_operators import rand_map_with_BCSZ_dist_batch
+    for choi in rand_map_with_BCSZ_dist_batch(2, 2, 10, seed=25):
+        assert choi_is_completely_positive(choi) and choi_is_trace_preserving(choi)
