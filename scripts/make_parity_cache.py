@@ -1,5 +1,7 @@
-"""Oracle results for scripts/parity_survey.py (run in the build container, ~1 min on 8 cores): the first 256 bench
-items (2 qubits, Pauli in-basis), fixed-100 and converge mode, Choi matrices and counters -> scripts/cache/."""
+"""Oracle results for scripts/parity_survey.py (run in the build container, ~1 min per 256 items on 8 cores): N bench
+items from `first` on (2 qubits, Pauli or SIC in-basis, trace preserving or not), fixed-100 and converge mode, Choi
+matrices and counters -> scripts/cache/oracle_<basis>[_tni][_<first>].npz.
+usage: python scripts/make_parity_cache.py [pauli|sic] [N] [first] [tni]"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,16 +10,19 @@ os.environ["OMP_NUM_THREADS"] = "1"
 import numpy as np
 from multiprocessing import Pool
 from fbx import synthetic
-N = 256
-design, us, e, c = synthetic.process_batch(2, "pauli", N)
+BASIS = sys.argv[1] if len(sys.argv) > 1 else "pauli"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+FIRST = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+TP = not (len(sys.argv) > 4 and sys.argv[4] == "tni")
+design, us, e, c = synthetic.process_batch(2, BASIS, N, first_item=FIRST)
 
 
 def work(b):
     from fbx_oracle import design as od, estimators as oe
     d = od.Design(2, "process", design.in_labels, design.paulis, design.coefs)
     A = oe.design_matrix_A(d)
-    x, s = oe.pgdb_process_estimate(d, e[b], c[b], mode="fixed", max_iters=100, A=A, return_stats=True)
-    y, t = oe.pgdb_process_estimate(d, e[b], c[b], A=A, return_stats=True)
+    x, s = oe.pgdb_process_estimate(d, e[b], c[b], trace_preserving=TP, mode="fixed", max_iters=100, A=A, return_stats=True)
+    y, t = oe.pgdb_process_estimate(d, e[b], c[b], trace_preserving=TP, A=A, return_stats=True)
     return x, s["backtracks"], s["dykstra"], y, t["backtracks"], t["dykstra"], t["iterations"]
 
 
@@ -25,8 +30,9 @@ if __name__ == "__main__":
     with Pool(os.cpu_count()) as p:
         res = p.map(work, range(N))
     os.makedirs(os.path.join(ROOT, "scripts", "cache"), exist_ok=True)
-    np.savez(os.path.join(ROOT, "scripts", "cache", "oracle_pauli.npz"),
+    name = "oracle_" + BASIS + ("" if TP else "_tni") + (f"_{FIRST}" if FIRST else "") + ".npz"
+    np.savez(os.path.join(ROOT, "scripts", "cache", name), basis=BASIS, first=FIRST, tp=TP,
              fixed=np.array([r[0] for r in res]), fixed_bt=np.array([r[1] for r in res]), fixed_dyk=np.array([r[2] for r in res]),
              conv=np.array([r[3] for r in res]), conv_bt=np.array([r[4] for r in res]), conv_dyk=np.array([r[5] for r in res]),
              conv_it=np.array([r[6] for r in res]))
-    print("done", N)
+    print("done", name, N)
