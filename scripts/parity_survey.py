@@ -13,7 +13,8 @@ N = z["fixed"].shape[0]
 BASIS = str(z["basis"]) if "basis" in z.files else "pauli"
 FIRST = int(z["first"]) if "first" in z.files else 0
 TP = bool(z["tp"]) if "tp" in z.files else True
-design, us, e, c = synthetic.process_batch(2, BASIS, N, first_item=FIRST)
+NQ = 3 if BASIS.endswith("3") else 2
+design, us, e, c = synthetic.process_batch(NQ, BASIS.rstrip("3"), N, first_item=FIRST)
 for mode, key, kw in (("fixed-100", "fixed", dict(mode="fixed", max_iters=100)), ("converge", "conv", {})):
     got, st = tomography.pgdb_process_estimate_batch(design, e, c, trace_preserving=TP, return_stats=True, **kw)
     d = np.abs(got - z[key]).reshape(N, -1).max(axis=1)
