@@ -89,13 +89,18 @@ def build_variant(name, extra_flags, verbose=True):
     -D flags (e.g. `python build.py --variant nosmall -DFBX_NO_SMALL_STEP`).  Not shipped, not loaded by tests."""
     out = os.path.join(HERE, f"libfbx_{name}.so")
     build(verbose=verbose)
-    src = os.path.join(CSRC, "fbx_pgdb.hip")
-    obj = os.path.join(HERE, "build", f"fbx_pgdb.hip.{name}.o")
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    objs = [obj] + [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if s != src]
+    # FBX_VARIANT_SOURCES=fbx_pgdb3.hip,... recompiles other files with the flags (default: the 2-qubit kernel)
+    names = os.environ.get("FBX_VARIANT_SOURCES", "fbx_pgdb.hip").split(",")
+    srcs = [os.path.join(CSRC, n) for n in names]
+    objs = []
+    for src in srcs:
+        obj = os.path.join(HERE, "build", f"{os.path.basename(src)}.{name}.o")
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    objs += [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if s not in srcs]
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + MAP, "-ldl"] + objs + ["-o", out])
     return out
 

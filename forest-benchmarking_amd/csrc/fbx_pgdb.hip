@@ -25,9 +25,6 @@
 #ifndef FBX_BASIS_CHAIN_SWEEPS
 #define FBX_BASIS_CHAIN_SWEEPS 216  // Jacobi sweeps a chain of stored bases may accumulate (per slot, on average) before a cold restart
 #endif
-#ifndef FBX_JTOL_REL
-#define FBX_JTOL_REL 1e-8          // eigensolver tolerance of the CP projections relative to the outer step (0: always 1e-13)
-#endif
 #ifndef FBX_BASIS_STEP
 #define FBX_BASIS_STEP 1e-3
 #endif
@@ -362,11 +359,11 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
         // Dykstra iterates are to each other (those stop at ~1e-2)
         basis.use_prev = outer_step < FBX_BASIS_STEP;
         // Inexact projections while the iteration is far from its fixed point: the eigensolver of the CP
-        // projections stops at an off-diagonal norm of FBX_JTOL_REL x the previous outer step (relative to
+        // projections stops at an off-diagonal norm of des.eig_rel_tol (default FBX_JTOL_REL; fbx_set_option) x the previous outer step (relative to
         // ||H||_F), never looser than that and never tighter than the 1e-13 it uses everywhere else.  What the
         // reconstruction V diag(M)+ V^H drops is of the size of that off-diagonal part, i.e. 1e-8 of the
         // distance the estimate still moves per iteration (-10 % time, parity survey unchanged).
-        { const double tr_ = FBX_JTOL_REL * outer_step; L.choi.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }
+        { const double tr_ = des.eig_rel_tol * outer_step; L.choi.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }
         basis.write_all = outer_step < FBX_BASIS_WRITE_STEP;
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
 #ifdef FBX_NO_VFIRST
@@ -718,9 +715,11 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
 #endif
     }
     const size_t m = des->dev.m;
+    DesignDev dev = des->dev;
+    dev.eig_rel_tol = option_pgdb_eig_rel_tol(NQ);
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, stream(), des->dev, (long long)nb,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, stream(), dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2,
                            it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr,
                            cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr,

@@ -21,9 +21,6 @@ extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
 #else
 #define FBX_PHASE_OUT3(b0) ((long long*)nullptr)
 #endif
-#ifndef FBX3_JTOL_REL
-#define FBX3_JTOL_REL 1e-8
-#endif
 #ifndef FBX3_BASIS_CHAIN_SWEEPS
 #define FBX3_BASIS_CHAIN_SWEEPS 216   // as FBX_BASIS_CHAIN_SWEEPS of the 2-qubit kernel (fbx_pgdb.hip)
 #endif
@@ -581,7 +578,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         if (iters == 0 || sweeps - chain_start >= FBX3_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) { basis.nprev = 0; chain_start = sweeps; }
         basis.use_prev = outer_step < 1e-3;
         basis.write_all = outer_step < 3e-2;
-        { const double tr_ = FBX3_JTOL_REL * outer_step; L.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }   // as in fbx_pgdb.hip
+        { const double tr_ = des.eig_rel_tol * outer_step; L.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }   // as in fbx_pgdb.hip
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch,
                                        basis.g ? &basis : nullptr);
@@ -663,9 +660,11 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     cplx* scratch = (cplx*)w;
     cplx* basis = scratch;                   // (`scratch` itself only tells the kernel that warm starts are on)
     const size_t m = des->dev.m, DD = (size_t)p3::D * p3::D;
+    DesignDev dev = des->dev;
+    dev.eig_rel_tol = option_pgdb_eig_rel_tol(3);
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), des->dev, (long long)nb,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
                            dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch,
                            FBX_PHASE_OUT3(b0), sw ? sw + 4 * b0 : nullptr, basis, BASIS_CAP);

@@ -148,6 +148,15 @@ int check_design(const fbx_design* des, const char* who) {
 
 using namespace fbx;
 
+// ---- tunables (process-wide, read at launch time)
+namespace fbx {
+namespace {
+std::atomic<double> g_eig_rel_tol2{FBX_JTOL_REL};     // 1- and 2-qubit PGDB (fbx_pgdb.hip)
+std::atomic<double> g_eig_rel_tol3{FBX3_JTOL_REL};     // 3-qubit PGDB (fbx_pgdb3.hip)
+}
+double option_pgdb_eig_rel_tol(int n_qubits) { return n_qubits >= 3 ? g_eig_rel_tol3.load() : g_eig_rel_tol2.load(); }
+}  // namespace fbx
+
 extern "C" {
 
 int fbx_version(void) { return 200; }
@@ -196,6 +205,29 @@ int fbx_synchronize(void) {
     if (rc) return rc;
     FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
+}
+
+// ---- tunables (process-wide, read at launch time; state above the extern "C" block)
+
+int fbx_set_option(const char* name, double value) {
+    FBX_REQUIRE(name != nullptr, "fbx_set_option: NULL name");
+    const std::string n(name);
+    if (n == "pgdb_eig_rel_tol" || n == "pgdb3_eig_rel_tol") {
+        FBX_REQUIRE(value >= 0.0 && value <= 1e-3, "fbx_set_option: the relative eigensolver tolerance must be in [0, 1e-3]");
+        (n == "pgdb_eig_rel_tol" ? fbx::g_eig_rel_tol2 : fbx::g_eig_rel_tol3).store(value);
+        return FBX_OK;
+    }
+    set_error("fbx_set_option: unknown option '" + n + "'");
+    return FBX_ERR_BAD_ARG;
+}
+
+int fbx_get_option(const char* name, double* value) {
+    FBX_REQUIRE(name != nullptr && value != nullptr, "fbx_get_option: NULL argument");
+    const std::string n(name);
+    if (n == "pgdb_eig_rel_tol") { *value = fbx::g_eig_rel_tol2.load(); return FBX_OK; }
+    if (n == "pgdb3_eig_rel_tol") { *value = fbx::g_eig_rel_tol3.load(); return FBX_OK; }
+    set_error("fbx_get_option: unknown option '" + n + "'");
+    return FBX_ERR_BAD_ARG;
 }
 
 int fbx_release_workspace(void) {
@@ -429,7 +461,7 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
     des->dev.order = (const int*)(base + oOrder);
     des->dev.sp = (const uint32_t*)(base + oSp);
     des->dev.sptr = (const int*)(base + oPtr);
-    des->dev.porder = nullptr; des->dev.pptr = nullptr; des->dev.pinvT = nullptr;
+    des->dev.porder = nullptr; des->dev.pptr = nullptr; des->dev.pinvT = nullptr; des->dev.eig_rel_tol = 0.0;
 
     if (kind == FBX_KIND_PROCESS) {
         // ---- linear-inversion tables.  In the orthonormal operator basis {P_j^T (x) P_i / d} the

@@ -103,6 +103,8 @@ PROTOTYPES = {
     "fbx_apply_choi_dev": [C.c_int, _i64, _vp, _vp, _vp],
     "fbx_state_measures_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "fbx_eigh_dev": [C.c_int, _i64, _vp, _vp, _vp],
+    "fbx_set_option": [C.c_char_p, C.c_double],
+    "fbx_get_option": [C.c_char_p, _dp],
     "fbx_pauli_vector": [C.c_int, _i64, _dp, _dp],
     "fbx_pauli_vector_dev": [C.c_int, _i64, _vp, _vp],
     "fbx_random_operators": [C.c_int, C.c_int, C.c_int, _i64, C.c_uint64, _i64, _dp],
@@ -158,6 +160,33 @@ def set_device(idx: int):
 def release_workspace():
     """Give the calling thread's cached device workspaces / staging pool back (fbx_release_workspace)."""
     check(lib().fbx_release_workspace())
+
+
+def set_option(name: str, value: float) -> None:
+    """Process-wide tunable (fbx_set_option; include/fbx.h): 'pgdb_eig_rel_tol', 'pgdb3_eig_rel_tol'."""
+    check(lib().fbx_set_option(name.encode(), float(value)))
+
+
+def get_option(name: str) -> float:
+    v = C.c_double(0.0)
+    check(lib().fbx_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+class option:
+    """``with _lib.option('pgdb_eig_rel_tol', 0.0): ...`` -- set a tunable for a block, then restore it."""
+
+    def __init__(self, name: str, value: float):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def device_name():

@@ -79,6 +79,15 @@ int         fbx_set_device(int device_id);          /* one process per GPU: call
 int         fbx_device_name(char* buf, size_t len, int* compute_units);
 int         fbx_synchronize(void);                  /* the calling thread's stream */
 int         fbx_release_workspace(void);            /* free the calling thread's cached device workspaces / staging pool */
+/* Process-wide tunables, read when a kernel is launched.
+ *   "pgdb_eig_rel_tol"  (default 1e-8), "pgdb3_eig_rel_tol" (default 3e-7; 3 qubits): while the projected-gradient
+ *   iteration of fbx_pgdb_process is far from its fixed point, the eigensolver of its CP projections stops at an
+ *   off-diagonal norm of <value> x the previous outer step (relative to ||H||_F) instead of always at 1e-13 --
+ *   an inexact projection whose error is that fraction of the distance the estimate still moves per iteration.
+ *   0 reproduces the reference's eigh-to-machine-precision trajectory iteration by iteration (tests use it);
+ *   the defaults leave the converged estimates within 1e-9 of the reference's.  Range [0, 1e-3]. */
+int         fbx_set_option(const char* name, double value);
+int         fbx_get_option(const char* name, double* value);
 
 /* ---------------------------------------------------------------- multi-GPU
  * One process per GPU; RCCL over xGMI.  The reconstruction path shards on the batch axis (the

@@ -32,24 +32,30 @@ def test_converged_estimate_matches_reference_golden(gpu):
 
 def test_few_iterations_match_oracle_incl_counts(gpu):
     """Fixed 3 outer iterations against the dense-A oracle (8064 x 4096 design matrix), two items,
-    trace-preserving and trace-non-increasing.  Tolerance: the parity bar (1e-9).  Far from the fixed point the
-    kernel's CP projections stop their eigensolver at an off-diagonal norm of 1e-8 x the outer step (DESIGN.md
-    2.1, FBX_JTOL_REL), so after three O(0.1) steps the estimate may sit 1e-9 from the oracle's (2e-11 measured;
-    1e-13 with -DFBX3_JTOL_REL=0); the counts must still be equal."""
-    from fbx import synthetic, tomography
+    trace-preserving and trace-non-increasing.  With the eigensolver held at 1e-13 throughout
+    (fbx_set_option('pgdb3_eig_rel_tol', 0)) the trajectory is the oracle's to 1e-11; with the default (inexact
+    projections while the iteration is far from its fixed point, 3e-7 x the outer step: include/fbx.h) the counts
+    are still equal and the estimate after three O(0.1 .. 1) steps sits within 1e-7 of it -- the price of an
+    early iterate, not of the result: run to convergence both agree with the oracle to 1e-10 (the golden test
+    above, scripts/parity_survey.py)."""
+    from fbx import synthetic, tomography, _lib
     from fbx_oracle import design as od, estimators as oe
     design, us, e, c = synthetic.process_batch(3, "sic", 2, first_item=5)
     d = od.Design(3, "process", design.in_labels, design.paulis, design.coefs)
     A = oe.design_matrix_A(d)
+    assert _lib.get_option("pgdb3_eig_rel_tol") == 3e-7
     for tp in (True, False):
-        got, st = tomography.pgdb_process_estimate_batch(design, e, c, trace_preserving=tp, mode="fixed",
-                                                         max_iters=3, return_stats=True)
-        for b in range(2):
-            want, ws = oe.pgdb_process_estimate(d, e[b], c[b], trace_preserving=tp, A=A, mode="fixed",
-                                                max_iters=3, return_stats=True)
-            assert np.abs(got[b] - want).max() < 1e-9
-            assert st["dykstra"][b] == ws["dykstra"] and st["backtracks"][b] == ws["backtracks"]
-            assert abs(st["cost"][b] - ws["cost"]) < 1e-9
+        want = [oe.pgdb_process_estimate(d, e[b], c[b], trace_preserving=tp, A=A, mode="fixed", max_iters=3,
+                                         return_stats=True) for b in range(2)]
+        for rel_tol, tol in ((0.0, 1e-11), (None, 1e-7)):
+            with _lib.option("pgdb3_eig_rel_tol", 3e-7 if rel_tol is None else rel_tol):
+                got, st = tomography.pgdb_process_estimate_batch(design, e, c, trace_preserving=tp, mode="fixed",
+                                                                 max_iters=3, return_stats=True)
+            for b in range(2):
+                assert np.abs(got[b] - want[b][0]).max() < tol
+                assert st["dykstra"][b] == want[b][1]["dykstra"] and st["backtracks"][b] == want[b][1]["backtracks"]
+                assert abs(st["cost"][b] - want[b][1]["cost"]) < tol
+    assert _lib.get_option("pgdb3_eig_rel_tol") == 3e-7
 
 
 def test_batch_of_256_properties(gpu):
@@ -120,11 +126,13 @@ def test_pauli_in_basis_3q_matches_oracle(gpu):
     assert design.m == 13608
     d = od.Design(3, "process", design.in_labels, design.paulis, design.coefs)
     A = oe.design_matrix_A(d, sparse=True)
-    got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=2, return_stats=True)
+    from fbx import _lib
+    with _lib.option("pgdb3_eig_rel_tol", 0.0):       # the oracle's trajectory iteration by iteration
+        got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=2, return_stats=True)
     want, ws = oe.pgdb_process_estimate(d, e[0], c[0], A=A, mode="fixed", max_iters=2, return_stats=True)
-    assert np.abs(got[0] - want).max() < 1e-9         # two O(0.1) steps with inexact projections, see above
+    assert np.abs(got[0] - want).max() < 1e-11
     assert st["dykstra"][0] == ws["dykstra"] and st["backtracks"][0] == ws["backtracks"]
-    assert abs(st["cost"][0] - ws["cost"]) < 1e-9
+    assert abs(st["cost"][0] - ws["cost"]) < 1e-11
     lin = tomography.linear_inv_process_estimate_batch(design, e)
     pt = np.einsum("iojo->ij", lin[0].reshape(8, 8, 8, 8))
     assert np.abs(lin[0] - lin[0].conj().T).max() < 1e-12 and np.abs(pt - np.eye(8)).max() < 1e-9
