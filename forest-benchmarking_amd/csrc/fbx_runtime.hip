@@ -22,8 +22,8 @@ struct ThreadCtx {
     bool timing = false;
     struct Block { void* p; size_t bytes; bool busy; };
     std::vector<Block> pool;
-    void* ws[WS_COUNT] = {nullptr, nullptr, nullptr, nullptr};
-    size_t ws_bytes[WS_COUNT] = {0, 0, 0, 0};
+    void* ws[WS_COUNT] = {};
+    size_t ws_bytes[WS_COUNT] = {};
 
     void drop_memory() {
         for (auto& b : pool) if (b.p) (void)hipFree(b.p);

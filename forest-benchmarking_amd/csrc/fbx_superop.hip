@@ -10,6 +10,7 @@
 //   distance_measures.py:271-359                             (entanglement / process fidelity)
 #include "fbx_choi.hpp"
 #include <cstdlib>
+#include <algorithm>
 
 namespace fbx {
 
@@ -365,6 +366,153 @@ convert3_kernel(int from, int to, long long B, const double* __restrict__ in, in
         }
     }
     store_matrix<NQ, NT, LD>(cur, out + item * (long long)D * D * 2, t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4 and 5 qubits (256 x 256 / 1024 x 1024 superoperators): the same walk through the representation graph
+// with the two work matrices of an item in HBM / L2 (1 MB / 16 MB each) instead of LDS -- one 1024-thread
+// workgroup per item, every primitive looped over the entries (or the quads of a butterfly stage) with a
+// workgroup barrier between the stages.  Conversions INTO chi from anything but Kraus operators go through
+// a D x D eigendecomposition in the reference (choi2kraus) and are not offered beyond 3 qubits.
+// ---------------------------------------------------------------------------------------------
+template <int NQ, bool INVERSE, int NT>
+__device__ void site_stages_big(cplx* M, int t) {
+    constexpr int D = 1 << (2 * NQ), NQUAD = D * D / 4;
+#pragma unroll 1
+    for (int q = NQ - 1; q >= 0; --q) {
+        for (int u = t; u < NQUAD; u += NT) pauli_site_stage<NQ, INVERSE, D>(M, u, 3 * NQ + q, 2 * NQ + q, -1.0);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int q = NQ - 1; q >= 0; --q) {
+        for (int u = t; u < NQUAD; u += NT) pauli_site_stage<NQ, INVERSE, D>(M, u, NQ + q, q, +1.0);
+        __syncthreads();
+    }
+}
+template <int NQ, int NT>
+__device__ void to_pauli_big(cplx* in, cplx* out, double scale, int t) {        // destroys `in`
+    constexpr int D = 1 << (2 * NQ);
+    site_stages_big<NQ, false, NT>(in, t);
+    for (int idx = t; idx < D * D; idx += NT) {
+        cplx v = in[site_index<NQ>(idx / D) * D + site_index<NQ>(idx % D)];
+        v.re *= scale; v.im *= scale;
+        out[idx] = v;
+    }
+}
+template <int NQ, int NT>
+__device__ void from_pauli_big(const cplx* in, cplx* out, double scale, int t) {
+    constexpr int D = 1 << (2 * NQ);
+    const double s = scale * D;
+    for (int idx = t; idx < D * D; idx += NT) {
+        cplx v = in[idx];
+        v.re *= s; v.im *= s;
+        out[site_index<NQ>(idx / D) * D + site_index<NQ>(idx % D)] = v;
+    }
+    __syncthreads();
+    site_stages_big<NQ, true, NT>(out, t);
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(1024)
+convert_big_kernel(int from, int to, long long B, const double* __restrict__ in, int K, double* __restrict__ out,
+                   cplx* __restrict__ work) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D, NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* kb = (cplx*)smem;                                  // the Kraus operators of the item
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    cplx* cur = work + (size_t)item * 2 * D * D;
+    cplx* nxt = cur + (size_t)D * D;
+    auto swap = [&]() { cplx* q = cur; cur = nxt; nxt = q; __syncthreads(); };
+    const double inv_d = 1.0 / d;
+    int rep = from;
+    if (from == FBX_REP_KRAUS) {
+        const bool sup = (to == FBX_REP_SUPEROP || to == FBX_REP_PAULI_LIOUVILLE);
+        kraus_to<NQ, NT, LD>(in + item * (long long)K * D * 2, K, sup, cur, kb, t);
+        __syncthreads();
+        rep = sup ? FBX_REP_SUPEROP : FBX_REP_CHOI;
+    } else {
+        load_matrix<NQ, NT, LD>(in + item * (long long)D * D * 2, cur, t);
+        __syncthreads();
+    }
+    while (rep != to) {
+        if (rep == FBX_REP_CHI) {
+            from_pauli_big<NQ, NT>(cur, nxt, 1.0, t); swap(); rep = FBX_REP_CHOI;
+        } else if (rep == FBX_REP_CHOI) {
+            if (to == FBX_REP_CHI) {            // only from Kraus operators (checked on the host): the Choi matrix is PSD
+                to_pauli_big<NQ, NT>(cur, nxt, inv_d * inv_d, t); swap(); rep = FBX_REP_CHI;
+            } else {
+                reshuffle<NQ, NT, LD>(cur, nxt, t); swap(); rep = FBX_REP_SUPEROP;
+            }
+        } else if (rep == FBX_REP_SUPEROP) {
+            if (to == FBX_REP_PAULI_LIOUVILLE) {
+                to_pauli_big<NQ, NT>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_PAULI_LIOUVILLE;
+            } else {
+                reshuffle<NQ, NT, LD>(cur, nxt, t); swap(); rep = FBX_REP_CHOI;
+            }
+        } else {
+            from_pauli_big<NQ, NT>(cur, nxt, inv_d, t); swap(); rep = FBX_REP_SUPEROP;
+        }
+    }
+    store_matrix<NQ, NT, LD>(cur, out + item * (long long)D * D * 2, t);
+}
+
+template <int NQ>
+static int launch_convert_big(int from, int to, int64_t B, const double* in, int K, double* out) {
+    constexpr size_t d = (size_t)1 << NQ, D = d * d;
+    if (to == FBX_REP_CHI && from != FBX_REP_KRAUS) {
+        set_error("fbx_convert: conversions into chi from a Choi / superoperator / Pauli-Liouville matrix go through a "
+                  "D x D eigendecomposition (choi2kraus) and are offered for 1..3 qubits only");
+        return FBX_ERR_UNSUPPORTED;
+    }
+    const size_t lds = sizeof(cplx) * (size_t)(K > 0 ? K : 1) * D;
+    if (lds > 160 * 1024) { set_error("fbx_convert: too many Kraus operators for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    auto kern = convert_big_kernel<NQ>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t per_item = 2 * D * D * sizeof(cplx);
+    const int64_t chunk = (int64_t)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)512 << 20) / per_item));
+    void* w = nullptr;
+    { const int rc = workspace(WS_CONVERT, per_item * (size_t)chunk, &w); if (rc) return rc; }
+    const size_t in_item = (from == FBX_REP_KRAUS ? (size_t)K * D : D * D) * 2;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), from, to, (long long)nb, in + b0 * in_item, K,
+                           out + b0 * D * D * 2, (cplx*)w);
+    }
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Any Hilbert-space dimension (qutrits, ...): the conversions that involve no operator basis --
+// kraus2superop, kraus2choi, superop2choi, choi2superop (superoperator_transformations.py:100-182,267-277,351-361).
+// One thread per output entry, straight from and to HBM.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+convert_general_kernel(int from, int to, int d, long long B, const double* __restrict__ in, int K, double* __restrict__ out) {
+    const long long D = (long long)d * d, DD = D * D;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * DD) return;
+    const long long item = gid / DD;
+    const int row = (int)((gid % DD) / D), col = (int)(gid % D);
+    double re = 0.0, im = 0.0;
+    if (from == FBX_REP_KRAUS) {
+        const double* k0 = in + item * K * D * 2;
+        for (int t = 0; t < K; ++t) {
+            const double* k = k0 + (long long)t * D * 2;
+            int ia, ib;
+            double sa = 1.0, sb = 1.0;
+            if (to == FBX_REP_SUPEROP) { ia = (row / d) * d + col / d; sa = -1.0; ib = (row % d) * d + col % d; }   // conj(K[i][j]) K[k][l]
+            else { ia = (row % d) * d + row / d; ib = (col % d) * d + col / d; sb = -1.0; }                         // vK[row] conj(vK[col])
+            const double ar = k[2 * ia], ai = sa * k[2 * ia + 1], br = k[2 * ib], bi = sb * k[2 * ib + 1];
+            re += ar * br - ai * bi; im += ar * bi + ai * br;
+        }
+    } else {        // the reshuffle, its own inverse: out[(p,q)][(r,s)] = in[(s,q)][(r,p)]
+        const int p = row / d, q = row % d, r = col / d, s = col % d;
+        const double* src = in + (item * DD + (long long)(s * d + q) * D + r * d + p) * 2;
+        re = src[0]; im = src[1];
+    }
+    out[2 * gid] = re; out[2 * gid + 1] = im;
 }
 
 static int launch_convert3(int from, int to, int64_t B, const double* in, int K, double* out) {
@@ -1113,7 +1261,7 @@ int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect, 
 }
 
 static int convert_check(int from_rep, int to_rep, int n_qubits, int64_t B, const void* in, int K, const void* out) {
-    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_convert: n_qubits must be 1..3");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 5, "fbx_convert: n_qubits must be 1..5");
     FBX_REQUIRE(from_rep >= FBX_REP_KRAUS && from_rep <= FBX_REP_CHI, "fbx_convert: bad source representation");
     FBX_REQUIRE(to_rep >= FBX_REP_CHOI && to_rep <= FBX_REP_CHI, "fbx_convert: bad target representation (Kraus output is not offered)");
     FBX_REQUIRE(from_rep != to_rep, "fbx_convert: source and target representation are the same");
@@ -1126,9 +1274,45 @@ int fbx_convert_dev(int from_rep, int to_rep, int n_qubits, int64_t B, const dou
     FBX_TRY(convert_check(from_rep, to_rep, n_qubits, B, d_in, K, d_out));
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
+    if (n_qubits == 5) return launch_convert_big<5>(from_rep, to_rep, B, d_in, K, d_out);
+    if (n_qubits == 4) return launch_convert_big<4>(from_rep, to_rep, B, d_in, K, d_out);
     if (n_qubits == 3) return launch_convert3(from_rep, to_rep, B, d_in, K, d_out);
     if (n_qubits == 1) return launch_convert<1>(from_rep, to_rep, B, d_in, K, d_out);
     return launch_convert<2>(from_rep, to_rep, B, d_in, K, d_out);
+}
+
+static int convert_general_check(int from_rep, int to_rep, int dim, int64_t B, const void* in, int K, const void* out) {
+    FBX_REQUIRE(dim >= 1 && dim <= 256, "fbx_convert_general: dim must be 1..256");
+    const bool ok = (from_rep == FBX_REP_KRAUS && (to_rep == FBX_REP_SUPEROP || to_rep == FBX_REP_CHOI)) ||
+                    (from_rep == FBX_REP_SUPEROP && to_rep == FBX_REP_CHOI) || (from_rep == FBX_REP_CHOI && to_rep == FBX_REP_SUPEROP);
+    FBX_REQUIRE(ok, "fbx_convert_general: only kraus -> superop / choi and superop <-> choi are basis free");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (in && out)), "fbx_convert_general: bad batch / NULL buffer");
+    FBX_REQUIRE(from_rep != FBX_REP_KRAUS || K >= 1, "fbx_convert_general: need K >= 1 Kraus operators");
+    return FBX_OK;
+}
+
+int fbx_convert_general_dev(int from_rep, int to_rep, int dim, int64_t B, const double* d_in, int K, double* d_out) {
+    FBX_TRY(convert_general_check(from_rep, to_rep, dim, B, d_in, K, d_out));
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const long long total = (long long)B * dim * dim * dim * dim;
+    hipLaunchKernelGGL(convert_general_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(), from_rep, to_rep, dim,
+                       (long long)B, d_in, K, d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_convert_general(int from_rep, int to_rep, int dim, int64_t B, const double* in, int K, double* out) {
+    FBX_TRY(convert_general_check(from_rep, to_rep, dim, B, in, K, out));
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t D = (size_t)dim * dim;
+    const size_t n_in = (from_rep == FBX_REP_KRAUS ? (size_t)K * D : D * D) * 2 * B, n_out = D * D * 2 * B;
+    HostIO io; double *d_in, *d_out;
+    FBX_TRY(io.in(in, n_in, &d_in)); FBX_TRY(io.out(n_out, &d_out));
+    FBX_TRY(fbx_convert_general_dev(from_rep, to_rep, dim, B, d_in, K, d_out));
+    FBX_TRY(io.back(out, d_out, n_out));
+    return io.sync();
 }
 
 int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K, double* out) {

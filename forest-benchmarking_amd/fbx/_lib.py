@@ -103,6 +103,8 @@ PROTOTYPES = {
     "fbx_apply_choi_dev": [C.c_int, _i64, _vp, _vp, _vp],
     "fbx_state_measures_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "fbx_eigh_dev": [C.c_int, _i64, _vp, _vp, _vp],
+    "fbx_convert_general": [C.c_int, C.c_int, C.c_int, _i64, _dp, C.c_int, _dp],
+    "fbx_convert_general_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
     "fbx_set_option": [C.c_char_p, C.c_double],
     "fbx_get_option": [C.c_char_p, _dp],
     "fbx_pauli_vector": [C.c_int, _i64, _dp, _dp],

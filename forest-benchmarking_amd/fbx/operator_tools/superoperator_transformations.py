@@ -39,31 +39,43 @@ def unvec(vector: np.ndarray, shape: Optional[Tuple[int, int]] = None) -> np.nda
     return vector.reshape(*shape).T
 
 
+_BASIS_FREE = {("kraus", "superop"), ("kraus", "choi"), ("superop", "choi"), ("choi", "superop")}
+
+
 def _nq_from_D(D):
+    """Number of qubits of a D x D superoperator, or None when D is not 4^n with n <= 5."""
     d = int(round(np.sqrt(D)))
-    n = int(round(np.log2(d)))
-    if 4 ** n != D:
-        raise ValueError("superoperator dimension must be a power of four")
-    return n
+    n = int(round(np.log2(d))) if d > 0 else 0
+    return n if 4 ** n == D and 1 <= n <= 5 else None
 
 
 def convert_batch(src: str, dst: str, x) -> np.ndarray:
-    """Stacked conversion: x is [B, K, d, d] for src == 'kraus', else [B, D, D]; returns [B, D, D]."""
+    """Stacked conversion: x is [B, K, d, d] for src == 'kraus', else [B, D, D]; returns [B, D, D].
+    Qubit systems (d = 2^n, n <= 5) take the Pauli-aware kernels (``fbx_convert``); any other dimension
+    is served for the basis-free pairs (kraus -> superop / choi, superop <-> choi; ``fbx_convert_general``)."""
     x = _lib.c128(x)
     if src == "kraus":
         if x.ndim != 4 or x.shape[-1] != x.shape[-2]:
             raise ValueError("kraus input must be [B, K, d, d] with square operators")
         B, K, d = x.shape[0], x.shape[1], x.shape[-1]
-        n = int(round(np.log2(d)))
-        if 2 ** n != d:
-            raise ValueError("Kraus dimension must be a power of two")
+        n = _nq_from_D(d * d)
     else:
         if x.ndim != 3 or x.shape[-1] != x.shape[-2]:
             raise ValueError("input must be [B, D, D]")
         B, K = x.shape[0], 0
+        d = int(round(np.sqrt(x.shape[-1])))
+        if d * d != x.shape[-1]:
+            raise ValueError("superoperator dimension must be a perfect square")
         n = _nq_from_D(x.shape[-1])
-    D = 4 ** n
+    D = d * d
     out = np.empty((B, D, D), dtype=np.complex128)
+    if n is None:
+        if (src, dst) not in _BASIS_FREE:
+            raise ValueError(f"{src} -> {dst} needs the Pauli basis of a qubit system (dimension 2^n, n <= 5); "
+                             f"got dimension {d}")
+        _lib.check(_lib.lib().fbx_convert_general(_REPS[src], _REPS[dst], d, B, _lib.dptr(x.view(np.float64)),
+                                                  K, _lib.dptr(out.view(np.float64))))
+        return out
     _lib.check(_lib.lib().fbx_convert(_REPS[src], _REPS[dst], n, B, _lib.dptr(x.view(np.float64)),
                                       K, _lib.dptr(out.view(np.float64))))
     return out

@@ -201,12 +201,21 @@ int fbx_state_log_likelihood_dev(const fbx_design* design, int64_t B, const doub
  * fbx_convert: the pairwise conversions of operator_tools/superoperator_transformations.py
  * :82-371.  `in` is [B][K][d][d] for FBX_REP_KRAUS (K operators per item), else [B][D][D];
  * `out` is [B][D][D].  Conversions *to* Kraus are not offered (eigenvector-valued outputs
- * are only defined up to phase, superoperator_transformations.py:325-336). */
+ * are only defined up to phase, superoperator_transformations.py:325-336).  n_qubits 1..5; for
+ * 4 and 5 qubits (256^2 / 1024^2 matrices, work matrices in HBM) the conversions INTO chi from a Choi /
+ * superoperator / Pauli-Liouville matrix -- which the reference routes through a D x D eigendecomposition
+ * (choi2kraus) -- return FBX_ERR_UNSUPPORTED; kraus -> chi and everything else is there. */
 int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K,
                 double* out);
 /* same with device pointers (buffers from fbx_malloc): the batch stays resident in HBM */
 int fbx_convert_dev(int from_rep, int to_rep, int n_qubits, int64_t B, const double* d_in, int K,
                     double* d_out);
+/* The conversions that involve no operator basis, for ANY Hilbert-space dimension `dim` (qutrits, ...;
+ * 1..256): kraus -> superop (superoperator_transformations.py:100-145), kraus -> choi (:159-182),
+ * superop <-> choi (:267-277, :351-361).  Shapes as above with d = dim, D = dim^2. */
+int fbx_convert_general(int from_rep, int to_rep, int dim, int64_t B, const double* in, int K, double* out);
+int fbx_convert_general_dev(int from_rep, int to_rep, int dim, int64_t B, const double* d_in, int K,
+                            double* d_out);
 
 /* Fused conversion sweep of BASELINE config 3: kraus2choi -> choi2pauli_liouville ->
  * choi2chi -> process_fidelity(ptm_ref, ptm) (superoperator_transformations.py:159,364,339;

@@ -190,3 +190,75 @@ def test_full_size_sweep_properties(gpu):
         else:
             assert np.abs(out[::997, 0, 0] - 1).max() < 1e-12
         del out
+
+
+# ------------------------------------------------------------------ beyond three qubits / beyond qubits
+def test_four_qubit_conversions_match_the_oracle(gpu):
+    """256 x 256 superoperators (work matrices in HBM, csrc/fbx_superop.hip convert_big_kernel): every pairwise
+    conversion that does not need the 256 x 256 eigendecomposition of choi2kraus, against the oracle's dense
+    basis-change matrices."""
+    from fbx.operator_tools import superoperator_transformations as st
+    from fbx_oracle import superops as so
+    rs = np.random.RandomState(4)
+    g = rs.randn(2, 2, 16, 16) + 1j * rs.randn(2, 2, 16, 16)
+    s = sum(k.conj().T @ k for k in g[0])
+    w, v = np.linalg.eigh(s)
+    fix = v @ np.diag(w ** -0.5) @ v.conj().T
+    kraus = np.array([[k @ fix for k in g[0]], [k @ fix for k in g[0][::-1]]])          # two CPTP sets
+    reps = {"choi": np.array([so.kraus2choi(list(k)) for k in kraus]), "superop": np.array([so.kraus2superop(list(k)) for k in kraus]),
+            "pauli_liouville": np.array([so.kraus2pauli_liouville(list(k)) for k in kraus]), "chi": np.array([so.kraus2chi(list(k)) for k in kraus])}
+    for dst in ("choi", "superop", "pauli_liouville", "chi"):
+        got = st.convert_batch("kraus", dst, kraus)
+        assert np.abs(got - reps[dst]).max() < 1e-11, ("kraus", dst)
+    for src in ("choi", "superop", "pauli_liouville", "chi"):
+        for dst in ("choi", "superop", "pauli_liouville"):
+            if src != dst:
+                got = st.convert_batch(src, dst, reps[src])
+                assert np.abs(got - reps[dst]).max() < 1e-11, (src, dst)
+    assert np.abs(reps["pauli_liouville"].imag).max() < 1e-12                            # a PTM is real
+    for src in ("choi", "superop", "pauli_liouville"):                                   # routed through eigh in the reference
+        with pytest.raises(Exception):
+            st.convert_batch(src, "chi", reps[src])
+
+
+def test_five_qubit_conversions(gpu):
+    """1024 x 1024 superoperators: the PTM of a product of single-qubit unitaries is the Kronecker product of the
+    single-qubit PTMs; reshuffle and Pauli transforms invert each other."""
+    from fbx.operator_tools import superoperator_transformations as st
+    from fbx.operator_tools.random_operators import haar_rand_unitary_batch
+    us = haar_rand_unitary_batch(2, 5, seed=9)
+    big = us[0]
+    ptm = st.kraus2pauli_liouville(us[0])
+    for u in us[1:]:
+        big = np.kron(big, u)
+        ptm = np.kron(ptm, st.kraus2pauli_liouville(u))
+    got = st.convert_batch("kraus", "pauli_liouville", big[None, None])[0]
+    assert got.shape == (1024, 1024) and np.abs(got - ptm).max() < 1e-12
+    sup = st.convert_batch("pauli_liouville", "superop", got[None])
+    assert np.abs(sup[0] - np.kron(big.conj(), big)).max() < 1e-12
+    choi = st.convert_batch("superop", "choi", sup)
+    v = big.T.reshape(-1, 1)
+    assert np.abs(choi[0] - v @ v.conj().T).max() < 1e-12
+    assert np.abs(st.convert_batch("choi", "pauli_liouville", choi)[0] - ptm).max() < 1e-12
+
+
+def test_basis_free_conversions_in_any_dimension(gpu):
+    """Qutrits and a 5-dimensional system: kraus2superop, kraus2choi and the reshuffle (fbx_convert_general) against
+    the oracle; conversions that need a Pauli basis say so."""
+    from fbx.operator_tools import superoperator_transformations as st
+    from fbx_oracle import superops as so
+    rs = np.random.RandomState(6)
+    for d in (3, 5):
+        ks = rs.randn(3, 2, d, d) + 1j * rs.randn(3, 2, d, d)
+        sup = st.convert_batch("kraus", "superop", ks)
+        choi = st.convert_batch("kraus", "choi", ks)
+        for b in range(3):
+            assert np.abs(sup[b] - so.kraus2superop(list(ks[b]))).max() < 1e-13
+            assert np.abs(choi[b] - so.kraus2choi(list(ks[b]))).max() < 1e-13
+            assert np.abs(st.superop2choi(sup[b]) - choi[b]).max() < 1e-13
+            assert np.abs(st.choi2superop(choi[b]) - sup[b]).max() < 1e-13
+        assert np.abs(st.kraus2superop(list(ks[0])) - sup[0]).max() == 0.0
+        with pytest.raises(ValueError):
+            st.kraus2pauli_liouville(list(ks[0]))
+        with pytest.raises(ValueError):
+            st.choi2chi(choi[0])
