@@ -1420,7 +1420,7 @@ int fbx_apply_choi(int n_qubits, int64_t B, const double* choi, const double* rh
 }
 
 int fbx_process_fidelity_dev(int n_qubits, int64_t B, const double* d_ptm0, const double* d_ptm1, double* d_fe_out, double* d_fp_out) {
-    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_process_fidelity: n_qubits must be 1..3");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 5, "fbx_process_fidelity: n_qubits must be 1..5");
     FBX_REQUIRE(B >= 0 && (B == 0 || (d_ptm0 && d_ptm1)), "fbx_process_fidelity: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
@@ -1431,7 +1431,7 @@ int fbx_process_fidelity_dev(int n_qubits, int64_t B, const double* d_ptm0, cons
 }
 
 int fbx_process_fidelity(int n_qubits, int64_t B, const double* ptm0, const double* ptm1, double* fe_out, double* fp_out) {
-    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_process_fidelity: n_qubits must be 1..3");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 5, "fbx_process_fidelity: n_qubits must be 1..5");
     FBX_REQUIRE(B >= 0 && (B == 0 || (ptm0 && ptm1)), "fbx_process_fidelity: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;

@@ -259,7 +259,7 @@ int fbx_pauli_twirl_chi_dev(int64_t B, int D, const double* d_chi, double* d_out
 
 /* entanglement_fidelity / process_fidelity (distance_measures.py:271-359) on
  * Pauli-Liouville matrices [B][D][D] (real parts of tr(A^H B) / d^2): fe_out, fp_out may be
- * NULL. */
+ * NULL.  n_qubits 1..5. */
 int fbx_process_fidelity(int n_qubits, int64_t B, const double* ptm0, const double* ptm1,
                          double* fe_out, double* fp_out);
 int fbx_process_fidelity_dev(int n_qubits, int64_t B, const double* d_ptm0, const double* d_ptm1,

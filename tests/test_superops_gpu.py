@@ -240,6 +240,11 @@ def test_five_qubit_conversions(gpu):
     v = big.T.reshape(-1, 1)
     assert np.abs(choi[0] - v @ v.conj().T).max() < 1e-12
     assert np.abs(st.convert_batch("choi", "pauli_liouville", choi)[0] - ptm).max() < 1e-12
+    # process fidelity on 1024 x 1024 Pauli transfer matrices: to itself 1, to the identity the product formula
+    from fbx import distance_measures as dm
+    assert abs(dm.process_fidelity(ptm, got) - 1.0) < 1e-12
+    fe = np.prod([abs(np.trace(u)) ** 2 / 4 for u in us])                 # entanglement fidelity of a product unitary
+    assert abs(dm.process_fidelity(np.eye(1024), got) - (32 * fe + 1) / 33) < 1e-12
 
 
 def test_basis_free_conversions_in_any_dimension(gpu):
