@@ -13,6 +13,9 @@
 #include "fbx_eigh.hpp"
 #include <cfloat>
 #include <cstdlib>
+#include <algorithm>
+#include <vector>
+#include <cstring>
 
 namespace fbx {
 
@@ -587,6 +590,121 @@ eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_ou
     }
 }
 
+// ---- Hermitian eigendecomposition for 64 < N <= 1024 (4- and 5-qubit Choi matrices, padded odd sizes): the same
+// systolic two-sided Jacobi with the matrix and the eigenvectors in HBM / L2 instead of LDS.  One 1024-thread
+// workgroup per matrix; a round = (a) the N/2 rotations from the pivot blocks into an LDS table, (b) every 2 x 2
+// block rotated and written to the seats the tournament permutation assigns it -- from the `cur` copies into the
+// `nxt` copies, so no entry is overwritten before it is read -- and the copies swap.  Correctness first: this
+// serves validators, choi2kraus and sqrtm of large operators, not a benchmark (one CU per matrix, ~20 us per round).
+__device__ __forceinline__ int jacobi_seat_rt(int NB, int s) {           // jacobi_seat<N> with N at run time
+    if (NB == 1) return s;
+    const int k = s >> 1;
+    if ((s & 1) == 0) {
+        if (k == 0) return 0;
+        if (k == NB - 1) return 2 * (NB - 1) + 1;
+        return 2 * (k + 1);
+    }
+    if (k == 0) return 2;
+    return 2 * (k - 1) + 1;
+}
+
+__global__ void __launch_bounds__(1024)
+eigh_big_kernel(int N, long long B, const double* __restrict__ a, double* __restrict__ w_out, double* __restrict__ v_out,
+                cplx* __restrict__ work) {
+    constexpr int NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* rot = (double*)smem;                 // [N/2][4]: c, sr, si, -
+    double* lam = rot + 2 * N;                   // [N]
+    int* pos = (int*)(lam + N);                  // [N]
+    double* red = (double*)(pos + N);            // [64]
+    const int t = threadIdx.x, NB = N / 2;
+    const long long item = blockIdx.x;
+    const size_t NN = (size_t)N * N;
+    cplx* M0 = work + (size_t)item * 4 * NN;
+    cplx* M1 = M0 + NN; cplx* V0 = M1 + NN; cplx* V1 = V0 + NN;
+    const double* src = a + item * (long long)NN * 2;
+    for (size_t idx = t; idx < NN; idx += NT) {            // numpy eigh: the lower triangle defines the matrix
+        const int r = (int)(idx / N), c = (int)(idx % N);
+        cplx h, v;
+        if (r > c) { h.re = src[2 * idx]; h.im = src[2 * idx + 1]; }
+        else if (r < c) { h.re = src[2 * ((size_t)c * N + r)]; h.im = -src[2 * ((size_t)c * N + r) + 1]; }
+        else { h.re = src[2 * idx]; h.im = 0.0; }
+        v.re = r == c ? 1.0 : 0.0; v.im = 0.0;
+        M0[idx] = h; V0[idx] = v;
+    }
+    __syncthreads();
+    cplx *Mc = M0, *Mn = M1, *Vc = V0, *Vn = V1;
+    for (int sweep = 0; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
+        double o2 = 0.0, n2 = 0.0;
+        for (size_t idx = t; idx < NN; idx += NT) {
+            const cplx v = Mc[idx];
+            const double a2 = v.re * v.re + v.im * v.im;
+            n2 += a2;
+            if (idx / N != idx % N) o2 += a2;
+        }
+        block_sum2<NT>(o2, n2, red);
+        if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
+        for (int r = 0; r < N - 1; ++r) {
+            for (int p = t; p < NB; p += NT) {
+                const cplx b = Mc[(size_t)(2 * p) * N + 2 * p + 1];
+                const JRot q = jacobi_rotation(Mc[(size_t)(2 * p) * N + 2 * p].re, Mc[(size_t)(2 * p + 1) * N + 2 * p + 1].re, b.re, b.im);
+                rot[4 * p] = q.c; rot[4 * p + 1] = q.sr; rot[4 * p + 2] = q.si;
+            }
+            __syncthreads();
+            for (int blk = t; blk < NB * NB; blk += NT) {
+                const int I = blk / NB, J = blk % NB;
+                const size_t r0 = (size_t)(2 * I) * N + 2 * J, r1 = r0 + N;
+                cplx m00 = Mc[r0], m01 = Mc[r0 + 1], m10 = Mc[r1], m11 = Mc[r1 + 1];
+                cplx v0p = Vc[r0], v0q = Vc[r0 + 1], v1p = Vc[r1], v1q = Vc[r1 + 1];
+                const double cJ = rot[4 * J], sJr = rot[4 * J + 1], sJi = rot[4 * J + 2];
+                jacobi_apply_m(rot[4 * I], rot[4 * I + 1], rot[4 * I + 2], cJ, sJr, sJi, m00, m01, m10, m11);
+                jacobi_apply_v(cJ, sJr, sJi, v0p, v0q, v1p, v1q);
+                if (I == J) { m01.re = m01.im = 0.0; m10.re = m10.im = 0.0; m00.im = 0.0; m11.im = 0.0; }
+                const size_t ra = (size_t)jacobi_seat_rt(NB, 2 * I) * N, rb = (size_t)jacobi_seat_rt(NB, 2 * I + 1) * N;
+                const int ca = jacobi_seat_rt(NB, 2 * J), cb = jacobi_seat_rt(NB, 2 * J + 1);
+                Mn[ra + ca] = m00; Mn[ra + cb] = m01; Mn[rb + ca] = m10; Mn[rb + cb] = m11;
+                const size_t va = (size_t)(2 * I) * N, vb = va + N;                  // eigenvector ROWS stay, columns move
+                Vn[va + ca] = v0p; Vn[va + cb] = v0q; Vn[vb + ca] = v1p; Vn[vb + cb] = v1q;
+            }
+            __syncthreads();
+            cplx* q = Mc; Mc = Mn; Mn = q; q = Vc; Vc = Vn; Vn = q;
+        }
+    }
+    // (after whole sweeps the seats are the indices again)
+    for (int k = t; k < N; k += NT) lam[k] = Mc[(size_t)k * N + k].re;
+    __syncthreads();
+    for (int k = t; k < N; k += NT) {               // rank of eigenvalue k in ascending order (stable)
+        int rank = 0;
+        for (int j = 0; j < N; ++j) rank += (lam[j] < lam[k]) || (lam[j] == lam[k] && j < k);
+        pos[k] = rank;
+        w_out[item * N + rank] = lam[k];
+    }
+    __syncthreads();
+    if (v_out) {
+        for (size_t idx = t; idx < NN; idx += NT) {
+            const int r = (int)(idx / N), k = (int)(idx % N);
+            const cplx v = Vc[idx];
+            double* o = v_out + ((item * N + r) * N + pos[k]) * 2;
+            o[0] = v.re; o[1] = v.im;
+        }
+    }
+}
+
+static int launch_eigh_big(int N, int64_t B, const double* da, double* dw, double* dv) {
+    const size_t lds = sizeof(double) * (2 * (size_t)N + N + 64) + sizeof(int) * N;
+    const size_t per_item = 4 * (size_t)N * N * sizeof(cplx);
+    const int64_t chunk = (int64_t)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)1 << 30) / per_item));
+    void* w = nullptr;
+    { const int rc = workspace(WS_CONVERT, per_item * (size_t)chunk, &w); if (rc) return rc; }
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        hipLaunchKernelGGL(eigh_big_kernel, dim3((unsigned)nb), dim3(1024), lds, stream(), N, (long long)nb,
+                           da + b0 * (size_t)N * N * 2, dw + b0 * N, dv ? dv + b0 * (size_t)N * N * 2 : nullptr, (cplx*)w);
+    }
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 template <int N>
 static int launch_eigh(int64_t B, const double* da, double* dw, double* dv) {
     constexpr int NT = (N / 2) * (N / 2) > 64 ? (N / 2) * (N / 2) : 64;
@@ -817,10 +935,12 @@ int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* 
 }
 
 int fbx_eigh_dev(int N, int64_t B, const double* d_a, double* d_w_out, double* d_v_out) {
-    FBX_REQUIRE(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "fbx_eigh: N must be a power of two in 2..64");
+    FBX_REQUIRE(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64 || (N > 64 && N <= 1024 && N % 2 == 0),
+                "fbx_eigh_dev: N must be a power of two in 2..64 or an even number in 66..1024");
     FBX_REQUIRE(B >= 0 && (B == 0 || (d_a && d_w_out)), "fbx_eigh: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
+    if (N > 64) return launch_eigh_big(N, B, d_a, d_w_out, d_v_out);
     switch (N) {
         case 2: FBX_TRY(launch_eigh<2>(B, d_a, d_w_out, d_v_out)); break;
         case 4: FBX_TRY(launch_eigh<4>(B, d_a, d_w_out, d_v_out)); break;
@@ -834,12 +954,13 @@ int fbx_eigh_dev(int N, int64_t B, const double* d_a, double* d_w_out, double* d
 }
 
 int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
-    FBX_REQUIRE(N >= 1 && N <= 64, "fbx_eigh: N must be in 1..64");
+    FBX_REQUIRE(N >= 1 && N <= 1024, "fbx_eigh: N must be in 1..1024");
     FBX_REQUIRE(B >= 0 && (B == 0 || (a && w_out)), "fbx_eigh: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     int Np = 2;
     while (Np < N) Np *= 2;
+    if (N > 64) Np = N + (N & 1);           // the HBM-resident solver takes any even size
     if (Np == N) {
         const size_t nn = (size_t)N * N * 2 * B;
         HostIO io; double *da, *dw, *dv = nullptr;

@@ -1171,6 +1171,26 @@ twirl_kernel(long long B, int D, const cplx* __restrict__ chi, cplx* __restrict_
 }
 }  // namespace fbx
 
+// ---- partial trace of an operator on A (x) B (calculational.py:5-35 with two subsystems): keep = 0 traces out B,
+// keep = 1 traces out A.  Any dimensions; one thread per output entry.
+__global__ void __launch_bounds__(256)
+partial_trace2_kernel(int da, int db, int keep, long long B, const double* __restrict__ in, double* __restrict__ out) {
+    const int n = keep == 0 ? da : db, m = keep == 0 ? db : da;
+    const long long N = (long long)da * db;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * n * n) return;
+    const long long item = gid / ((long long)n * n);
+    const int r = (int)((gid / n) % n), c = (int)(gid % n);
+    const double* src = in + item * N * N * 2;
+    double re = 0.0, im = 0.0;
+    for (int k = 0; k < m; ++k) {
+        const long long row = keep == 0 ? (long long)r * db + k : (long long)k * db + r;
+        const long long col = keep == 0 ? (long long)c * db + k : (long long)k * db + c;
+        re += src[(row * N + col) * 2]; im += src[(row * N + col) * 2 + 1];
+    }
+    out[2 * gid] = re; out[2 * gid + 1] = im;
+}
+
 extern "C" {
 
 int fbx_kraus_pairs_dev(int tensor, int64_t B, int K2, int rows2, int cols2, int K1, int rows1, int cols1,
@@ -1289,6 +1309,33 @@ static int convert_general_check(int from_rep, int to_rep, int dim, int64_t B, c
     FBX_REQUIRE(B >= 0 && (B == 0 || (in && out)), "fbx_convert_general: bad batch / NULL buffer");
     FBX_REQUIRE(from_rep != FBX_REP_KRAUS || K >= 1, "fbx_convert_general: need K >= 1 Kraus operators");
     return FBX_OK;
+}
+
+int fbx_partial_trace_dev(int dim_a, int dim_b, int keep, int64_t B, const double* d_in, double* d_out) {
+    FBX_REQUIRE(dim_a >= 1 && dim_b >= 1 && (long long)dim_a * dim_b <= 4096, "fbx_partial_trace: dimensions must be >= 1 with dim_a * dim_b <= 4096");
+    FBX_REQUIRE(keep == 0 || keep == 1, "fbx_partial_trace: keep must be 0 (first subsystem) or 1 (second)");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_in && d_out)), "fbx_partial_trace: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const long long n = keep == 0 ? dim_a : dim_b, total = (long long)B * n * n;
+    hipLaunchKernelGGL(partial_trace2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(), dim_a, dim_b, keep,
+                       (long long)B, d_in, d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_partial_trace(int dim_a, int dim_b, int keep, int64_t B, const double* in, double* out) {
+    FBX_REQUIRE(dim_a >= 1 && dim_b >= 1 && (long long)dim_a * dim_b <= 4096, "fbx_partial_trace: dimensions must be >= 1 with dim_a * dim_b <= 4096");
+    FBX_REQUIRE(keep == 0 || keep == 1, "fbx_partial_trace: keep must be 0 (first subsystem) or 1 (second)");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (in && out)), "fbx_partial_trace: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t N = (size_t)dim_a * dim_b, n = keep == 0 ? dim_a : dim_b;
+    HostIO io; double *d_in, *d_out;
+    FBX_TRY(io.in(in, N * N * 2 * B, &d_in)); FBX_TRY(io.out(n * n * 2 * B, &d_out));
+    FBX_TRY(fbx_partial_trace_dev(dim_a, dim_b, keep, B, d_in, d_out));
+    FBX_TRY(io.back(out, d_out, n * n * 2 * B));
+    return io.sync();
 }
 
 int fbx_convert_general_dev(int from_rep, int to_rep, int dim, int64_t B, const double* d_in, int K, double* d_out) {

@@ -105,6 +105,8 @@ PROTOTYPES = {
     "fbx_eigh_dev": [C.c_int, _i64, _vp, _vp, _vp],
     "fbx_convert_general": [C.c_int, C.c_int, C.c_int, _i64, _dp, C.c_int, _dp],
     "fbx_convert_general_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
+    "fbx_partial_trace": [C.c_int, C.c_int, C.c_int, _i64, _dp, _dp],
+    "fbx_partial_trace_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, _vp],
     "fbx_set_option": [C.c_char_p, C.c_double],
     "fbx_get_option": [C.c_char_p, _dp],
     "fbx_pauli_vector": [C.c_int, _i64, _dp, _dp],
@@ -226,16 +228,17 @@ def iptr(a):
 
 
 def eigh_batch(a, eigenvectors=True):
-    """numpy.linalg.eigh semantics (lower triangle, ascending) for stacked [B, N, N], any N in 1..64
-    (the hot sizes are the powers of two; other sizes are zero-padded inside fbx_eigh).  Larger
-    matrices are outside this build: FbxError(FBX_ERR_UNSUPPORTED) -- there is no host fallback."""
+    """numpy.linalg.eigh semantics (lower triangle, ascending) for stacked [B, N, N], any N in 1..1024: up to
+    64 in LDS (the hot sizes are the powers of two; other sizes are zero-padded inside fbx_eigh), above that
+    with the matrix in HBM (4- and 5-qubit Choi matrices; slow but on the device).  Larger matrices:
+    FbxError(FBX_ERR_UNSUPPORTED) -- there is no host fallback."""
     a = c128(a)
     a = a.reshape((-1,) + a.shape[-2:])
     B, N = a.shape[0], a.shape[-1]
     if a.shape[-2] != N:
         raise ValueError("matrices must be square")
-    if N > 64:
-        raise FbxError(FBX_ERR_UNSUPPORTED, f"fbx_eigh handles N <= 64 (got {N}): matrices of more than 3 qubits "
+    if N > 1024:
+        raise FbxError(FBX_ERR_UNSUPPORTED, f"fbx_eigh handles N <= 1024 (got {N}): matrices of more than 5 qubits "
                                             f"are outside this build, and there is no host fallback")
     w = np.empty((B, N))
     v = np.empty((B, N, N), dtype=np.complex128) if eigenvectors else None

@@ -1,14 +1,28 @@
 """Small matrix helpers with the reference's names (forest/benchmarking/operator_tools/calculational.py).
 
-``sqrtm_psd`` goes through the device eigensolver (``fbx_eigh``); ``partial_trace`` for arbitrary
-subsystem lists is an index shuffle plus a trace and stays on the host (the two-subsystem partial
-trace the estimators need lives inside the kernels, csrc/fbx_choi.hpp ``partial_trace_out``).
+``sqrtm_psd`` goes through the device eigensolver (``fbx_eigh``); ``partial_trace`` of an operator on two
+subsystems runs on the device (``fbx_partial_trace``); for longer subsystem lists it is an index shuffle plus a
+trace and stays on the host (the partial trace the estimators need lives inside the kernels,
+csrc/fbx_choi.hpp ``partial_trace_out``).
 """
 import numpy as np
 
 from .. import _lib
 
-__all__ = ["partial_trace", "outer_product", "inner_product", "sqrtm_psd"]
+__all__ = ["partial_trace", "partial_trace_bipartite_batch", "outer_product", "inner_product", "sqrtm_psd"]
+
+
+def partial_trace_bipartite_batch(rho, dim_a: int, dim_b: int, keep: int) -> np.ndarray:
+    """Stack [B, dim_a dim_b, dim_a dim_b] of operators on A (x) B -> Tr_B (keep = 0) or Tr_A (keep = 1), on the device
+    (``fbx_partial_trace``)."""
+    x = _lib.c128(rho)
+    if x.ndim != 3 or x.shape[1] != dim_a * dim_b or x.shape[2] != dim_a * dim_b:
+        raise ValueError("rho must be [B, dim_a * dim_b, dim_a * dim_b]")
+    n = dim_a if keep == 0 else dim_b
+    out = np.empty((x.shape[0], n, n), dtype=np.complex128)
+    _lib.check(_lib.lib().fbx_partial_trace(int(dim_a), int(dim_b), int(keep), x.shape[0], _lib.dptr(x.view(np.float64)),
+                                            _lib.dptr(out.view(np.float64))))
+    return out
 
 
 def partial_trace(rho, keep, dims, optimize=False):
@@ -19,6 +33,8 @@ def partial_trace(rho, keep, dims, optimize=False):
     dims = [int(x) for x in np.asarray(dims).ravel()]
     kept = set(int(k) for k in np.asarray(keep).ravel())
     n = len(dims)
+    if n == 2 and len(kept) == 1 and kept <= {0, 1} and dims[0] * dims[1] <= 4096 and np.asarray(rho).shape == (dims[0] * dims[1],) * 2:
+        return partial_trace_bipartite_batch(np.asarray(rho)[None], dims[0], dims[1], next(iter(kept)))[0]
     t = np.asarray(rho).reshape(dims + dims)
     keep_axes = [i for i in range(n) if i in kept]
     drop_axes = [i for i in range(n) if i not in kept]

@@ -7,6 +7,7 @@ from typing import Sequence
 import numpy as np
 
 from .apply_superoperator import apply_choi_matrix_2_state
+from .calculational import partial_trace_bipartite_batch
 from .project_superoperators import proj_choi_to_trace_preserving
 from .superoperator_transformations import _kraus_stack, choi2kraus
 from .validate_operator import is_hermitian_matrix, is_identity_matrix, is_positive_semidefinite_matrix
@@ -33,6 +34,8 @@ def choi_is_trace_preserving(choi, rtol: float = 1e-05, atol: float = 1e-08) -> 
     on the device, so pt is read off its corner blocks."""
     choi = np.asarray(choi, dtype=np.complex128)
     dim = int(np.sqrt(choi.shape[0]))
+    if dim not in (2, 4, 8):                                    # beyond the 1-3 qubit projection kernels: Tr_out directly
+        return is_identity_matrix(partial_trace_bipartite_batch(choi[None], dim, dim, 0)[0], rtol, atol)
     diff = choi - proj_choi_to_trace_preserving(choi)          # kron((pt - I)/dim, I_dim)
     pt = diff[::dim, ::dim] * dim + np.eye(dim)
     return is_identity_matrix(pt, rtol, atol)
@@ -53,6 +56,9 @@ def choi_is_cptp(choi, rtol: float = 1e-05, atol: float = 1e-08) -> bool:
 def choi_is_unital(choi, rtol: float = 1e-05, atol: float = 1e-08) -> bool:
     """validate_superoperator.py:130-145."""
     dim = int(np.sqrt(np.asarray(choi).shape[0]))
+    if dim not in (2, 4, 8):                                    # the channel applied to the identity = Tr_in of the Choi matrix
+        out = partial_trace_bipartite_batch(np.asarray(choi, dtype=np.complex128)[None], dim, dim, 1)[0]
+        return is_identity_matrix(out, rtol, atol)
     out = apply_choi_matrix_2_state(np.asarray(choi, dtype=np.complex128), np.identity(dim, dtype=np.complex128))
     return is_identity_matrix(out, rtol, atol)
 

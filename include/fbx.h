@@ -361,10 +361,19 @@ int fbx_random_kraus(int n_qubits, int64_t B, int K, uint64_t seed, int64_t firs
 int fbx_random_kraus_dev(int n_qubits, int64_t B, int K, uint64_t seed, int64_t first_item,
                          double* d_kraus_out);
 
+/* partial_trace (calculational.py:5-35) of operators on A (x) B, any dimensions with dim_a * dim_b <= 4096:
+ * keep = 0 traces out B (out [B][dim_a][dim_a]), keep = 1 traces out A (out [B][dim_b][dim_b]); in is
+ * [B][dim_a dim_b][dim_a dim_b].  Tr_out of a Choi matrix (trace preservation, validate_superoperator.py:80-97)
+ * is keep = 0 with dim_a = dim_b = d; its action on the identity (unitality, :130-145) is keep = 1. */
+int fbx_partial_trace(int dim_a, int dim_b, int keep, int64_t B, const double* in, double* out);
+int fbx_partial_trace_dev(int dim_a, int dim_b, int keep, int64_t B, const double* d_in, double* d_out);
+
 /* Batched Hermitian eigendecomposition with numpy.linalg.eigh / scipy.linalg.eigh semantics (the
- * LOWER triangle of a[B][N][N] is read, eigenvalues ascending).  The host form takes any N in 1..64
- * (sizes that are not a power of two -- a qutrit, a 9 x 9 Choi matrix -- are embedded in the next
- * power of two with decoupled zero padding); the _dev form N in {2, 4, 8, 16, 32, 64}.  This is the
+ * LOWER triangle of a[B][N][N] is read, eigenvalues ascending).  The host form takes any N in 1..1024
+ * (up to 64: in LDS, sizes that are not a power of two -- a qutrit, a 9 x 9 Choi matrix -- embedded in the
+ * next power of two with decoupled zero padding; above 64: the same Jacobi with matrix and eigenvectors in
+ * HBM, one workgroup per matrix -- 4- and 5-qubit Choi matrices, not a fast path); the _dev form N in
+ * {2, 4, 8, 16, 32, 64} or even in 66..1024.  This is the
  * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators
  * (validate_operator.py:118-150), proj_choi_to_unitary (project_superoperators.py:147-175),
  * sqrtm_psd (calculational.py:77-91) and the spectral distance measures (distance_measures.py:153-195,440-460).

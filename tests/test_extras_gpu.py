@@ -137,3 +137,45 @@ def test_estimate_by_qubit_groups_batches_pairs(gpu):
     assert np.array_equal(got[(4, 5)], want45)
     lin = tomography.estimate_by_qubit_groups(results, [(0, 1)], kind="process", estimator="linear_inv")
     assert np.abs(lin[(0, 1)] - tomography.linear_inv_process_estimate(results[:design.m], [0, 1])).max() == 0
+
+
+@pytest.mark.parametrize("N", [66, 100, 129, 256])
+def test_eigh_beyond_lds_sizes(gpu, N):
+    """64 < N <= 1024: the HBM-resident Jacobi (csrc/fbx_state.hip eigh_big_kernel) with numpy.linalg.eigh
+    semantics -- lower triangle, ascending eigenvalues, A V = V diag(w), V unitary; odd sizes are padded."""
+    from fbx import _lib
+    rs = np.random.RandomState(N)
+    g = rs.randn(2, N, N) + 1j * rs.randn(2, N, N)
+    a = g + g.conj().transpose(0, 2, 1)
+    a[1] = np.tril(a[1]) + 1j * 0.5 * np.triu(np.ones((N, N)), 1)      # garbage above the diagonal must be ignored
+    w, v = _lib.eigh_batch(a)
+    for b in range(2):
+        low = np.tril(a[b]) + np.tril(a[b], -1).conj().T
+        low[np.diag_indices(N)] = low[np.diag_indices(N)].real
+        assert np.abs(w[b] - np.linalg.eigvalsh(low)).max() < 1e-11 * N
+        assert np.all(np.diff(w[b]) >= 0)
+        assert np.abs(low @ v[b] - v[b] * w[b]).max() < 1e-11 * N
+        assert np.abs(v[b].conj().T @ v[b] - np.eye(N)).max() < 1e-12 * N
+
+
+def test_four_qubit_choi_validators_and_kraus(gpu):
+    """What the large eigensolver unlocks: CP / CPTP checks and choi2kraus of a 256 x 256 Choi matrix, chi from a Choi."""
+    from fbx.operator_tools import (choi2kraus, choi_is_completely_positive, choi_is_cptp, kraus2choi)
+    rs = np.random.RandomState(44)
+    u, _ = np.linalg.qr(rs.randn(16, 16) + 1j * rs.randn(16, 16))
+    choi = kraus2choi(u)
+    assert choi_is_completely_positive(choi) and choi_is_cptp(choi)
+    ops = choi2kraus(choi)
+    assert len(ops) == 1
+    phase = np.vdot(u, ops[0]) / 16
+    assert abs(abs(phase) - 1) < 1e-10 and np.abs(ops[0] - phase * u).max() < 1e-9
+    assert not choi_is_completely_positive(choi - 0.1 * np.eye(256))
+    from fbx.operator_tools import choi_is_trace_preserving, choi_is_unital, rand_map_with_BCSZ_dist
+    from fbx.operator_tools.calculational import partial_trace
+    assert choi_is_unital(choi) and not choi_is_trace_preserving(choi + 0.01 * np.eye(256))
+    qutrit = rand_map_with_BCSZ_dist(3, 2)                           # 9 x 9: neither a qubit system nor a power of two
+    assert choi_is_trace_preserving(qutrit) and choi_is_cptp(qutrit) and not choi_is_unital(qutrit)
+    rho = rs.randn(12, 12) + 1j * rs.randn(12, 12)                   # operator on C^3 (x) C^4: both device partial traces
+    t = rho.reshape(3, 4, 3, 4)
+    assert np.abs(partial_trace(rho, [0], [3, 4]) - np.einsum("ajbj->ab", t)).max() < 1e-14
+    assert np.abs(partial_trace(rho, [1], [3, 4]) - np.einsum("iaib->ab", t)).max() < 1e-14

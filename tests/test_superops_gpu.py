@@ -216,9 +216,12 @@ def test_four_qubit_conversions_match_the_oracle(gpu):
                 got = st.convert_batch(src, dst, reps[src])
                 assert np.abs(got - reps[dst]).max() < 1e-11, (src, dst)
     assert np.abs(reps["pauli_liouville"].imag).max() < 1e-12                            # a PTM is real
-    for src in ("choi", "superop", "pauli_liouville"):                                   # routed through eigh in the reference
-        with pytest.raises(Exception):
+    for src in ("choi", "superop", "pauli_liouville"):                                   # routed through eigh in the reference:
+        with pytest.raises(Exception):                                                   # not in the batched kernel ...
             st.convert_batch(src, "chi", reps[src])
+    # ... but the reference-named functions take the reference's route (choi2kraus on the 256 x 256 eigensolver)
+    assert np.abs(st.choi2chi(reps["choi"][0]) - reps["chi"][0]).max() < 1e-9
+    assert np.abs(st.pauli_liouville2chi(reps["pauli_liouville"][1]) - reps["chi"][1]).max() < 1e-9
 
 
 def test_five_qubit_conversions(gpu):
