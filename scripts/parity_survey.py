@@ -22,3 +22,6 @@ for mode, key, kw in (("fixed-100", "fixed", dict(mode="fixed", max_iters=100)),
           f"dykstra mismatches {(st['dykstra'] != z[key + '_dyk']).sum()}  halving-count mismatches {(st['backtracks'] != z[key + '_bt']).sum()}"
           + (f"  iteration mismatches {(st['iterations'] != z['conv_it']).sum()}" if key == "conv" else "")
           + (f"  items above 1e-9: {[(FIRST + int(i), float('%.1e' % d[i])) for i in np.flatnonzero(d > 1e-9)]}" if key == "conv" and (d > 1e-9).any() else ""))
+    if key == "fixed":
+        top = np.argsort(-d)[:3]
+        print("      largest fixed-100 deviations:", [(FIRST + int(i), float('%.1e' % d[i]), int(st['backtracks'][i]), int(z['fixed_bt'][i])) for i in top], "(item, dev, halvings gpu, oracle)")
