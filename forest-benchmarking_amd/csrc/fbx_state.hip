@@ -705,6 +705,54 @@ static int launch_eigh_big(int N, int64_t B, const double* da, double* dw, doubl
     return FBX_OK;
 }
 
+// ---- out = op(A) diag(s) op(B) for stacks of N x N complex matrices, N up to 1024: the products around the large
+// eigensolver (V f(lambda) V^H of sqrtm_psd, calculational.py:77-91; sqrt(rho) sigma sqrt(rho) of fidelity,
+// distance_measures.py:64-84).  16 x 16 output tiles staged through LDS; a utility, not a tuned GEMM.
+__global__ void __launch_bounds__(256)
+matmul_kernel(int N, long long B, const double* __restrict__ a, int conj_t_a, const double* __restrict__ scale,
+              const double* __restrict__ b, int conj_t_b, double* __restrict__ out) {
+    __shared__ cplx As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles = (N + 15) / 16;
+    const long long item = blockIdx.x / (tiles * tiles);
+    const int tile = (int)(blockIdx.x % (tiles * tiles)), row0 = (tile / tiles) * 16, col0 = (tile % tiles) * 16;
+    const double* pa = a + item * (long long)N * N * 2;
+    const double* pb = b + item * (long long)N * N * 2;
+    double re = 0.0, im = 0.0;
+    for (int k0 = 0; k0 < N; k0 += 16) {
+        {   // As[ty][tx] = op(A)[row0 + ty][k0 + tx] * s[k0 + tx];  Bs[ty][tx] = op(B)[k0 + ty][col0 + tx]
+            const int r = row0 + ty, k = k0 + tx;
+            cplx v; v.re = 0.0; v.im = 0.0;
+            if (r < N && k < N) {
+                const long long idx = conj_t_a ? (long long)k * N + r : (long long)r * N + k;
+                v.re = pa[2 * idx]; v.im = conj_t_a ? -pa[2 * idx + 1] : pa[2 * idx + 1];
+                if (scale) { const double sc = scale[item * N + k]; v.re *= sc; v.im *= sc; }
+            }
+            As[ty][tx] = v;
+            const int kk = k0 + ty, c = col0 + tx;
+            cplx w; w.re = 0.0; w.im = 0.0;
+            if (kk < N && c < N) {
+                const long long idx = conj_t_b ? (long long)c * N + kk : (long long)kk * N + c;
+                w.re = pb[2 * idx]; w.im = conj_t_b ? -pb[2 * idx + 1] : pb[2 * idx + 1];
+            }
+            Bs[ty][tx] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const cplx x = As[ty][k], y = Bs[k][tx];
+            re += x.re * y.re - x.im * y.im;
+            im += x.re * y.im + x.im * y.re;
+        }
+        __syncthreads();
+    }
+    const int r = row0 + ty, c = col0 + tx;
+    if (r < N && c < N) {
+        double* o = out + (item * (long long)N * N + (long long)r * N + c) * 2;
+        o[0] = re; o[1] = im;
+    }
+}
+
 template <int N>
 static int launch_eigh(int64_t B, const double* da, double* dw, double* dv) {
     constexpr int NT = (N / 2) * (N / 2) > 64 ? (N / 2) * (N / 2) : 64;
@@ -931,6 +979,35 @@ int fbx_state_log_likelihood(const fbx_design* design, int64_t B, const double* 
     FBX_TRY(io.out((size_t)B, &dout));
     FBX_TRY(fbx_state_log_likelihood_dev(design, B, dr, de, dc, dout));
     FBX_TRY(io.back(ll_out, dout, (size_t)B));
+    return io.sync();
+}
+
+int fbx_matmul_dev(int N, int64_t B, const double* d_a, int conj_t_a, const double* d_scale, const double* d_b, int conj_t_b,
+                   double* d_out) {
+    FBX_REQUIRE(N >= 1 && N <= 1024, "fbx_matmul: N must be in 1..1024");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_a && d_b && d_out)), "fbx_matmul: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const long long tiles = (N + 15) / 16;
+    FBX_REQUIRE(B * tiles * tiles < (1LL << 31), "fbx_matmul: batch too large for one launch");
+    hipLaunchKernelGGL(matmul_kernel, dim3((unsigned)(B * tiles * tiles)), dim3(256), 0, stream(), N, (long long)B, d_a, conj_t_a,
+                       d_scale, d_b, conj_t_b, d_out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+int fbx_matmul(int N, int64_t B, const double* a, int conj_t_a, const double* scale, const double* b, int conj_t_b, double* out) {
+    FBX_REQUIRE(N >= 1 && N <= 1024, "fbx_matmul: N must be in 1..1024");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (a && b && out)), "fbx_matmul: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t nn = (size_t)N * N * 2 * B;
+    HostIO io; double *da, *db, *ds = nullptr, *dout;
+    FBX_TRY(io.in(a, nn, &da)); FBX_TRY(io.in(b, nn, &db));
+    if (scale) FBX_TRY(io.in(scale, (size_t)N * B, &ds));
+    FBX_TRY(io.out(nn, &dout));
+    FBX_TRY(fbx_matmul_dev(N, B, da, conj_t_a, ds, db, conj_t_b, dout));
+    FBX_TRY(io.back(out, dout, nn));
     return io.sync();
 }
 

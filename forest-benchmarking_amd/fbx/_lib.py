@@ -107,6 +107,8 @@ PROTOTYPES = {
     "fbx_convert_general_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
     "fbx_partial_trace": [C.c_int, C.c_int, C.c_int, _i64, _dp, _dp],
     "fbx_partial_trace_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, _vp],
+    "fbx_matmul": [C.c_int, _i64, _dp, C.c_int, _dp, _dp, C.c_int, _dp],
+    "fbx_matmul_dev": [C.c_int, _i64, _vp, C.c_int, _vp, _vp, C.c_int, _vp],
     "fbx_set_option": [C.c_char_p, C.c_double],
     "fbx_get_option": [C.c_char_p, _dp],
     "fbx_pauli_vector": [C.c_int, _i64, _dp, _dp],
@@ -244,6 +246,20 @@ def eigh_batch(a, eigenvectors=True):
     v = np.empty((B, N, N), dtype=np.complex128) if eigenvectors else None
     check(lib().fbx_eigh(N, B, dptr(a.view(np.float64)), dptr(w), dptr(v.view(np.float64)) if eigenvectors else None))
     return (w, v) if eigenvectors else w
+
+
+def matmul_batch(a, b, conj_t_a=False, conj_t_b=False, scale=None):
+    """op(a) diag(scale) op(b) for stacked [B, N, N] complex matrices on the device (fbx_matmul), N <= 1024."""
+    a, b = c128(a), c128(b)
+    a = a.reshape((-1,) + a.shape[-2:]); b = b.reshape((-1,) + b.shape[-2:])
+    if a.shape != b.shape or a.shape[-1] != a.shape[-2]:
+        raise ValueError("operands must be stacks of square matrices of one shape")
+    B, N = a.shape[0], a.shape[-1]
+    sc = None if scale is None else np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(B, N))
+    out = np.empty((B, N, N), dtype=np.complex128)
+    check(lib().fbx_matmul(N, B, dptr(a.view(np.float64)), int(bool(conj_t_a)), dptr(sc), dptr(b.view(np.float64)),
+                           int(bool(conj_t_b)), dptr(out.view(np.float64))))
+    return out
 
 
 class DeviceBuffer:

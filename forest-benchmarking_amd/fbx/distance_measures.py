@@ -42,12 +42,35 @@ def state_measures_batch(rho, sigma=None, which=("purity", "fidelity", "trace_di
         sig = rho if same else pad(sig)
         d = p
     if d > 8:
-        raise _lib.FbxError(_lib.FBX_ERR_UNSUPPORTED, "state measures: dimensions above 8 (3 qubits) are outside this build")
+        return _state_measures_large(rho, sig, which)
     outs = {k: np.empty(B) for k in which}
     _lib.check(_lib.lib().fbx_state_measures(
         _nq(d), B, _lib.dptr(rho.view(np.float64)), _lib.dptr(sig.view(np.float64)),
         _lib.dptr(outs.get("purity")), _lib.dptr(outs.get("fidelity")),
         _lib.dptr(outs.get("trace_distance")), _lib.dptr(outs.get("hs_ip"))))
+    return outs
+
+
+def _state_measures_large(rho, sig, which):
+    """Dimensions above 8 (4 and 5 qubits, up to 1024): the reference's formulas step by step on the generic device
+    primitives -- ``fbx_matmul`` for the products, ``fbx_eigh`` (HBM-resident above 64) for the matrix square roots
+    (distance_measures.py:14-36, 64-84, 100-114, 198-216).  The kernels of ``fbx_state_measures`` keep whole states
+    in LDS and stop at three qubits."""
+    from .operator_tools.calculational import sqrtm_psd_batch
+    if rho.shape[-1] > 1024:
+        raise _lib.FbxError(_lib.FBX_ERR_UNSUPPORTED, "state measures: dimensions above 1024 are outside this build")
+    outs = {}
+    if "purity" in which:
+        outs["purity"] = np.trace(_lib.matmul_batch(rho, rho), axis1=1, axis2=2).real
+    if "hs_ip" in which:
+        outs["hs_ip"] = np.trace(_lib.matmul_batch(rho, sig, conj_t_a=True), axis1=1, axis2=2).real
+    if "trace_distance" in which:                                  # half the induced 1-norm, as the reference has it
+        outs["trace_distance"] = 0.5 * np.abs(rho - sig).sum(axis=1).max(axis=1)
+    if "fidelity" in which:
+        root = sqrtm_psd_batch(rho)
+        inner = _lib.matmul_batch(_lib.matmul_batch(root, sig), root)
+        w = _lib.eigh_batch(inner, eigenvectors=False)              # tr sqrtm_psd(.) = sum of sqrt of the clipped eigenvalues
+        outs["fidelity"] = np.sqrt(np.maximum(w, 0)).sum(axis=1) ** 2
     return outs
 
 

@@ -66,10 +66,10 @@ def inner_product(bra1: np.ndarray, bra2: np.ndarray) -> complex:
 
 
 def sqrtm_psd_batch(matrices) -> np.ndarray:
-    """V sqrt(max(lambda, 0)) V^H for stacked Hermitian matrices [B, N, N], N in {2,...,64}."""
+    """V sqrt(max(lambda, 0)) V^H for stacked Hermitian matrices [B, N, N], N <= 1024: eigendecomposition and the
+    product both on the device (``fbx_eigh``, ``fbx_matmul``)."""
     w, v = _lib.eigh_batch(matrices)
-    w = np.sqrt(np.maximum(w, 0))
-    return np.einsum("bik,bk,bjk->bij", v, w, v.conj())
+    return _lib.matmul_batch(v, v, conj_t_b=True, scale=np.sqrt(np.maximum(w, 0)))
 
 
 def sqrtm_psd(matrix: np.ndarray, check_finite: bool = True) -> np.ndarray:

@@ -361,6 +361,14 @@ int fbx_random_kraus(int n_qubits, int64_t B, int K, uint64_t seed, int64_t firs
 int fbx_random_kraus_dev(int n_qubits, int64_t B, int K, uint64_t seed, int64_t first_item,
                          double* d_kraus_out);
 
+/* out[b] = op(a[b]) diag(scale[b]) op(b[b]) for stacks of N x N complex matrices, N in 1..1024: op = the matrix itself
+ * (conj_t = 0) or its conjugate transpose (conj_t = 1); scale is [B][N] real or NULL.  The products around fbx_eigh:
+ * V f(lambda) V^H (sqrtm_psd, calculational.py:77-91), sqrt(rho) sigma sqrt(rho) (fidelity, distance_measures.py:64-84). */
+int fbx_matmul(int N, int64_t B, const double* a, int conj_t_a, const double* scale, const double* b, int conj_t_b,
+               double* out);
+int fbx_matmul_dev(int N, int64_t B, const double* d_a, int conj_t_a, const double* d_scale, const double* d_b,
+                   int conj_t_b, double* d_out);
+
 /* partial_trace (calculational.py:5-35) of operators on A (x) B, any dimensions with dim_a * dim_b <= 4096:
  * keep = 0 traces out B (out [B][dim_a][dim_a]), keep = 1 traces out A (out [B][dim_b][dim_b]); in is
  * [B][dim_a dim_b][dim_a dim_b].  Tr_out of a Choi matrix (trace preservation, validate_superoperator.py:80-97)

@@ -179,3 +179,31 @@ def test_four_qubit_choi_validators_and_kraus(gpu):
     t = rho.reshape(3, 4, 3, 4)
     assert np.abs(partial_trace(rho, [0], [3, 4]) - np.einsum("ajbj->ab", t)).max() < 1e-14
     assert np.abs(partial_trace(rho, [1], [3, 4]) - np.einsum("iaib->ab", t)).max() < 1e-14
+
+
+def test_state_measures_for_four_and_five_qubits(gpu):
+    """16 x 16 and 32 x 32 states: purity, fidelity, trace distance, Hilbert-Schmidt product and the Bures quantities
+    against the oracle's restatement of the reference formulas; sqrtm_psd and the device matmul on the way."""
+    from fbx import distance_measures as dm, _lib
+    from fbx.operator_tools.calculational import sqrtm_psd
+    from fbx_oracle import measures as om
+    rs = np.random.RandomState(16)
+    for d in (16, 32):
+        g = rs.randn(2, d, d + 3) + 1j * rs.randn(2, d, d + 3)
+        rho, sigma = (x @ x.conj().T for x in g)
+        rho /= np.trace(rho).real; sigma /= np.trace(sigma).real
+        assert abs(dm.purity(rho) - om.purity(rho)) < 1e-13
+        assert abs(dm.purity(rho, dim_renorm=True) - om.purity(rho, dim_renorm=True)) < 1e-12
+        assert abs(dm.fidelity(rho, sigma) - om.fidelity(rho, sigma)) < 1e-11
+        assert abs(dm.fidelity(rho, rho) - 1.0) < 1e-11
+        assert abs(dm.trace_distance(rho, sigma) - om.trace_distance(rho, sigma)) < 1e-14
+        assert abs(dm.hilbert_schmidt_ip(rho, sigma) - om.hilbert_schmidt_ip(rho, sigma)) < 1e-13
+        assert abs(dm.bures_distance(rho, sigma) - om.bures_distance(rho, sigma)) < 1e-10
+        root = sqrtm_psd(rho)
+        assert np.abs(root @ root - rho).max() < 1e-12
+    a = rs.randn(3, 70, 70) + 1j * rs.randn(3, 70, 70)
+    b = rs.randn(3, 70, 70) + 1j * rs.randn(3, 70, 70)
+    sc = rs.rand(3, 70)
+    assert np.abs(_lib.matmul_batch(a, b) - a @ b).max() < 1e-11
+    want = np.einsum("bki,bk,bjk->bij", a.conj(), sc, b.conj())                  # A^H diag(s) B^H
+    assert np.abs(_lib.matmul_batch(a, b, conj_t_a=True, conj_t_b=True, scale=sc) - want).max() < 1e-11
