@@ -1,9 +1,10 @@
 """Channel application on MI355X (mirror of operator_tools/apply_superoperator.py).
 
-The device kernel (``fbx_apply_choi``) works on 2^n-dimensional spaces, n <= 3.  Other dimensions
+The device kernel (``fbx_apply_choi``) works on 2^n-dimensional spaces, n <= 3.  Other dimensions up to 8
 (a qutrit; the non-square Kraus operators of apply_superoperator.py:33-57) are embedded: operators are
 zero-padded to the next power of two, which changes neither Tr_in[(rho^T (x) 1) Choi] nor
-sum_k K rho K^H on the original block."""
+sum_k K rho K^H on the original block.  Dimensions 9..32 (4 and 5 qubits) take the reference's formula on the
+generic primitives (``fbx_matmul``, ``fbx_partial_trace``)."""
 import numpy as np
 
 from .. import _lib
@@ -37,8 +38,14 @@ def apply_choi_matrix_2_state_batch(choi, state) -> np.ndarray:
         raise ValueError("Dimensions of state and Choi matrix are incompatible")
     p = _pow2_at_least(d)
     if p > 8:
-        raise _lib.FbxError(_lib.FBX_ERR_UNSUPPORTED, "apply_choi_matrix_2_state: dimensions above 8 (3 qubits) "
-                                                      "are outside this build")
+        # 4 and 5 qubits (and anything else up to dimension 32): the reference's formula literally,
+        # Tr_in[Choi (rho^T (x) 1)] (apply_superoperator.py:87-90), on the generic device primitives
+        if d > 32:
+            raise _lib.FbxError(_lib.FBX_ERR_UNSUPPORTED, "apply_choi_matrix_2_state: dimensions above 32 (5 qubits) "
+                                                          "are outside this build")
+        from .calculational import partial_trace_bipartite_batch
+        lift = np.einsum("bji,kl->bikjl", s, np.eye(d)).reshape(s.shape[0], d * d, d * d)     # rho^T (x) 1
+        return partial_trace_bipartite_batch(_lib.matmul_batch(c, lift), d, d, 1)
     if p != d:
         c = _embed_choi(c, d, p)
         sp = np.zeros((s.shape[0], p, p), dtype=np.complex128)

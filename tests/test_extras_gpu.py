@@ -207,3 +207,29 @@ def test_state_measures_for_four_and_five_qubits(gpu):
     assert np.abs(_lib.matmul_batch(a, b) - a @ b).max() < 1e-11
     want = np.einsum("bki,bk,bjk->bij", a.conj(), sc, b.conj())                  # A^H diag(s) B^H
     assert np.abs(_lib.matmul_batch(a, b, conj_t_a=True, conj_t_b=True, scale=sc) - want).max() < 1e-11
+
+
+def test_channel_application_and_state_projection_beyond_three_qubits(gpu):
+    """apply_choi_matrix_2_state / apply_kraus_ops_2_state on 16-dimensional states and
+    project_state_matrix_to_physical for a qutrit, 4 and 5 qubits, against the oracle."""
+    from fbx.operator_tools import apply_choi_matrix_2_state, kraus2choi
+    from fbx.operator_tools.project_state_matrix import project_state_matrix_to_physical
+    from fbx_oracle import superops as so
+    rs = np.random.RandomState(23)
+    ks = rs.randn(2, 16, 16) + 1j * rs.randn(2, 16, 16)
+    g = rs.randn(16, 16) + 1j * rs.randn(16, 16)
+    rho = g @ g.conj().T; rho /= np.trace(rho)
+    choi = kraus2choi(list(ks))
+    want = sum(k @ rho @ k.conj().T for k in ks)
+    assert np.abs(apply_choi_matrix_2_state(choi, rho) - want).max() < 1e-11
+    assert np.abs(so.apply_choi_matrix_2_state(choi, rho) - want).max() < 1e-11
+    for d in (3, 16, 32):
+        h = rs.randn(d, d) + 1j * rs.randn(d, d)
+        h = h + h.conj().T
+        h = h / np.trace(h).real * 1.0
+        got = project_state_matrix_to_physical(h)
+        assert np.abs(got - so.project_state_matrix_to_physical(h)).max() < 1e-11
+        w = np.linalg.eigvalsh(got)
+        assert w.min() > -1e-12 and abs(np.trace(got) - 1) < 1e-12
+        good = h @ h.conj().T
+        assert np.abs(project_state_matrix_to_physical(good) - good / np.trace(good)).max() < 1e-14     # physical: only rescaled
