@@ -13,13 +13,67 @@ def proj_choi_batch(kind: int, choi, return_iters=False):
     x = x.reshape((-1,) + x.shape[-2:])
     B, D = x.shape[0], x.shape[-1]
     d = int(round(np.sqrt(D)))
+    if d * d != D or x.shape[-2] != D:
+        raise ValueError("Choi matrices must be d^2 x d^2")
     n = int(round(np.log2(d)))
-    if 4 ** n != D or x.shape[-2] != D:
-        raise ValueError("Choi matrices must be 4^n x 4^n")
+    if 2 ** n != d or n > 3:
+        return _proj_general(kind, x, d, return_iters)
     out = np.empty_like(x)
     iters = np.zeros(B, dtype=np.int32)
     _lib.check(_lib.lib().fbx_proj_choi(kind, n, B, _lib.dptr(x.view(np.float64)),
                                         _lib.dptr(out.view(np.float64)), _lib.iptr(iters)))
+    return (out, iters) if return_iters else out
+
+
+# ---- any other dimension (a qutrit's 9 x 9, the 256 x 256 of four qubits; up to 1024): the reference's algorithms
+# step by step, every eigendecomposition, matrix product and partial trace on the device (fbx_eigh -- HBM-resident
+# above 64 --, fbx_matmul, fbx_partial_trace); the Dykstra bookkeeping (differences, the scalar stopping rule) and
+# the Kronecker placement of a d x d correction are index work on the host.  The fused kernels stop at three qubits.
+def _cp_general(x):
+    herm = (x + x.conj().transpose(0, 2, 1)) / 2
+    w, v = _lib.eigh_batch(herm)
+    return _lib.matmul_batch(v, v, conj_t_b=True, scale=np.maximum(w, 0))
+
+
+def _tp_general(x, d, non_increasing=False):
+    from .calculational import partial_trace_bipartite_batch
+    pt = partial_trace_bipartite_batch(x, d, d, 0)
+    if non_increasing:                                          # project_superoperators.py:37-59
+        w, v = _lib.eigh_batch((pt + pt.conj().transpose(0, 2, 1)) / 2)
+        target = _lib.matmul_batch(v, v, conj_t_b=True, scale=np.minimum(w, 1))
+    else:                                                       # :62-84
+        target = np.broadcast_to(np.eye(d), pt.shape)
+    return x - np.einsum("bij,kl->bikjl", (pt - target) / d, np.eye(d)).reshape(x.shape)
+
+
+def _proj_general(kind, x, d, return_iters):
+    if x.shape[-1] > 1024:
+        raise _lib.FbxError(_lib.FBX_ERR_UNSUPPORTED, "Choi projections: dimensions above 1024 are outside this build")
+    iters = np.zeros(x.shape[0], dtype=np.int32)
+    if kind == _lib.PROJ_CP:
+        out = _cp_general(x)
+    elif kind in (_lib.PROJ_TP, _lib.PROJ_TNI):
+        out = _tp_general(x, d, kind == _lib.PROJ_TNI)
+    else:                                                       # Dykstra, :87-144, one item at a time
+        out = np.empty_like(x)
+        tni = kind == _lib.PROJ_PHYSICAL_TNI
+        for b in range(x.shape[0]):
+            old_cp = np.zeros_like(x[b]); old_tp = np.zeros_like(x[b]); last_cp = np.zeros_like(x[b])
+            last_state = x[b]
+            while True:
+                iters[b] += 1
+                pre_cp = last_state - old_cp
+                cp = _cp_general(pre_cp[None])[0]
+                new_cp = cp - pre_cp
+                pre_tp = cp - old_tp
+                new_state = _tp_general(pre_tp[None], d, tni)[0]
+                new_tp = new_state - pre_tp
+                crit = (np.linalg.norm(new_cp - old_cp) ** 2 + np.linalg.norm(new_tp - old_tp) ** 2
+                        + 2 * abs(np.vdot(old_tp, new_state - last_state)) + 2 * abs(np.vdot(old_cp, cp - last_cp)))
+                if not crit >= 1e-4:
+                    break
+                old_cp, old_tp, last_cp, last_state = new_cp, new_tp, cp, new_state
+            out[b] = new_state
     return (out, iters) if return_iters else out
 
 

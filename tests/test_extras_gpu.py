@@ -233,3 +233,29 @@ def test_channel_application_and_state_projection_beyond_three_qubits(gpu):
         assert w.min() > -1e-12 and abs(np.trace(got) - 1) < 1e-12
         good = h @ h.conj().T
         assert np.abs(project_state_matrix_to_physical(good) - good / np.trace(good)).max() < 1e-14     # physical: only rescaled
+
+
+def test_choi_projections_beyond_three_qubits_and_for_a_qutrit(gpu):
+    """CP / TP / TNI / physical (Dykstra) projections of 9 x 9 and 256 x 256 Choi matrices against the oracle, with
+    the oracle's Dykstra iteration counts.  (A 256 x 256 eigendecomposition takes 0.1 s on the one CU it runs on, so
+    the 4-qubit Dykstra case is one run from a mildly perturbed channel.)"""
+    from fbx.operator_tools import project_superoperators as ps
+    from fbx import _lib
+    from fbx_oracle import superops as so
+    rs = np.random.RandomState(31)
+    for d, noise in ((3, 0.05), (16, 1e-3)):
+        D = d * d
+        k = rs.randn(2, d, d) + 1j * rs.randn(2, d, d)
+        w, v = np.linalg.eigh(sum(q.conj().T @ q for q in k))
+        k = k @ (v @ np.diag(w ** -0.5) @ v.conj().T)                # a CPTP pair of Kraus operators
+        x = so.kraus2choi(list(k)) + noise * (rs.randn(D, D) + 1j * rs.randn(D, D))
+        assert np.abs(ps.proj_choi_to_completely_positive(x) - so.proj_choi_to_completely_positive(x)).max() < 1e-11
+        assert np.abs(ps.proj_choi_to_trace_preserving(x) - so.proj_choi_to_trace_preserving(x)).max() < 1e-13
+        assert np.abs(ps.proj_choi_to_trace_non_increasing(x) - so.proj_choi_to_trace_non_increasing(x)).max() < 1e-11
+        for tp, kind in ((True, _lib.PROJ_PHYSICAL_TP), (False, _lib.PROJ_PHYSICAL_TNI)):
+            if d > 3 and not tp:
+                continue
+            want, it = so.proj_choi_to_physical(x, tp, return_iters=True)
+            got, its = ps.proj_choi_batch(kind, x[None], return_iters=True)
+            assert its[0] == it and np.abs(got[0] - want).max() < 1e-10
+            assert d == 3 or it < 40
