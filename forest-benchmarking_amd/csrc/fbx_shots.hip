@@ -1,9 +1,10 @@
 // fbx_shots.hip -- shots -> observable moments (observable_estimation.py:804-853): a byte-stream
-// reduction.  One 256-thread workgroup per setting; every lane streams 16-byte pieces of the
-// [n_shots][n_qubits] 0/1 byte array (coalesced 4 KiB per workgroup-instruction), masks the
-// observable's columns, folds the bytes of each shot with XOR (parity = eigenvalue sign) and
-// counts the -1 outcomes with popcounts; integer counts are reduced through the wave and LDS.
-// HBM-bound integer work: n_qubits bytes per shot in, 16 bytes per setting out.
+// reduction.  Every lane streams 16-byte pieces of the [n_shots][n_qubits] 0/1 byte array (coalesced), masks the
+// observable's columns, folds the bytes of each shot with XOR (parity = eigenvalue sign) and counts the -1
+// outcomes with popcounts; integer counts are reduced through the wave (and LDS).  One WAVEFRONT per setting
+// while a setting's record is short (the usual 1000 shots x 2 qubits = 2 KB: four settings in flight per
+// workgroup and no barrier -- a workgroup per setting ran at 1.0 TB/s there), one 256-thread workgroup per
+// setting for long records.  HBM-bound integer work: n_qubits bytes per shot in, 16 bytes per setting out.
 #include "fbx_common.hpp"
 
 namespace fbx {
@@ -18,17 +19,17 @@ __device__ __forceinline__ int odd_shots(unsigned long long x) {
 }
 
 template <int NQB>      // NQB in {1, 2, 4, 8}: bytes per shot, 16-byte vector path
-__device__ long long count_minus_vec(const uint8_t* __restrict__ bits, long long n_shots, unsigned long long pat) {
+__device__ long long count_minus_vec(const uint8_t* __restrict__ bits, long long n_shots, unsigned long long pat, int tid, int nth) {
     const long long total = n_shots * NQB;
     const long long nvec = total / 16;
     const ulonglong2* v = reinterpret_cast<const ulonglong2*>(bits);
     long long cnt = 0;
-    for (long long i = threadIdx.x; i < nvec; i += blockDim.x) {
+    for (long long i = tid; i < nvec; i += nth) {
         const ulonglong2 w = v[i];
         cnt += odd_shots<NQB>(w.x & pat) + odd_shots<NQB>(w.y & pat);
     }
     // tail (fewer than 16 bytes): whole shots, byte-wise, by one lane
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         for (long long s = nvec * 16 / NQB; s < n_shots; ++s) {
             int par = 0;
             for (int q = 0; q < NQB; ++q) par ^= bits[s * NQB + q] & (int)((pat >> (8 * q)) & 1);
@@ -38,10 +39,54 @@ __device__ long long count_minus_vec(const uint8_t* __restrict__ bits, long long
     return cnt;
 }
 
-__device__ long long count_minus_generic(const uint8_t* __restrict__ bits, long long n_shots, int n,
-                                         const uint8_t* __restrict__ mask) {
+// Qubit counts that do not divide 16 (3, 5, 6, 7): every lane takes runs of 16 shots = 16 NQ bytes = 2 NQ 64-bit words,
+// masks the observable's columns with a pattern of period NQ laid over the run, and counts a shot as -1 when the
+// population of its byte range is odd (the bytes are 0 / 1).  Needs the record 8-byte aligned.
+template <int NQ>
+__device__ long long count_minus_packed(const uint8_t* __restrict__ bits, long long n_shots, const uint8_t* __restrict__ mask,
+                                        int tid, int nth) {
+    constexpr int W = 2 * NQ;                       // words per run of 16 shots
+    unsigned long long pat[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int byte = 0; byte < 8; ++byte) m |= (unsigned long long)(mask[(8 * w + byte) % NQ] ? 1 : 0) << (8 * byte);
+        pat[w] = m;
+    }
+    const long long runs = n_shots / 16;
+    const unsigned long long* v = reinterpret_cast<const unsigned long long*>(bits);
     long long cnt = 0;
-    for (long long s = threadIdx.x; s < n_shots; s += blockDim.x) {
+    for (long long r = tid; r < runs; r += nth) {
+        unsigned long long x[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) x[w] = v[r * W + w] & pat[w];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {              // shot j: bytes [j NQ, j NQ + NQ)
+            constexpr unsigned long long ALL = ~0ull;
+            const int lo = j * NQ, hi = lo + NQ - 1, w0 = lo >> 3, w1 = hi >> 3;
+            int pop;
+            if (w0 == w1) {
+                const unsigned long long m = (ALL >> (8 * (7 - (hi & 7)))) & (ALL << (8 * (lo & 7)));
+                pop = __popcll(x[w0] & m);
+            } else {
+                pop = __popcll(x[w0] & (ALL << (8 * (lo & 7)))) + __popcll(x[w1] & (ALL >> (8 * (7 - (hi & 7)))));
+            }
+            cnt += pop & 1;
+        }
+    }
+    for (long long s = runs * 16 + tid; s < n_shots; s += nth) {       // the last n_shots % 16 shots, byte-wise
+        int par = 0;
+        for (int q = 0; q < NQ; ++q) par ^= (bits[s * NQ + q] & 1) & (mask[q] ? 1 : 0);
+        cnt += par;
+    }
+    return cnt;
+}
+
+__device__ long long count_minus_generic(const uint8_t* __restrict__ bits, long long n_shots, int n,
+                                         const uint8_t* __restrict__ mask, int tid, int nth) {
+    long long cnt = 0;
+    for (long long s = tid; s < n_shots; s += nth) {
         int par = 0;
         for (int q = 0; q < n; ++q) par ^= (bits[s * n + q] & 1) & (mask[q] ? 1 : 0);
         cnt += par;
@@ -49,12 +94,16 @@ __device__ long long count_minus_generic(const uint8_t* __restrict__ bits, long 
     return cnt;
 }
 
+template <bool PER_WAVE>
 __global__ void __launch_bounds__(256)
 shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __restrict__ bits,
              const uint8_t* __restrict__ obs_mask, const double* __restrict__ coefs, int beta_prior,
              double* __restrict__ mean_out, double* __restrict__ var_out) {
     __shared__ long long part[4];
-    for (long long s = blockIdx.x; s < n_settings; s += gridDim.x) {
+    const int tid = PER_WAVE ? (threadIdx.x & 63) : threadIdx.x, nth = PER_WAVE ? 64 : 256;
+    const long long first = PER_WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
+    const long long stride = PER_WAVE ? (long long)gridDim.x * 4 : gridDim.x;
+    for (long long s = first; s < n_settings; s += stride) {
         const uint8_t* mk = obs_mask + s * n;
         const uint8_t* b = bits + s * n_shots * n;
         bool any = false;
@@ -65,22 +114,30 @@ shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __re
         if (any) {
             if ((n == 1 || n == 2 || n == 4 || n == 8) && aligned) {
                 for (int byte = 0; byte < 8; ++byte) pat |= (unsigned long long)(mk[byte % n] ? 1 : 0) << (8 * byte);
-                if (n == 1) cnt = count_minus_vec<1>(b, n_shots, pat);
-                else if (n == 2) cnt = count_minus_vec<2>(b, n_shots, pat);
-                else if (n == 4) cnt = count_minus_vec<4>(b, n_shots, pat);
-                else cnt = count_minus_vec<8>(b, n_shots, pat);
+                if (n == 1) cnt = count_minus_vec<1>(b, n_shots, pat, tid, nth);
+                else if (n == 2) cnt = count_minus_vec<2>(b, n_shots, pat, tid, nth);
+                else if (n == 4) cnt = count_minus_vec<4>(b, n_shots, pat, tid, nth);
+                else cnt = count_minus_vec<8>(b, n_shots, pat, tid, nth);
+            } else if ((n == 3 || n == 5 || n == 6 || n == 7) && ((uintptr_t)b & 7) == 0) {
+                if (n == 3) cnt = count_minus_packed<3>(b, n_shots, mk, tid, nth);
+                else if (n == 5) cnt = count_minus_packed<5>(b, n_shots, mk, tid, nth);
+                else if (n == 6) cnt = count_minus_packed<6>(b, n_shots, mk, tid, nth);
+                else cnt = count_minus_packed<7>(b, n_shots, mk, tid, nth);
             } else {
-                cnt = count_minus_generic(b, n_shots, n, mk);
+                cnt = count_minus_generic(b, n_shots, n, mk, tid, nth);
             }
         }
-        // wave reduction of the integer count (as two 32-bit halves of an exact double)
+        // wave reduction of the integer count (exact in a double: counts stay below 2^53)
         double c = (double)cnt;
         c = wave_sum(c);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (long long)c;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const long long n_minus = part[0] + part[1] + part[2] + part[3];
+        long long n_minus = (long long)c;
+        if (!PER_WAVE) {
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (long long)c;
+            __syncthreads();
+            n_minus = part[0] + part[1] + part[2] + part[3];
+        }
+        if (tid == 0) {
             const long long n_plus = n_shots - n_minus;
             const double coef = coefs ? coefs[s] : 1.0;
             double mean, var;
@@ -281,9 +338,16 @@ int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, 
     int rc = ensure_device();
     if (rc) return rc;
     if (n_settings == 0) return FBX_OK;
-    const unsigned grid = (unsigned)(n_settings < 256 * 16 ? n_settings : 256 * 16);
-    hipLaunchKernelGGL(shots_kernel, dim3(grid), dim3(256), 0, stream(), n_qubits, (long long)n_settings,
-                       (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out);
+    // short records (below 16 KB per setting): a wavefront per setting, four settings per workgroup
+    const bool per_wave = n_shots * n_qubits < 16384 && n_settings >= 4;
+    const int64_t units = per_wave ? (n_settings + 3) / 4 : n_settings;
+    const unsigned grid = (unsigned)(units < 256 * 16 ? units : 256 * 16);
+    if (per_wave)
+        hipLaunchKernelGGL(shots_kernel<true>, dim3(grid), dim3(256), 0, stream(), n_qubits, (long long)n_settings,
+                           (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out);
+    else
+        hipLaunchKernelGGL(shots_kernel<false>, dim3(grid), dim3(256), 0, stream(), n_qubits, (long long)n_settings,
+                           (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;
 }

@@ -48,3 +48,24 @@ def test_large_stream_exact_counts(gpu):
     par = (bits[0, :, 0] ^ bits[0, :, 1]).astype(np.int64)
     m = (shots - 2 * par.sum()) / shots
     assert mean[0] == m and abs(var[0] - (1 - m * m) / shots) < 1e-20
+
+
+@pytest.mark.parametrize("n,shots", [(3, 1000), (3, 1003), (5, 1000), (6, 24), (7, 1048), (2, 1000), (8, 40), (9, 1000), (3, 20000)])
+def test_every_counting_path_is_exact(gpu, n, shots):
+    """The wave-per-setting and workgroup-per-setting forms, the 16-byte path (n | 16), the packed path of
+    n = 3, 5, 6, 7 (runs of 16 shots + byte-wise tail) and the byte-wise fallback (n = 9; records that are not
+    8-byte aligned, shots = 1003): means equal numpy's to the last bit for every setting."""
+    from fbx import _lib
+    rs = np.random.RandomState(n * 1000 + shots)
+    S = 37
+    bits = rs.randint(0, 2, size=(S, shots, n)).astype(np.uint8)
+    mask = rs.randint(0, 2, size=(S, n)).astype(np.uint8)
+    mask[0] = 0                                                     # an identity term
+    mean, var = np.empty(S), np.empty(S)
+    _lib.check(_lib.lib().fbx_shots_to_moments(n, S, shots, bits.ctypes.data_as(_lib.C.POINTER(_lib.C.c_uint8)),
+                                               mask.ctypes.data_as(_lib.C.POINTER(_lib.C.c_uint8)), None, 0,
+                                               _lib.dptr(mean), _lib.dptr(var)))
+    prod = np.where(mask[:, None, :] != 0, 1 - 2 * bits.astype(np.int64), 1).prod(axis=2)
+    want = prod.sum(axis=1) / shots
+    assert np.array_equal(mean, want)
+    assert np.allclose(var[1:], (1 - want[1:] ** 2) / shots, rtol=1e-15, atol=0) and var[0] == 0.0
