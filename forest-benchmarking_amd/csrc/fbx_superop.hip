@@ -226,14 +226,19 @@ __device__ void store_matrix(const cplx* m, double* __restrict__ g, int lane) {
 // ---------------------------------------------------------------------------------------------
 // fbx_convert
 // ---------------------------------------------------------------------------------------------
-template <int NQ>
+// EIGH = false: the conversions that never pass through choi2kraus need no eigensolver arrays -- 10 KB instead of
+// 23 KB of LDS per wavefront (2 qubits), i.e. 15 instead of 6 wavefronts per CU on a kernel that only waits for HBM.
+template <int NQ, bool EIGH = true>
 __global__ void __launch_bounds__(64)
 convert_kernel(int from, int to, long long B, const double* __restrict__ in, int K, double* __restrict__ out) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* p = smem;
-    ChoiLds<NQ> L; L.carve(p);
-    p = smem + ((ChoiLds<NQ>::bytes() + 15) & ~(size_t)15);      // (no pointer -> integer -> pointer: keeps the LDS address space)
+    ChoiLds<NQ> L;
+    if constexpr (EIGH) {
+        L.carve(p);
+        p = smem + ((ChoiLds<NQ>::bytes() + 15) & ~(size_t)15);  // (no pointer -> integer -> pointer: keeps the LDS address space)
+    }
     cplx* A = (cplx*)p; p += sizeof(cplx) * D * LD;
     cplx* Bm = (cplx*)p; p += sizeof(cplx) * D * LD;
     cplx* kb = (cplx*)p;
@@ -262,7 +267,7 @@ convert_kernel(int from, int to, long long B, const double* __restrict__ in, int
         } else if (rep == FBX_REP_CHOI) {
             if (to == FBX_REP_CHI) {
                 if (!kraus_chi) {                       // through choi2kraus (eigh, |C|, tol 1e-9)
-                    abs_via_eigh<NQ>(cur, nxt, L, 1e-9, lane); swap();
+                    if constexpr (EIGH) { abs_via_eigh<NQ>(cur, nxt, L, 1e-9, lane); swap(); }
                 }
                 to_pauli_sites<NQ>(cur, nxt, inv_d * inv_d, lane); swap(); rep = FBX_REP_CHI;
             } else {
@@ -284,9 +289,10 @@ convert_kernel(int from, int to, long long B, const double* __restrict__ in, int
 template <int NQ>
 static int launch_convert(int from, int to, int64_t B, const double* in, int K, double* out) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    const size_t lds = ChoiLds<NQ>::bytes() + 16 + sizeof(cplx) * (2 * D * LD + (size_t)(K > 0 ? K : 1) * D);
+    const bool eigh = to == FBX_REP_CHI && from != FBX_REP_KRAUS;
+    const size_t lds = (eigh ? ChoiLds<NQ>::bytes() + 16 : 0) + sizeof(cplx) * (2 * D * LD + (size_t)(K > 0 ? K : 1) * D);
     if (lds > 160 * 1024) { set_error("fbx_convert: too many Kraus operators for LDS staging"); return FBX_ERR_UNSUPPORTED; }
-    auto kern = convert_kernel<NQ>;
+    auto kern = eigh ? convert_kernel<NQ, true> : convert_kernel<NQ, false>;
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream(), from, to, (long long)B, in, K, out);
     FBX_HIP(hipGetLastError());
