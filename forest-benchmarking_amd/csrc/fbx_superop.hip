@@ -962,11 +962,9 @@ static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm
 // fbx_proj_choi
 // ---------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ void __launch_bounds__(64)
-proj_choi_kernel(int kind, long long B, const double* __restrict__ in, double* __restrict__ out,
-                 int* __restrict__ iters_out) {
+__device__ __forceinline__ void proj_choi_body(char* smem, int kind, long long B, const double* __restrict__ in,
+                                               double* __restrict__ out, int* __restrict__ iters_out) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* p = smem;
     ChoiLds<NQ> L; L.carve(p);
     PhaseClock pc; pc.reset(); L.pc = &pc;
@@ -987,6 +985,21 @@ proj_choi_kernel(int kind, long long B, const double* __restrict__ in, double* _
     __syncthreads();
     store_matrix<NQ>(L.Mw, out + item * (long long)D * D * 2, lane);
     if (lane == 0 && iters_out) iters_out[item] = iters;
+}
+// one wavefront per SIMD (every register the Dykstra state wants: 324 for two qubits) ...
+template <int NQ>
+__global__ void __launch_bounds__(64)
+proj_choi_kernel(int kind, long long B, const double* __restrict__ in, double* __restrict__ out, int* __restrict__ iters_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    proj_choi_body<NQ>(smem, kind, B, in, out, iters_out);
+}
+// ... or two per SIMD (at most 256 registers) for batches that put several items on a SIMD anyway: two dependent
+// Jacobi chains interleave, as in pgdb_lean_kernel.  Same arithmetic, same results.
+template <int NQ>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+proj_choi_w2_kernel(int kind, long long B, const double* __restrict__ in, double* __restrict__ out, int* __restrict__ iters_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    proj_choi_body<NQ>(smem, kind, B, in, out, iters_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1427,7 +1440,10 @@ int fbx_proj_choi_dev(int proj_kind, int n_qubits, int64_t B, const double* d_ch
         hipLaunchKernelGGL(proj_choi_kernel<1>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_choi, d_out, d_iters_out);
     } else {
         const size_t lds = ChoiLds<2>::bytes() + 64;
-        hipLaunchKernelGGL(proj_choi_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_choi, d_out, d_iters_out);
+        if (B >= 2048)
+            hipLaunchKernelGGL(proj_choi_w2_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_choi, d_out, d_iters_out);
+        else
+            hipLaunchKernelGGL(proj_choi_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream(), proj_kind, (long long)B, d_choi, d_out, d_iters_out);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
