@@ -11,6 +11,7 @@
 //   purity / fidelity / trace_distance / hilbert_schmidt_ip   distance_measures.py:14-114,198-216
 //   sqrtm_psd                        operator_tools/calculational.py:77-91
 #include "fbx_eigh.hpp"
+#include <hip/hip_cooperative_groups.h>
 #include <cfloat>
 #include <cstdlib>
 #include <algorithm>
@@ -690,6 +691,127 @@ eigh_big_kernel(int N, long long B, const double* __restrict__ a, double* __rest
     }
 }
 
+// ---- the same decomposition with ONE matrix spread over the chip: a cooperative launch (every workgroup resident),
+// each workgroup takes a share of the 2 x 2 blocks of a round, computes the round's N/2 rotations for itself (they
+// are cheap and every block needs two of them), and a grid-wide barrier separates the rounds.  One CU moves the
+// 4 N^2 x 16 bytes of a round at ~85 GB/s; the chip moves them at L2 / HBM speed, so the barrier (a few microseconds)
+// becomes the cost of a round.  hipLaunchCooperativeKernel refuses a grid that cannot be co-resident, in which case
+// (or with FBX_EIGH_NO_COOP in the environment) the single-workgroup kernel above takes over.
+__global__ void __launch_bounds__(256)
+eigh_coop_kernel(int N, const double* __restrict__ a, double* __restrict__ w_out, double* __restrict__ v_out,
+                 cplx* __restrict__ work, double* __restrict__ partial) {
+    namespace cg = cooperative_groups;
+    cg::grid_group grid = cg::this_grid();
+    constexpr int NT = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* rot = (double*)smem;                 // [N/2][4]
+    double* red = rot + 2 * N;                   // [16]
+    const int t = threadIdx.x, NB = N / 2, G = gridDim.x, g = blockIdx.x;
+    const size_t NN = (size_t)N * N;
+    cplx* M0 = work; cplx* M1 = M0 + NN; cplx* V0 = M1 + NN; cplx* V1 = V0 + NN;
+    for (size_t idx = (size_t)g * NT + t; idx < NN; idx += (size_t)G * NT) {
+        const int r = (int)(idx / N), c = (int)(idx % N);
+        cplx h, v;
+        if (r > c) { h.re = a[2 * idx]; h.im = a[2 * idx + 1]; }
+        else if (r < c) { h.re = a[2 * ((size_t)c * N + r)]; h.im = -a[2 * ((size_t)c * N + r) + 1]; }
+        else { h.re = a[2 * idx]; h.im = 0.0; }
+        v.re = r == c ? 1.0 : 0.0; v.im = 0.0;
+        M0[idx] = h; V0[idx] = v;
+    }
+    grid.sync();
+    cplx *Mc = M0, *Mn = M1, *Vc = V0, *Vn = V1;
+    for (int sweep = 0; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
+        double o2 = 0.0, n2 = 0.0;
+        for (size_t idx = (size_t)g * NT + t; idx < NN; idx += (size_t)G * NT) {
+            const cplx v = Mc[idx];
+            const double a2 = v.re * v.re + v.im * v.im;
+            n2 += a2;
+            if (idx / N != idx % N) o2 += a2;
+        }
+        block_sum2<NT>(o2, n2, red);
+        if (t == 0) { partial[2 * g] = o2; partial[2 * g + 1] = n2; }
+        grid.sync();
+        o2 = 0.0; n2 = 0.0;
+        for (int k = 0; k < G; ++k) { o2 += partial[2 * k]; n2 += partial[2 * k + 1]; }      // same order in every workgroup
+        grid.sync();                                  // `partial` is rewritten at the next sweep
+        if (!(o2 > FBX_JACOBI_TOL2 * n2)) break;
+        for (int r = 0; r < N - 1; ++r) {
+            for (int p = t; p < NB; p += NT) {
+                const cplx b = Mc[(size_t)(2 * p) * N + 2 * p + 1];
+                const JRot q = jacobi_rotation(Mc[(size_t)(2 * p) * N + 2 * p].re, Mc[(size_t)(2 * p + 1) * N + 2 * p + 1].re, b.re, b.im);
+                rot[4 * p] = q.c; rot[4 * p + 1] = q.sr; rot[4 * p + 2] = q.si;
+            }
+            __syncthreads();
+            for (int blk = g * NT + t; blk < NB * NB; blk += G * NT) {
+                const int I = blk / NB, J = blk % NB;
+                const size_t r0 = (size_t)(2 * I) * N + 2 * J, r1 = r0 + N;
+                cplx m00 = Mc[r0], m01 = Mc[r0 + 1], m10 = Mc[r1], m11 = Mc[r1 + 1];
+                cplx v0p = Vc[r0], v0q = Vc[r0 + 1], v1p = Vc[r1], v1q = Vc[r1 + 1];
+                const double cJ = rot[4 * J], sJr = rot[4 * J + 1], sJi = rot[4 * J + 2];
+                jacobi_apply_m(rot[4 * I], rot[4 * I + 1], rot[4 * I + 2], cJ, sJr, sJi, m00, m01, m10, m11);
+                jacobi_apply_v(cJ, sJr, sJi, v0p, v0q, v1p, v1q);
+                if (I == J) { m01.re = m01.im = 0.0; m10.re = m10.im = 0.0; m00.im = 0.0; m11.im = 0.0; }
+                const size_t ra = (size_t)jacobi_seat_rt(NB, 2 * I) * N, rb = (size_t)jacobi_seat_rt(NB, 2 * I + 1) * N;
+                const int ca = jacobi_seat_rt(NB, 2 * J), cb = jacobi_seat_rt(NB, 2 * J + 1);
+                Mn[ra + ca] = m00; Mn[ra + cb] = m01; Mn[rb + ca] = m10; Mn[rb + cb] = m11;
+                const size_t va = (size_t)(2 * I) * N, vb = va + N;
+                Vn[va + ca] = v0p; Vn[va + cb] = v0q; Vn[vb + ca] = v1p; Vn[vb + cb] = v1q;
+            }
+            grid.sync();
+            cplx* q = Mc; Mc = Mn; Mn = q; q = Vc; Vc = Vn; Vn = q;
+        }
+    }
+    // eigenvalues ascending, eigenvectors as columns in that order (ranks recomputed by every thread that needs one)
+    for (size_t idx = (size_t)g * NT + t; idx < (size_t)N; idx += (size_t)G * NT) {
+        const int k = (int)idx;
+        const double lk = Mc[(size_t)k * N + k].re;
+        int rank = 0;
+        for (int j = 0; j < N; ++j) { const double lj = Mc[(size_t)j * N + j].re; rank += (lj < lk) || (lj == lk && j < k); }
+        w_out[rank] = lk;
+        partial[2 * G + k] = (double)rank;            // column k goes to column `rank`
+    }
+    grid.sync();
+    if (v_out) {
+        for (size_t idx = (size_t)g * NT + t; idx < NN; idx += (size_t)G * NT) {
+            const int r = (int)(idx / N), k = (int)(idx % N);
+            const cplx v = Vc[idx];
+            double* o = v_out + ((size_t)r * N + (int)partial[2 * G + k]) * 2;
+            o[0] = v.re; o[1] = v.im;
+        }
+    }
+}
+
+static int launch_eigh_coop(int N, int64_t B, const double* da, double* dw, double* dv, bool* done) {
+    *done = false;
+    if (getenv("FBX_EIGH_NO_COOP")) return FBX_OK;
+    int dev = current_device(), coop = 0, cus = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) { (void)hipGetLastError(); return FBX_OK; }
+    FBX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const size_t lds = sizeof(double) * (2 * (size_t)N + 16);
+    int per_cu = 0;
+    FBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eigh_coop_kernel, 256, lds));
+    if (per_cu < 1) return FBX_OK;
+    const long long blocks_needed = ((long long)(N / 2) * (N / 2) + 255) / 256;
+    long long G = std::min<long long>(blocks_needed, (long long)cus * std::min(per_cu, 2));
+    if (G < 2) return FBX_OK;
+    const size_t NN = (size_t)N * N;
+    void* w = nullptr;
+    { const int rc = workspace(WS_CONVERT, 4 * NN * sizeof(cplx) + sizeof(double) * (2 * (size_t)G + N), &w); if (rc) return rc; }
+    cplx* work = (cplx*)w;
+    double* partial = (double*)(work + 4 * NN);
+    for (int64_t b = 0; b < B; ++b) {
+        const double* a = da + b * NN * 2;
+        double* wo = dw + b * N;
+        double* vo = dv ? dv + b * NN * 2 : nullptr;
+        int n_arg = N;
+        void* args[] = {&n_arg, (void*)&a, (void*)&wo, (void*)&vo, (void*)&work, (void*)&partial};
+        const hipError_t e = hipLaunchCooperativeKernel((const void*)eigh_coop_kernel, dim3((unsigned)G), dim3(256), args, (unsigned)lds, stream());
+        if (e != hipSuccess) { (void)hipGetLastError(); if (b == 0) return FBX_OK; return hip_fail(e, "hipLaunchCooperativeKernel", __FILE__, __LINE__); }
+    }
+    *done = true;
+    return FBX_OK;
+}
+
 static int launch_eigh_big(int N, int64_t B, const double* da, double* dw, double* dv) {
     const size_t lds = sizeof(double) * (2 * (size_t)N + N + 64) + sizeof(int) * N;
     const size_t per_item = 4 * (size_t)N * N * sizeof(cplx);
@@ -1017,7 +1139,14 @@ int fbx_eigh_dev(int N, int64_t B, const double* d_a, double* d_w_out, double* d
     FBX_REQUIRE(B >= 0 && (B == 0 || (d_a && d_w_out)), "fbx_eigh: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    if (N > 64) return launch_eigh_big(N, B, d_a, d_w_out, d_v_out);
+    if (N > 64) {
+        // few large matrices: one at a time over the whole chip; many: one CU each
+        // (measured: one CU per matrix 14 / 108 / 1270 / 9300 ms for N = 128 / 256 / 512 / 1024, whatever the batch up to
+        // the number of CUs; the whole chip on one matrix 6 / 25 / 200 / 820 ms each)
+        const int64_t coop_up_to = N >= 768 ? 10 : N >= 384 ? 5 : 3;
+        if (N >= 128 && B <= coop_up_to) { bool done = false; FBX_TRY(launch_eigh_coop(N, B, d_a, d_w_out, d_v_out, &done)); if (done) return FBX_OK; }
+        return launch_eigh_big(N, B, d_a, d_w_out, d_v_out);
+    }
     switch (N) {
         case 2: FBX_TRY(launch_eigh<2>(B, d_a, d_w_out, d_v_out)); break;
         case 4: FBX_TRY(launch_eigh<4>(B, d_a, d_w_out, d_v_out)); break;

@@ -380,7 +380,8 @@ int fbx_partial_trace_dev(int dim_a, int dim_b, int keep, int64_t B, const doubl
  * LOWER triangle of a[B][N][N] is read, eigenvalues ascending).  The host form takes any N in 1..1024
  * (up to 64: in LDS, sizes that are not a power of two -- a qutrit, a 9 x 9 Choi matrix -- embedded in the
  * next power of two with decoupled zero padding; above 64: the same Jacobi with matrix and eigenvectors in
- * HBM, one workgroup per matrix -- 4- and 5-qubit Choi matrices, not a fast path); the _dev form N in
+ * HBM -- one workgroup per matrix for batches, a cooperative launch over the whole chip for a few matrices; 4- and
+ * 5-qubit Choi matrices, not a fast path: 25 ms for 256 x 256, 0.8 s for 1024 x 1024); the _dev form N in
  * {2, 4, 8, 16, 32, 64} or even in 66..1024.  This is the
  * primitive under choi2kraus (superoperator_transformations.py:325-336), the PSD validators
  * (validate_operator.py:118-150), proj_choi_to_unitary (project_superoperators.py:147-175),
