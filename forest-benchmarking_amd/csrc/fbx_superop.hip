@@ -521,8 +521,79 @@ convert_general_kernel(int from, int to, int d, long long B, const double* __res
     out[2 * gid] = re; out[2 * gid + 1] = im;
 }
 
+// ---- 3 qubits, the routes between Choi / superoperator / Pauli-Liouville: ONE 64 KB matrix in LDS instead of two,
+// so that two workgroups share a CU and the HBM loads / stores of one overlap the butterfly stages of the other.
+// The reshuffle rides on the global load (forward) or store (backward) as an index permutation, the bit-permuting
+// copy of the site-factored transform on the other side.  ROUTE: 0 choi->PL, 1 PL->choi, 2 superop->PL, 3 PL->superop,
+// 4 choi<->superop (pure permutation, no LDS).
+template <int ROUTE>
+__global__ void __launch_bounds__(1024)
+convert3_fast_kernel(long long B, const double* __restrict__ in, double* __restrict__ out) {
+    constexpr int NQ = 3, d = 8, D = 64, LD = 64, NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* X = (cplx*)smem;
+    const int t = threadIdx.x;
+    const double inv_d = 1.0 / d;
+    for (long long item = blockIdx.x; item < B; item += gridDim.x) {
+        const double* src = in + item * (long long)D * D * 2;
+        double* dst = out + item * (long long)D * D * 2;
+        auto shuffled = [](int idx) {                      // entry (p,q),(r,s) <- entry (s,q),(r,p): its own inverse
+            const int row = idx / D, col = idx % D;
+            const int p = row / d, q = row % d, r = col / d, s_ = col % d;
+            return (s_ * d + q) * D + r * d + p;
+        };
+        if (ROUTE == 4) {
+            for (int idx = t; idx < D * D; idx += NT) { const int j = shuffled(idx); dst[2 * idx] = src[2 * j]; dst[2 * idx + 1] = src[2 * j + 1]; }
+            continue;
+        }
+        __syncthreads();                                   // the previous item's readers of X are done
+        if (ROUTE == 0 || ROUTE == 2) {                    // -> Pauli-Liouville: (reshuffled) load, stages, permuted scaled store
+            for (int idx = t; idx < D * D; idx += NT) {
+                const int j = ROUTE == 0 ? shuffled(idx) : idx;
+                cplx v; v.re = src[2 * j]; v.im = src[2 * j + 1];
+                X[idx] = v;
+            }
+            __syncthreads();
+            site_stages<NQ, false, NT, LD>(X, t);
+            for (int idx = t; idx < D * D; idx += NT) {
+                const cplx v = X[site_index<NQ>(idx / D) * LD + site_index<NQ>(idx % D)];
+                dst[2 * idx] = v.re * inv_d; dst[2 * idx + 1] = v.im * inv_d;
+            }
+        } else {                                           // Pauli-Liouville ->: permuted scaled load, inverse stages, (reshuffled) store
+            const double sc = inv_d * D;
+            for (int idx = t; idx < D * D; idx += NT) {
+                cplx v; v.re = src[2 * idx] * sc; v.im = src[2 * idx + 1] * sc;
+                X[site_index<NQ>(idx / D) * LD + site_index<NQ>(idx % D)] = v;
+            }
+            __syncthreads();
+            site_stages<NQ, true, NT, LD>(X, t);
+            for (int idx = t; idx < D * D; idx += NT) {
+                const cplx v = X[ROUTE == 1 ? shuffled(idx) : idx];
+                dst[2 * idx] = v.re; dst[2 * idx + 1] = v.im;
+            }
+        }
+    }
+}
+template <int ROUTE>
+static int launch_convert3_fast(int64_t B, const double* in, double* out) {
+    const size_t lds = ROUTE == 4 ? 0 : sizeof(cplx) * 64 * 64;
+    auto kern = convert3_fast_kernel<ROUTE>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)(B < 512 * 8 ? B : 512 * 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream(), (long long)B, in, out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 static int launch_convert3(int from, int to, int64_t B, const double* in, int K, double* out) {
     constexpr size_t D = 64;
+#ifndef FBX_CONVERT3_GENERAL_ONLY
+    if (from == FBX_REP_CHOI && to == FBX_REP_PAULI_LIOUVILLE) return launch_convert3_fast<0>(B, in, out);
+    if (from == FBX_REP_PAULI_LIOUVILLE && to == FBX_REP_CHOI) return launch_convert3_fast<1>(B, in, out);
+    if (from == FBX_REP_SUPEROP && to == FBX_REP_PAULI_LIOUVILLE) return launch_convert3_fast<2>(B, in, out);
+    if (from == FBX_REP_PAULI_LIOUVILLE && to == FBX_REP_SUPEROP) return launch_convert3_fast<3>(B, in, out);
+    if ((from == FBX_REP_CHOI && to == FBX_REP_SUPEROP) || (from == FBX_REP_SUPEROP && to == FBX_REP_CHOI)) return launch_convert3_fast<4>(B, in, out);
+#endif
     const size_t lds = 2 * sizeof(cplx) * D * D + sizeof(double) * 128 + sizeof(cplx) * (size_t)(K > 0 ? K : 1) * D;
     if (lds > 160 * 1024) { set_error("fbx_convert: too many Kraus operators for LDS staging (3 qubits: at most 31)"); return FBX_ERR_UNSUPPORTED; }
     FBX_HIP(hipFuncSetAttribute((const void*)convert3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
