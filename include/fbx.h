@@ -24,8 +24,10 @@
  *    asynchronous on the library stream until fbx_synchronize().
  *  - column-stacking vec; un-normalised Choi on H_in (x) H_out; n-qubit Pauli order
  *    itertools.product('IXYZ', repeat=n) with qubits[0] the left-most tensor factor.
- *  - qubit counts: every matrix entry point takes 1..3 qubits (fbx_kraus_sweep is one fused
- *    kernel for 1..2 and a composition of the pairwise conversions for 3).
+ *  - sizes: the estimators, projections, state measures and channel application take 1..3 qubits
+ *    (fbx_kraus_sweep is one fused kernel for 1..2 and a composition of the pairwise conversions for 3);
+ *    fbx_convert and fbx_process_fidelity 1..5 qubits; fbx_eigh / fbx_matmul any N <= 1024;
+ *    fbx_convert_general and fbx_partial_trace any dimension (each entry point states its own range).
  *  - label codes: one-qubit input states 0:X+ 1:X- 2:Y+ 3:Y- 4:Z+ 5:Z- 6:SIC0 7:SIC1
  *    8:SIC2 9:SIC3; one-qubit Paulis 0:I 1:X 2:Y 3:Z.
  */
