@@ -1148,30 +1148,54 @@ static int launch_sweep3(int64_t B, int K, const double* kraus, const double* pt
 // linear_inv_process_estimate (tomography.py:459-491): R[i][:] = pinv(Abar_i) e_i, Choi by the
 // inverse Pauli transform, plus the explicit identity term I_D / d (tomography.py:491)
 // ---------------------------------------------------------------------------------------------
-template <int NQ>
+// ITEMS experiments per wavefront: a row of the block pseudo-inverses (540 x 16 doubles for two qubits, more than the
+// L1 holds) is loaded once and used for all of them -- one experiment per wavefront ran at the L2's pace (6.8e7 /s).
+// Every experiment's sums run over the same settings in the same order as before.
+template <int NQ, int ITEMS>
 __global__ void __launch_bounds__(64)
 linv_process_kernel(DesignDev des, long long B, const double* __restrict__ expect, double* __restrict__ out) {
-    constexpr int d = 1 << NQ, D = d * d, NB = D / 2;
+    constexpr int d = 1 << NQ, D = d * d, NB = D / 2, PER = (D * D + 63) / 64;
     __shared__ double Rb[D * D];
     __shared__ cplx Mw[D * (D + 1)];
     const int lane = threadIdx.x;
-    const long long item = blockIdx.x;
-    for (int idx = lane; idx < D * D; idx += 64) {
-        const int i = idx / D, j = idx % D;
-        double acc = 0.0;
-        for (int g = des.pptr[i]; g < des.pptr[i + 1]; ++g)
-            acc += expect[item * des.m + des.porder[g]] * des.pinvT[(size_t)g * D + j];
-        Rb[j * D + i] = acc + ((idx == 0) ? 1.0 : 0.0);      // transposed, as pauli_real_to_choi_blk reads it
-    }
-    __syncthreads();
-    const Blk c = pauli_real_to_choi_blk<NQ>(Rb, Mw, lane);
-    if (lane < NB * NB) {
-        const int I = lane / NB, J = lane % NB;
+    const long long first = (long long)blockIdx.x * ITEMS;
+    double acc[PER][ITEMS];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
-            double* o = out + ((item * D + row) * D + col) * 2;
-            o[0] = c.re[e]; o[1] = c.im[e];
+    for (int u = 0; u < PER; ++u) {
+        const int idx = lane + 64 * u;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) acc[u][k] = 0.0;
+        if (idx < D * D) {
+            const int i = idx / D, j = idx % D;
+            for (int g = des.pptr[i]; g < des.pptr[i + 1]; ++g) {
+                const double p = des.pinvT[(size_t)g * D + j];
+                const int col = des.porder[g];
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k)
+                    if (first + k < B) acc[u][k] += expect[(first + k) * des.m + col] * p;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const long long item = first + k;
+        if (item >= B) break;                                   // uniform
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < D * D) Rb[(idx % D) * D + idx / D] = acc[u][k] + ((idx == 0) ? 1.0 : 0.0);   // transposed, as pauli_real_to_choi_blk reads it
+        }
+        __syncthreads();
+        const Blk c = pauli_real_to_choi_blk<NQ>(Rb, Mw, lane);
+        if (lane < NB * NB) {
+            const int I = lane / NB, J = lane % NB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+                double* o = out + ((item * D + row) * D + col) * 2;
+                o[0] = c.re[e]; o[1] = c.im[e];
+            }
         }
     }
 }
@@ -1350,8 +1374,8 @@ int fbx_linv_process_dev(const fbx_design* design, int64_t B, const double* d_ex
     if (B == 0) return FBX_OK;
     const int n = design->dev.n;
     if (n == 3) FBX_TRY(linv_process3_launch(design, B, d_expect, d_choi_out));
-    else if (n == 1) hipLaunchKernelGGL(linv_process_kernel<1>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, d_expect, d_choi_out);
-    else hipLaunchKernelGGL(linv_process_kernel<2>, dim3((unsigned)B), dim3(64), 0, stream(), design->dev, (long long)B, d_expect, d_choi_out);
+    else if (n == 1) hipLaunchKernelGGL((linv_process_kernel<1, 4>), dim3((unsigned)((B + 3) / 4)), dim3(64), 0, stream(), design->dev, (long long)B, d_expect, d_choi_out);
+    else hipLaunchKernelGGL((linv_process_kernel<2, 4>), dim3((unsigned)((B + 3) / 4)), dim3(64), 0, stream(), design->dev, (long long)B, d_expect, d_choi_out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;
 }
