@@ -130,3 +130,23 @@ def test_linv_process_and_apply_choi_on_device_pointers(gpu):
         choi = tomography.linear_inv_process_estimate_batch(design, e)
         assert np.array_equal(d_choi.to_array(np.complex128, (B, D, D)), choi)
         assert np.array_equal(d_out.to_array(np.complex128, (B, d, d)), apply_choi_matrix_2_state_batch(choi, rho))
+
+
+def test_process_tomography_walkthrough_example(gpu):
+    """examples/process_tomography_walkthrough.py end to end: settings -> results -> linear inversion / PGDB -> projections ->
+    fidelities, Watrous bounds -> bootstrap error bars -> plot inputs, all through the reference-named API."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "process_tomography_walkthrough.py")
+    spec = importlib.util.spec_from_file_location("walkthrough", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(verbose=False)
+    assert 0.93 < out["fidelity_pgdb"] < 0.99                        # a CNOT with 3 % depolarising noise
+    assert out["fidelity_closest_unitary"] > 0.995                  # its unitary part is the CNOT
+    assert abs(out["fidelity_linear_inversion_projected"] - out["fidelity_pgdb"]) < 0.02
+    mean, err = out["bootstrap_fidelity"]
+    assert abs(mean - out["fidelity_pgdb"]) < 5 * err + 5e-3 and 1e-4 < err < 1e-2
+    assert out["ptm"].shape == (16, 16) and out["labels"][:3] == ["II", "IX", "IY"]
+    lo, hi = out["diamond_norm_bounds_to_ideal"]
+    assert 0 < lo < hi
