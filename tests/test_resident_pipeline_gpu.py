@@ -150,3 +150,20 @@ def test_process_tomography_walkthrough_example(gpu):
     assert out["ptm"].shape == (16, 16) and out["labels"][:3] == ["II", "IX", "IY"]
     lo, hi = out["diamond_norm_bounds_to_ideal"]
     assert 0 < lo < hi
+
+
+def test_state_tomography_from_shots_example(gpu):
+    """examples/state_tomography_from_shots.py end to end: bitstrings -> moments -> linear inversion / MLE variants ->
+    projection -> measures -> bootstrap variance."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "state_tomography_from_shots.py")
+    spec = importlib.util.spec_from_file_location("state_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(verbose=False)
+    for name in ("... projected to physical", "MLE", "max-entropy MLE", "hedged MLE"):
+        fid, tdist, pur = out[name]
+        assert fid > 0.97 and tdist < 0.08 and 0.75 < pur < 1.0, (name, out[name])
+    mean, err = out["bootstrap purity"]
+    assert abs(mean - out["true purity"]) < 5 * err + 0.02 and 1e-4 < err < 0.05
