@@ -22,6 +22,7 @@ hipStream_t stream();    // the calling thread's stream (created on first use)
 int device_epoch();      // increases whenever fbx_set_device selects a different device: cached device memory is stale then
 int current_device();    // device selected for the process, -1 before the first use
 double option_pgdb_eig_rel_tol(int n_qubits);   // fbx_set_option("pgdb_eig_rel_tol" / "pgdb3_eig_rel_tol")
+bool option_eigh_cooperative();                 // fbx_set_option("eigh_cooperative")
 // Defaults of those options: the eigensolver of PGDB's CP projections stops at an off-diagonal norm of
 // <this> x the previous outer step (relative to ||H||_F), never tighter than 1e-13; 0 = always 1e-13.
 // Surveys against the oracle: 2 qubits, 704 items -- identical deviation histogram at 1e-8

@@ -153,8 +153,10 @@ namespace fbx {
 namespace {
 std::atomic<double> g_eig_rel_tol2{FBX_JTOL_REL};     // 1- and 2-qubit PGDB (fbx_pgdb.hip)
 std::atomic<double> g_eig_rel_tol3{FBX3_JTOL_REL};     // 3-qubit PGDB (fbx_pgdb3.hip)
+std::atomic<int> g_eigh_coop{1};                      // large eigendecompositions may use a cooperative launch
 }
 double option_pgdb_eig_rel_tol(int n_qubits) { return n_qubits >= 3 ? g_eig_rel_tol3.load() : g_eig_rel_tol2.load(); }
+bool option_eigh_cooperative() { return g_eigh_coop.load() != 0; }
 }  // namespace fbx
 
 extern "C" {
@@ -217,6 +219,7 @@ int fbx_set_option(const char* name, double value) {
         (n == "pgdb_eig_rel_tol" ? fbx::g_eig_rel_tol2 : fbx::g_eig_rel_tol3).store(value);
         return FBX_OK;
     }
+    if (n == "eigh_cooperative") { fbx::g_eigh_coop.store(value != 0.0 ? 1 : 0); return FBX_OK; }
     set_error("fbx_set_option: unknown option '" + n + "'");
     return FBX_ERR_BAD_ARG;
 }
@@ -226,6 +229,7 @@ int fbx_get_option(const char* name, double* value) {
     const std::string n(name);
     if (n == "pgdb_eig_rel_tol") { *value = fbx::g_eig_rel_tol2.load(); return FBX_OK; }
     if (n == "pgdb3_eig_rel_tol") { *value = fbx::g_eig_rel_tol3.load(); return FBX_OK; }
+    if (n == "eigh_cooperative") { *value = fbx::g_eigh_coop.load(); return FBX_OK; }
     set_error("fbx_get_option: unknown option '" + n + "'");
     return FBX_ERR_BAD_ARG;
 }

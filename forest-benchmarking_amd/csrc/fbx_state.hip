@@ -696,7 +696,7 @@ eigh_big_kernel(int N, long long B, const double* __restrict__ a, double* __rest
 // are cheap and every block needs two of them), and a grid-wide barrier separates the rounds.  One CU moves the
 // 4 N^2 x 16 bytes of a round at ~85 GB/s; the chip moves them at L2 / HBM speed, so the barrier (a few microseconds)
 // becomes the cost of a round.  hipLaunchCooperativeKernel refuses a grid that cannot be co-resident, in which case
-// (or with FBX_EIGH_NO_COOP in the environment) the single-workgroup kernel above takes over.
+// (or with fbx_set_option("eigh_cooperative", 0)) the single-workgroup kernel above takes over.
 __global__ void __launch_bounds__(256)
 eigh_coop_kernel(int N, const double* __restrict__ a, double* __restrict__ w_out, double* __restrict__ v_out,
                  cplx* __restrict__ work, double* __restrict__ partial) {
@@ -783,7 +783,7 @@ eigh_coop_kernel(int N, const double* __restrict__ a, double* __restrict__ w_out
 
 static int launch_eigh_coop(int N, int64_t B, const double* da, double* dw, double* dv, bool* done) {
     *done = false;
-    if (getenv("FBX_EIGH_NO_COOP")) return FBX_OK;
+    if (!option_eigh_cooperative()) return FBX_OK;
     int dev = current_device(), coop = 0, cus = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) { (void)hipGetLastError(); return FBX_OK; }
     FBX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

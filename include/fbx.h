@@ -87,7 +87,9 @@ int         fbx_release_workspace(void);            /* free the calling thread's
  *   off-diagonal norm of <value> x the previous outer step (relative to ||H||_F) instead of always at 1e-13 --
  *   an inexact projection whose error is that fraction of the distance the estimate still moves per iteration.
  *   0 reproduces the reference's eigh-to-machine-precision trajectory iteration by iteration (tests use it);
- *   the defaults leave the converged estimates within 1e-9 of the reference's.  Range [0, 1e-3]. */
+ *   the defaults leave the converged estimates within 1e-9 of the reference's.  Range [0, 1e-3].
+ *   "eigh_cooperative" (default 1): fbx_eigh of a few matrices with N >= 128 spreads each matrix over the whole chip with a
+ *   cooperative launch; 0 keeps one workgroup per matrix. */
 int         fbx_set_option(const char* name, double value);
 int         fbx_get_option(const char* name, double* value);
 

@@ -156,6 +156,10 @@ def test_eigh_beyond_lds_sizes(gpu, N):
         assert np.all(np.diff(w[b]) >= 0)
         assert np.abs(low @ v[b] - v[b] * w[b]).max() < 1e-11 * N
         assert np.abs(v[b].conj().T @ v[b] - np.eye(N)).max() < 1e-12 * N
+    if N >= 128:                        # the cooperative form was used above; one workgroup per matrix must agree
+        with _lib.option("eigh_cooperative", 0):
+            w1 = _lib.eigh_batch(a, eigenvectors=False)
+        assert np.abs(w1 - w).max() < 1e-11 * N
 
 
 def test_four_qubit_choi_validators_and_kraus(gpu):
