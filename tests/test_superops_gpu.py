@@ -270,3 +270,20 @@ def test_basis_free_conversions_in_any_dimension(gpu):
             st.kraus2pauli_liouville(list(ks[0]))
         with pytest.raises(ValueError):
             st.choi2chi(choi[0])
+
+
+def test_projection_kernel_variants_agree_bit_for_bit(gpu):
+    """Batches of 2048 and more take the two-wavefronts-per-SIMD copy of the projection kernel (proj_choi_w2_kernel):
+    same arithmetic, so the same bits as the one-wavefront kernel that small batches use -- for every projection kind,
+    Dykstra iteration counts included."""
+    from fbx.operator_tools import project_superoperators as ps
+    from fbx import _lib
+    rs = np.random.RandomState(77)
+    x = rs.randn(256, 16, 16) + 1j * rs.randn(256, 16, 16)
+    x = 0.1 * x + np.eye(16)[None] / 4
+    big = np.ascontiguousarray(np.tile(x, (9, 1, 1)))            # 2304 items
+    for kind in (_lib.PROJ_CP, _lib.PROJ_TP, _lib.PROJ_TNI, _lib.PROJ_PHYSICAL_TP, _lib.PROJ_PHYSICAL_TNI):
+        small, its = ps.proj_choi_batch(kind, x, return_iters=True)
+        large, itl = ps.proj_choi_batch(kind, big, return_iters=True)
+        assert np.array_equal(large[:256], small) and np.array_equal(large[-256:], small)
+        assert np.array_equal(itl[:256], its)
