@@ -67,6 +67,9 @@ def parse():
                     help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "
                          "sweep / pgdb3 = that workload as the primary line")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
+    ap.add_argument("--anchor-items", type=int, default=65536,
+                    help="N = 1, workload all: also time this many items (BASELINE configs[4]'s whole batch) on the one "
+                         "GPU -- the same-workload anchor of the 1/2/4/8-GPU strong-scaling curve (0 = skip)")
     ap.add_argument("--spawn-timeout", type=float, default=1800.0,
                     help="seconds the self-spawned ranks (--gpus > 1 without a launcher) may take before they are killed")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -400,9 +403,17 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
 class PgdbBatch:
     """A resident batch of 2-qubit process tomographies and its output buffers."""
 
-    def __init__(self, _lib, synthetic, in_basis, B, first_item, max_distinct=8192):
+    def __init__(self, _lib, synthetic, in_basis, B, first_item, max_distinct=1 << 20):
+        # every item distinct (its own Haar unitary and shot noise, seeds first_item + b): generated on the host in
+        # blocks of 8192 (~3 s each) so that the generator's temporaries stay small
         n_distinct = min(B, max_distinct)
-        self.design, self.us, e, c = synthetic.process_batch(2, in_basis, n_distinct, first_item=first_item)
+        parts, self.us = [], None
+        for b0 in range(0, n_distinct, 8192):
+            self.design, us, e, c = synthetic.process_batch(2, in_basis, min(8192, n_distinct - b0), first_item=first_item + b0)
+            parts.append((e, c))
+            if self.us is None:
+                self.us = us
+        e = np.concatenate([p[0] for p in parts]); c = np.concatenate([p[1] for p in parts])
         if n_distinct < B:
             reps = -(-B // n_distinct)
             e = np.tile(e, (reps, 1))[:B]; c = np.tile(c, (reps, 1))[:B]
@@ -465,7 +476,7 @@ def run_pgdb(args, comm, _lib, synthetic, rank_info):
     if total > 0:
         lo, hi = shard_bounds(total, rank, world)
         batch = PgdbBatch(_lib, synthetic, args.in_basis, hi - lo, lo)
-        scaling, shards = "strong", f"contiguous blocks of a {total}-item batch, distinct seeds ({batch.n_distinct} distinct experiments per rank, tiled beyond)"
+        scaling, shards = "strong", f"contiguous blocks of a {total}-item batch, distinct seeds (items {lo}..{hi - 1} on this rank, all distinct)"
     else:
         batch = PgdbBatch(_lib, synthetic, args.in_basis, args.batch, rank * args.batch)
         scaling, shards = "weak", "distinct seeds per rank"
@@ -505,6 +516,31 @@ def run_pgdb(args, comm, _lib, synthetic, rank_info):
         wb.free()
         return line, None
     return line, batch
+
+
+def strong_anchor(args, comm, _lib, synthetic):
+    """N = 1 only: BASELINE configs[4]'s whole batch (65 536 distinct items, the very items the ranks of an N-GPU run
+    own between them) on ONE GPU, so that the driver's 1 -> 2 -> 4 -> 8 curve has a same-workload N = 1 point next to
+    the 1024-item headline (which runs the one-wave kernel; this batch, like every rank's share of it, runs the
+    two-waves-per-SIMD kernel in launches of 8192)."""
+    total = args.anchor_items
+    t0 = time.perf_counter()
+    batch = PgdbBatch(_lib, synthetic, args.in_basis, total, 0)
+    t_gen = time.perf_counter() - t0
+    steps = max(1, min(args.steps, 3))
+    elapsed, kms = timed_steps(lambda: batch.launch(_lib.MODE_FIXED, args.iters), steps, 1, comm, _lib)
+    st = batch.stats()
+    out = {"value": total * steps / elapsed, "unit": "reconstructions/s", "n_gpus": 1, "scaling": "strong",
+           "steps": steps, "warmup": 1, "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": kms / steps,
+           "workload": f"{total} independent 2-qubit process tomographies (BASELINE configs[4], items 0..{total - 1}, all "
+                       f"distinct) on one GPU, {args.in_basis} in-basis, {args.iters} fixed PGDB iterations, inputs resident in HBM",
+           "kernel": "pgdb_lean_kernel<2,9>" if batch.design.m > 256 else "pgdb_lean_kernel<2,4>",
+           "mean_outer_iters": float(st["iterations"].mean()), "mean_dykstra_iters": float(st["dykstra"].mean()),
+           "mean_jacobi_sweeps": float(st["work"][:, 0].mean()), "host_input_generation_s": t_gen,
+           "note": "compare bench.py --gpus N (value = the same 65 536 items block-partitioned over N ranks) with THIS "
+                   "figure, not with the 1024-item headline"}
+    batch.free()
+    return out
 
 
 def single_gpu_extras(args, comm, _lib, synthetic, batch, line):
@@ -566,11 +602,27 @@ def main():
         args.in_basis = "pauli"
 
     from fbx import _lib, synthetic, parallel
-    comm, rdzv = parallel.init_from_env(allow_host_fallback=True, allow_oversubscribe=args.oversubscribe)   # selects GPU LOCAL_RANK; fails loudly without one
+    # Selects GPU LOCAL_RANK and fails loudly without one.  One GPU per rank: the ranks form an RCCL communicator or
+    # the run exits non-zero -- the host-files barrier is a test convenience for ranks that SHARE a device and is only
+    # reachable with --oversubscribe.
+    comm, rdzv = parallel.init_from_env(allow_host_fallback=args.oversubscribe, allow_oversubscribe=args.oversubscribe)
     dev_name, cus = _lib.device_name()
-    transport = {"backend": comm.backend, "ranks": comm.world}
+    ordinal, pci = _lib.device_id()
+    transport = {"backend": comm.backend}
     if comm.backend == "rccl":
-        transport["rccl_version"] = comm.rccl_version
+        q = comm.query()                       # what the COMMUNICATOR reports (ncclCommCount / UserRank / CuDevice), not the environment
+        transport.update(ranks=q["world"], rccl_version=comm.rccl_version)
+        mine = np.zeros(40, dtype=np.uint8)
+        mine[:4] = np.frombuffer(np.array([q["rank"], q["device"]], dtype=np.int16).tobytes(), dtype=np.uint8)
+        mine[4:4 + len(pci)] = np.frombuffer(pci.encode(), dtype=np.uint8)
+        rows = comm.allgather(mine)            # one all-gather over RCCL: every rank's own view of itself
+        transport["rank_devices"] = [{"rank": int(r[:4].view(np.int16)[0]), "device": int(r[:4].view(np.int16)[1]),
+                                      "pci_bus_id": bytes(r[4:]).rstrip(b"\0").decode()} for r in rows]
+        if len({d["pci_bus_id"] for d in transport["rank_devices"]}) != comm.world:
+            sys.exit(f"bench.py: ranks share a physical device: {transport['rank_devices']}")
+    else:
+        transport.update(ranks=comm.world, rank_devices=[{"rank": comm.rank, "device": ordinal, "pci_bus_id": pci}]
+                         if comm.world == 1 else "ranks share devices (--oversubscribe)")
     if getattr(comm, "failure", None):
         transport["rccl_failure"] = comm.failure
     rank_info = {"device": dev_name.strip(), "cus": cus, "transport": transport}
@@ -594,6 +646,10 @@ def main():
             if comm.world == 1 and args.workload == "all":
                 single_gpu_extras(args, comm, _lib, synthetic, batch, line)
             batch.free()
+            if comm.world == 1 and args.workload == "all" and args.anchor_items > 0:
+                _lib.release_workspace()
+                line["strong_65536" if args.anchor_items == 65536 else f"strong_{args.anchor_items}"] = \
+                    strong_anchor(args, comm, _lib, synthetic)
         if secondary:
             line["secondary"] = secondary
     comm.barrier()

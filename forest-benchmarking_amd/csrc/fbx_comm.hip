@@ -13,8 +13,13 @@
 // librccl.so is opened on the first fbx_comm_* call (dlopen), not linked: it is a 570 MB image, and
 // single-GPU users of libfbx.so never touch it.  Only the types of <rccl/rccl.h> are used at build time.
 #include "fbx_common.hpp"
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <dlfcn.h>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <rccl/rccl.h>
 
 namespace fbx {
@@ -31,11 +36,21 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 Rccl g_rccl;
-std::mutex g_mu;             // guards the loader and the communicator pointer
+std::mutex g_mu;             // guards the loader, the state below and the communicator pointer -- never held across a
+                             // blocking RCCL call (ncclCommInitRank waits for every peer)
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_world = 0, g_comm_device = -1;
+// NONE -> INITIALISING (one fbx_comm_init in flight, g_mu released) -> READY | NONE; an initialisation that
+// timed out leaves ABANDONED: its helper thread still sits inside ncclCommInitRank (there is no handle to abort
+// before it returns), so no further communicator can be formed in this process, and every fbx_comm_* call
+// says so at once instead of blocking.
+enum CommState { COMM_NONE = 0, COMM_INITIALISING = 1, COMM_READY = 2, COMM_ABANDONED = 3 };
+CommState g_state = COMM_NONE;
 
 template <class F> bool sym(void* h, const char* name, F& out) {
     out = reinterpret_cast<F>(dlsym(h, name));
@@ -53,7 +68,8 @@ int load_rccl() {
                     sym(h, "ncclCommDestroy", r.CommDestroy) && sym(h, "ncclCommAbort", r.CommAbort) &&
                     sym(h, "ncclAllGather", r.AllGather) && sym(h, "ncclAllReduce", r.AllReduce) &&
                     sym(h, "ncclBroadcast", r.Broadcast) && sym(h, "ncclGetErrorString", r.GetErrorString) &&
-                    sym(h, "ncclGetVersion", r.GetVersion);
+                    sym(h, "ncclGetVersion", r.GetVersion) && sym(h, "ncclCommCount", r.CommCount) &&
+                    sym(h, "ncclCommCuDevice", r.CommCuDevice) && sym(h, "ncclCommUserRank", r.CommUserRank);
     if (!ok) { dlclose(h); set_error("fbx_comm: librccl.so lacks an expected symbol"); return FBX_ERR_RCCL; }
     g_rccl = r;
     return FBX_OK;
@@ -66,6 +82,9 @@ int rccl_fail(ncclResult_t r, const char* what) {
 #define FBX_RCCL(call, what) do { ncclResult_t _r = (call); if (_r != ncclSuccess) return rccl_fail(_r, what); } while (0)
 
 int need_comm(const char* who) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_state == COMM_INITIALISING) { set_error(std::string(who) + ": fbx_comm_init is still in progress on another thread"); return FBX_ERR_BAD_ARG; }
+    if (g_state == COMM_ABANDONED) { set_error(std::string(who) + ": an earlier fbx_comm_init timed out; this process cannot form a communicator any more"); return FBX_ERR_RCCL; }
     if (!g_comm) { set_error(std::string(who) + ": no communicator (call fbx_comm_init first)"); return FBX_ERR_BAD_ARG; }
     if (g_comm_device != current_device()) {
         set_error(std::string(who) + ": the communicator belongs to another device"); return FBX_ERR_BAD_ARG;
@@ -92,22 +111,66 @@ int fbx_comm_unique_id(uint8_t* id_out) {
     return FBX_OK;
 }
 
-int fbx_comm_init(const uint8_t* id_in, int rank, int world) {
+// One initialisation: the collective ncclCommInitRank runs in a helper thread that owns no library context
+// (it only selects the device), while the caller waits on a condition variable with a deadline.
+namespace {
+struct InitBox {
+    std::mutex mu; std::condition_variable cv;
+    bool done = false; ncclResult_t result = ncclSuccess; hipError_t hip = hipSuccess; ncclComm_t comm = nullptr;
+};
+}
+
+int fbx_comm_init_timeout(const uint8_t* id_in, int rank, int world, double timeout_seconds) {
     FBX_REQUIRE(id_in != nullptr, "fbx_comm_init: NULL id");
     FBX_REQUIRE(world >= 1 && rank >= 0 && rank < world, "fbx_comm_init: need 0 <= rank < world");
+    FBX_REQUIRE(timeout_seconds > 0.0, "fbx_comm_init: timeout must be positive");
     int rc = ensure_device();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
-    FBX_REQUIRE(g_comm == nullptr, "fbx_comm_init: a communicator already exists (fbx_comm_destroy first)");
-    rc = load_rccl();
-    if (rc) return rc;
+    const int device = current_device();
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_state == COMM_ABANDONED) { set_error("fbx_comm_init: an earlier initialisation timed out; this process cannot form a communicator any more"); return FBX_ERR_RCCL; }
+        FBX_REQUIRE(g_state != COMM_INITIALISING, "fbx_comm_init: another initialisation is in progress");
+        FBX_REQUIRE(g_state == COMM_NONE && g_comm == nullptr, "fbx_comm_init: a communicator already exists (fbx_comm_destroy first)");
+        rc = load_rccl();
+        if (rc) return rc;
+        g_state = COMM_INITIALISING;
+    }
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof id);
-    FBX_HIP(hipSetDevice(current_device()));
-    ncclComm_t comm = nullptr;
-    FBX_RCCL(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
-    g_comm = comm; g_rank = rank; g_world = world; g_comm_device = current_device();
+    auto box = std::make_shared<InitBox>();
+    const auto init_rank = g_rccl.CommInitRank;
+    std::thread([box, init_rank, id, rank, world, device]() {
+        ncclComm_t comm = nullptr;
+        hipError_t he = hipSetDevice(device);
+        ncclResult_t r = he == hipSuccess ? init_rank(&comm, world, id, rank) : ncclUnhandledCudaError;
+        std::lock_guard<std::mutex> lk(box->mu);
+        box->hip = he; box->result = r; box->comm = comm; box->done = true;
+        box->cv.notify_all();
+    }).detach();
+    bool finished;
+    {
+        std::unique_lock<std::mutex> lk(box->mu);
+        finished = box->cv.wait_for(lk, std::chrono::duration<double>(timeout_seconds), [&] { return box->done; });
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!finished) {
+        g_state = COMM_ABANDONED;
+        char msg[160];
+        snprintf(msg, sizeof msg, "fbx_comm_init: ncclCommInitRank (rank %d of %d) did not return within %.0f s -- a peer is missing", rank, world, timeout_seconds);
+        set_error(msg);
+        return FBX_ERR_RCCL;
+    }
+    if (box->hip != hipSuccess) { g_state = COMM_NONE; return hip_fail(box->hip, "hipSetDevice (fbx_comm_init)", __FILE__, __LINE__); }
+    if (box->result != ncclSuccess) { g_state = COMM_NONE; return rccl_fail(box->result, "ncclCommInitRank"); }
+    g_comm = box->comm; g_rank = rank; g_world = world; g_comm_device = device; g_state = COMM_READY;
     return FBX_OK;
+}
+
+int fbx_comm_init(const uint8_t* id_in, int rank, int world) {
+    double limit = 180.0;
+    if (const char* e = getenv("FBX_RCCL_INIT_TIMEOUT")) { const double v = atof(e); if (v > 0.0) limit = v; }
+    return fbx_comm_init_timeout(id_in, rank, world, limit);
 }
 
 int fbx_comm_info(int* rank, int* world, int* rccl_version) {
@@ -121,11 +184,30 @@ int fbx_comm_info(int* rank, int* world, int* rccl_version) {
     return FBX_OK;
 }
 
+// What the COMMUNICATOR says about itself (ncclCommUserRank / ncclCommCount / ncclCommCuDevice), not what the
+// launcher's environment claimed: bench.py prints these per rank.
+int fbx_comm_query(int* rank, int* world, int* device) {
+    int rc = need_comm("fbx_comm_query");
+    if (rc) return rc;
+    int r = -1, w = -1, d = -1;
+    FBX_RCCL(g_rccl.CommUserRank(g_comm, &r), "ncclCommUserRank");
+    FBX_RCCL(g_rccl.CommCount(g_comm, &w), "ncclCommCount");
+    FBX_RCCL(g_rccl.CommCuDevice(g_comm, &d), "ncclCommCuDevice");
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (device) *device = d;
+    return FBX_OK;
+}
+
 int fbx_comm_destroy(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_comm) return FBX_OK;
-    ncclComm_t c = g_comm;
-    g_comm = nullptr; g_world = 0; g_rank = 0; g_comm_device = -1;
+    ncclComm_t c;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_state == COMM_INITIALISING) { set_error("fbx_comm_destroy: fbx_comm_init is still in progress on another thread"); return FBX_ERR_BAD_ARG; }
+        if (!g_comm) return FBX_OK;              // nothing to destroy (also after an abandoned initialisation)
+        c = g_comm;
+        g_comm = nullptr; g_world = 0; g_rank = 0; g_comm_device = -1; g_state = COMM_NONE;
+    }
     FBX_RCCL(g_rccl.CommDestroy(c), "ncclCommDestroy");
     return FBX_OK;
 }
@@ -168,17 +250,21 @@ int fbx_comm_allreduce_f64(double* host_inout, size_t n, int op) {
     int rc = need_comm("fbx_comm_allreduce_f64");
     if (rc) return rc;
     FBX_REQUIRE(n == 0 || host_inout, "fbx_comm_allreduce_f64: NULL buffer");
-    FBX_REQUIRE(n <= 4096, "fbx_comm_allreduce_f64: the host form is for summary vectors (n <= 4096)");
     if (n == 0) return FBX_OK;
+    // any length: pieces of at most CHUNK doubles through one small staging workspace
+    constexpr size_t CHUNK = 4096;
     void* w = nullptr;
-    rc = workspace(WS_COMM, sizeof(double) * 4096, &w);
+    rc = workspace(WS_COMM, sizeof(double) * CHUNK, &w);
     if (rc) return rc;
     double* d = (double*)w;
-    FBX_HIP(hipMemcpyAsync(d, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, stream()));
-    rc = fbx_comm_allreduce_f64_dev(d, d, n, op);
-    if (rc) return rc;
-    FBX_HIP(hipMemcpyAsync(host_inout, d, sizeof(double) * n, hipMemcpyDeviceToHost, stream()));
-    FBX_HIP(hipStreamSynchronize(stream()));
+    for (size_t o = 0; o < n; o += CHUNK) {
+        const size_t k = n - o < CHUNK ? n - o : CHUNK;
+        FBX_HIP(hipMemcpyAsync(d, host_inout + o, sizeof(double) * k, hipMemcpyHostToDevice, stream()));
+        rc = fbx_comm_allreduce_f64_dev(d, d, k, op);
+        if (rc) return rc;
+        FBX_HIP(hipMemcpyAsync(host_inout + o, d, sizeof(double) * k, hipMemcpyDeviceToHost, stream()));
+        FBX_HIP(hipStreamSynchronize(stream()));
+    }
     return FBX_OK;
 }
 

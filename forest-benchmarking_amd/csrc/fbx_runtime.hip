@@ -202,6 +202,15 @@ int fbx_device_name(char* buf, size_t len, int* compute_units) {
     return FBX_OK;
 }
 
+// selected device: ordinal and PCI bus id ("0000:05:00.0") -- what tells two ranks' devices apart
+int fbx_device_id(int* ordinal, char* pci_bus_id, size_t len) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (ordinal) *ordinal = g_device.load();
+    if (pci_bus_id && len) FBX_HIP(hipDeviceGetPCIBusId(pci_bus_id, (int)len, g_device.load()));
+    return FBX_OK;
+}
+
 int fbx_synchronize(void) {
     int rc = ensure_device();
     if (rc) return rc;

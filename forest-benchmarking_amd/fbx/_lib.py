@@ -44,10 +44,13 @@ PROTOTYPES = {
     "fbx_device_count": [C.POINTER(C.c_int)],
     "fbx_set_device": [C.c_int],
     "fbx_device_name": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
+    "fbx_device_id": [C.POINTER(C.c_int), C.c_char_p, C.c_size_t],
     "fbx_synchronize": [],
     "fbx_release_workspace": [],
     "fbx_comm_unique_id": [_u8p],
     "fbx_comm_init": [_u8p, C.c_int, C.c_int],
+    "fbx_comm_init_timeout": [_u8p, C.c_int, C.c_int, C.c_double],
+    "fbx_comm_query": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "fbx_comm_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "fbx_comm_destroy": [],
     "fbx_comm_allgather_dev": [_vp, _vp, C.c_size_t],
@@ -200,6 +203,14 @@ def device_name():
     cus = C.c_int(0)
     check(lib().fbx_device_name(buf, 256, C.byref(cus)))
     return buf.value.decode(), cus.value
+
+
+def device_id():
+    """(ordinal, PCI bus id) of the device this process selected."""
+    buf = C.create_string_buffer(64)
+    o = C.c_int(-1)
+    check(lib().fbx_device_id(C.byref(o), buf, 64))
+    return o.value, buf.value.decode()
 
 
 def synchronize():

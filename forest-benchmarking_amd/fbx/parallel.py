@@ -14,7 +14,6 @@ No torch here: the communicator lives in libfbx.so.  A communicator object only 
 the same partition / gather code through a gloo-backed stand-in (tests/test_distributed_gloo.py).
 """
 import os
-import threading
 import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -35,64 +34,160 @@ class FileRendezvous:
     """Host-side hand-off between the ranks of ONE node through a private directory: every rank
     publishes a small payload under a tag (atomic rename) and reads everybody else's.  Used to pass
     the RCCL unique id from rank 0 to the others, and as the barrier of last resort when RCCL cannot
-    be initialised (e.g. several test ranks sharing one GPU)."""
+    be initialised (e.g. several test ranks sharing one GPU).
 
-    def __init__(self, rank: int, world: int, directory: Optional[str] = None, timeout: float = 300.0):
+    A directory can outlive a failed attempt (torchrun restarts its workers with the same parent and
+    MASTER_PORT; FBX_RDZV_DIR may be reused), so nothing in it is trusted by name alone: rank 0 opens a
+    GENERATION -- it removes whatever the directory held and publishes a fresh random nonce under the one
+    fixed name ``gen`` -- and every other file name carries that nonce.  A rank that still sees the
+    previous attempt's ``gen`` joins a generation nobody else is in; it times out on the first exchange
+    (``join_timeout``) and re-reads ``gen``.  ``close`` is acknowledged: files go only after every rank
+    has said it will read no more."""
+
+    def __init__(self, rank: int, world: int, directory: Optional[str] = None, timeout: float = 300.0,
+                 join_timeout: float = 5.0):
         if directory is None:
             directory = os.environ.get("FBX_RDZV_DIR")
         if directory is None:
-            # torchrun children share their parent (the elastic agent) and MASTER_PORT
+            # torchrun children share their parent (the elastic agent) and MASTER_PORT; the restart count
+            # separates the attempts of one agent
             directory = os.path.join(os.environ.get("TMPDIR", "/tmp"),
-                                     f"fbx_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
-        os.makedirs(directory, exist_ok=True)
+                                     "fbx_rdzv_%s_%s_%d_r%s" % (os.getuid(), os.environ.get("MASTER_PORT", "0"), os.getppid(),
+                                                                os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")))
+        os.makedirs(directory, mode=0o700, exist_ok=True)
+        st = os.stat(directory)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise PermissionError(f"rendezvous directory {directory} is not private to this user")
         self.dir, self.rank, self.world, self.timeout = directory, int(rank), int(world), timeout
         self._mine: List[str] = []
         self._seq = 0
+        self.gen = self._open_generation(join_timeout)
 
-    def allgather(self, payload: bytes, tag: Optional[str] = None) -> List[bytes]:
-        if tag is None:
-            tag = f"x{self._seq}"
-            self._seq += 1
-        path = os.path.join(self.dir, f"{tag}.{self.rank}")
+    # -- generation handshake
+    def _open_generation(self, join_timeout: float) -> str:
+        """Rank 0: purge, publish a fresh ``gen`` nonce, collect every rank's join TOKEN, echo the tokens in an
+        ``ack``.  Rank r: read ``gen``, publish a fresh random token, and accept the generation only if rank 0's
+        ack echoes that token -- files of a dead attempt can look complete, but cannot contain a token drawn now."""
+        gen_path = os.path.join(self.dir, "gen")
+        deadline = time.monotonic() + self.timeout
+        if self.rank == 0:
+            for name in os.listdir(self.dir):                 # leftovers of an earlier attempt
+                try:
+                    os.remove(os.path.join(self.dir, name))
+                except OSError:
+                    pass
+            self.gen = os.urandom(8).hex()
+            tmp = gen_path + ".tmp0"
+            with open(tmp, "w") as f:
+                f.write(self.gen)
+            os.replace(tmp, gen_path)
+            self._publish(b"rank0", "join")
+            tokens = self._collect("join", self.timeout)
+            self._publish(b",".join(tokens), "ack")
+            return self.gen
+        tried = set()
+        while True:
+            self.gen = self._read(gen_path, deadline, skip=tried)
+            token = os.urandom(8).hex().encode()
+            try:
+                self._publish(token, "join")
+                ack = self._collect("ack", join_timeout, ranks=(0,))[0].split(b",")
+                if len(ack) == self.world and ack[self.rank] == token:
+                    return self.gen
+            except (TimeoutError, OSError):                    # (OSError: rank 0 purged the directory under us)
+                pass
+            tried.add(self.gen)                                # a stale generation: wait for rank 0's new one
+            self._mine = []
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous: no live generation appeared in {self.dir}")
+
+    def _read(self, path: str, deadline: float, skip=()) -> str:
+        delay = 1e-4
+        while True:
+            try:
+                with open(path, "r") as f:
+                    val = f.read()
+                if val and val not in skip:
+                    return val
+            except (FileNotFoundError, PermissionError):
+                pass
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous: {path} never appeared")
+            time.sleep(delay)
+            delay = min(delay * 1.5, 2e-3)
+
+    def _publish(self, payload: bytes, tag: str) -> str:
+        path = os.path.join(self.dir, f"{self.gen}.{tag}.{self.rank}")
         tmp = path + ".tmp"
         with open(tmp, "wb") as f:
             f.write(payload)
         os.replace(tmp, path)
         self._mine.append(path)
-        out, deadline = [], time.monotonic() + self.timeout
-        for r in range(self.world):
-            p = os.path.join(self.dir, f"{tag}.{r}")
+        return path
+
+    def _collect(self, tag: str, timeout: float, ranks=None) -> List[bytes]:
+        out, deadline = [], time.monotonic() + timeout
+        for r in (range(self.world) if ranks is None else ranks):
+            p = os.path.join(self.dir, f"{self.gen}.{tag}.{r}")
             delay = 1e-4
-            while not os.path.exists(p):
+            while True:
+                try:
+                    with open(p, "rb") as f:              # (no exists()-then-open window)
+                        out.append(f.read())
+                    break
+                except FileNotFoundError:
+                    pass
                 if time.monotonic() > deadline:
                     raise TimeoutError(f"rendezvous: rank {r} never published '{tag}' in {self.dir}")
                 time.sleep(delay)
                 delay = min(delay * 1.5, 2e-3)
-            with open(p, "rb") as f:
-                out.append(f.read())
         return out
+
+    def _exchange(self, payload: bytes, tag: str, timeout: float) -> List[bytes]:
+        self._publish(payload, tag)
+        return self._collect(tag, timeout)
+
+    def allgather(self, payload: bytes, tag: Optional[str] = None) -> List[bytes]:
+        if tag is None:
+            tag = f"x{self._seq}"
+            self._seq += 1
+        return self._exchange(payload, tag, self.timeout)
 
     def barrier(self):
         self.allgather(b"")
 
     def close(self):
-        # a rank's files may only go once every rank has read them: one last round, then everybody
-        # deletes what it wrote (the directory goes with the last file)
+        """Acknowledged: "closing" is a full round (every rank has read everything it will ever read, so data
+        files may go); a rank then publishes "closed" -- its promise to read nothing more, not even the
+        "closing" markers -- and leaves without waiting.  Rank 0 waits for every "closed" and removes what is
+        left, directory included.  No rank sleeps and hopes; no rank polls for a file a peer already deleted."""
         try:
-            self.allgather(b"", tag="close")
-            time.sleep(0.05)
+            self._exchange(b"", "closing", self.timeout)
         except TimeoutError:
-            pass
-        for p in self._mine:
+            self._mine = []
+            return
+        for p in self._mine[:-1]:                             # all but my "closing" marker, which peers may still read
             try:
                 os.remove(p)
             except OSError:
                 pass
         self._mine = []
-        try:
-            os.rmdir(self.dir)
-        except OSError:
-            pass
+        self._publish(b"", "closed")
+        self._mine = []
+        if self.rank == 0:
+            try:
+                self._collect("closed", self.timeout)
+            except TimeoutError:
+                return
+            for name in os.listdir(self.dir):
+                try:
+                    os.remove(os.path.join(self.dir, name))
+                except OSError:
+                    pass
+            try:
+                os.rmdir(self.dir)
+            except OSError:
+                pass
 
 
 # ------------------------------------------------------------------------------------ communicators
@@ -119,15 +214,30 @@ class RcclComm:
     backend = "rccl"
     _OPS = {"sum": 0, "max": 1, "min": 2}
 
-    def __init__(self, rank: int, world: int, unique_id: bytes):
+    def __init__(self, rank: int, world: int, unique_id: bytes, timeout: Optional[float] = None):
+        """Collective.  ``timeout`` (seconds; default FBX_RCCL_INIT_TIMEOUT or 180): a missing peer makes the
+        call fail with FbxError(FBX_ERR_RCCL) instead of blocking for ever (fbx_comm_init_timeout)."""
         from . import _lib
         self._lib = _lib
         ident = (_lib.C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(unique_id)
-        _lib.check(_lib.lib().fbx_comm_init(ident, int(rank), int(world)))
-        self.rank, self.world = int(rank), int(world)
+        if timeout is None:
+            _lib.check(_lib.lib().fbx_comm_init(ident, int(rank), int(world)))
+        else:
+            _lib.check(_lib.lib().fbx_comm_init_timeout(ident, int(rank), int(world), float(timeout)))
         v = _lib.C.c_int(0)
         _lib.lib().fbx_comm_info(None, None, _lib.C.byref(v))
         self.rccl_version = v.value
+        # rank / world / device as the communicator itself reports them (not the launcher's environment)
+        q = self.query()
+        self.rank, self.world, self.device = q["rank"], q["world"], q["device"]
+        if (self.rank, self.world) != (int(rank), int(world)):
+            raise _lib.FbxError(_lib.FBX_ERR_RCCL, f"communicator reports rank {self.rank} of {self.world}, asked for {rank} of {world}")
+
+    def query(self) -> dict:
+        C = self._lib.C
+        r, w, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        self._lib.check(self._lib.lib().fbx_comm_query(C.byref(r), C.byref(w), C.byref(d)))
+        return {"rank": r.value, "world": w.value, "device": d.value}
 
     @staticmethod
     def new_unique_id() -> bytes:
@@ -228,24 +338,12 @@ def init_from_env(allow_host_fallback: bool = False, allow_oversubscribe: bool =
     failure = err.decode() if err else None
     comm = None
     if failure is None and (ndev >= world or not allow_host_fallback):
-        # ncclCommInitRank is a collective: it blocks for as long as a peer is missing.  It runs in a
-        # helper thread so that a rank whose peer died reports a failure instead of hanging the job.
-        box: dict = {}
-
-        def _init():
-            try:
-                box["comm"] = RcclComm(rank, world, ident)
-            except Exception as exc:                         # noqa: BLE001 -- reported below
-                box["error"] = str(exc)
-
-        limit = float(os.environ.get("FBX_RCCL_INIT_TIMEOUT", "180"))
-        worker = threading.Thread(target=_init, name="fbx-rccl-init", daemon=True)
-        worker.start()
-        worker.join(limit)
-        if worker.is_alive():
-            failure = f"ncclCommInitRank did not return within {limit:.0f} s"
-        else:
-            comm, failure = box.get("comm"), box.get("error")
+        # ncclCommInitRank is a collective; fbx_comm_init_timeout bounds the wait for a missing peer inside the
+        # library (no Python helper thread, no lock held meanwhile)
+        try:
+            comm = RcclComm(rank, world, ident, timeout=float(os.environ.get("FBX_RCCL_INIT_TIMEOUT", "180")))
+        except Exception as exc:                             # noqa: BLE001 -- reported to every rank below
+            failure = str(exc)
     elif failure is None:
         failure = f"{world} ranks share {ndev} GPU(s): RCCL needs one GPU per rank"
     # all ranks must agree on the transport

@@ -79,6 +79,7 @@ const char* fbx_last_error(void);
 int         fbx_device_count(int* count);
 int         fbx_set_device(int device_id);          /* one process per GPU: call once */
 int         fbx_device_name(char* buf, size_t len, int* compute_units);
+int         fbx_device_id(int* ordinal, char* pci_bus_id, size_t len);   /* the selected device; "0000:05:00.0"-style id (len >= 16) */
 int         fbx_synchronize(void);                  /* the calling thread's stream */
 int         fbx_release_workspace(void);            /* free the calling thread's cached device workspaces / staging pool */
 /* Process-wide tunables, read when a kernel is launched.
@@ -108,14 +109,20 @@ int         fbx_get_option(const char* name, double* value);
 #define FBX_COMM_MAX 1
 #define FBX_COMM_MIN 2
 int fbx_comm_unique_id(uint8_t* id_out /* [FBX_COMM_ID_BYTES] */);
-int fbx_comm_init(const uint8_t* id, int rank, int world);
+int fbx_comm_init(const uint8_t* id, int rank, int world);   /* = fbx_comm_init_timeout with 180 s (env FBX_RCCL_INIT_TIMEOUT) */
+/* ncclCommInitRank is a collective: it blocks for as long as a peer is missing.  It runs in a helper thread of the
+ * library (no library lock is held meanwhile); when it has not returned after timeout_seconds the call fails with
+ * FBX_ERR_RCCL and the process can form no further communicator (every later fbx_comm_* call says so at once). */
+int fbx_comm_init_timeout(const uint8_t* id, int rank, int world, double timeout_seconds);
 int fbx_comm_info(int* rank, int* world, int* rccl_version);   /* world = 0 without a communicator */
+/* rank / size / device as the COMMUNICATOR reports them (ncclCommUserRank, ncclCommCount, ncclCommCuDevice) */
+int fbx_comm_query(int* rank, int* world, int* device);
 int fbx_comm_destroy(void);
 int fbx_comm_allgather_dev(const void* d_send, void* d_recv /* [world][bytes_per_rank] */,
                            size_t bytes_per_rank);
 int fbx_comm_broadcast_dev(void* d_buf, size_t bytes, int root);
 int fbx_comm_allreduce_f64_dev(const double* d_send, double* d_recv, size_t n, int op);
-int fbx_comm_allreduce_f64(double* host_inout, size_t n, int op);   /* summary vectors, n <= 4096; synchronises */
+int fbx_comm_allreduce_f64(double* host_inout, size_t n, int op);   /* host vector of any length (meant for summary vectors); synchronises */
 int fbx_comm_barrier(void);   /* all ranks' work enqueued by the calling threads is complete */
 
 /* device memory helpers so callers can keep batches resident in HBM */

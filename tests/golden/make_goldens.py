@@ -303,8 +303,107 @@ def make_round2():
     print("round2 done")
 
 
+# ------------------------------------------------------------------------------------------------
+# Timed mode (round 3): the benchmark runs EXACTLY 100 outer iterations (FBX_MODE_FIXED), a loop the
+# reference itself never runs past its stopping rule.  The fixtures below are produced by a driver loop
+# that is tomography.py:563-592 statement by statement -- every number comes from the reference's own
+# _extract_from_results / _cost / _grad_cost / proj_choi_to_physical -- with the `break` of :589 replaced
+# by a record of the iteration at which it would have fired.  One run therefore yields the reference's
+# converged estimate (a snapshot at that iteration, asserted bit-identical to a direct
+# pgdb_process_estimate call for the first items of every set), the fixed-N estimate, and per-iteration
+# Dykstra / halving counts and costs.
+def ref_pgdb_trace(results, qubits, n_iters, trace_preserving=True):
+    import importlib
+    PS = importlib.import_module("forest.benchmarking.operator_tools.project_superoperators")
+    calls = [0]
+    orig_cp = PS.proj_choi_to_completely_positive
+
+    def counting_cp(choi):                      # one CP projection per Dykstra iteration
+        calls[0] += 1
+        return orig_cp(choi)
+
+    PS.proj_choi_to_completely_positive = counting_cp
+    try:
+        A, n = T._extract_from_results(results, qubits[::-1])
+        dim = 2 ** len(qubits)
+        est = np.eye(dim ** 2, dim ** 2, dtype=complex) / dim
+        old_cost = T._cost(A, n, est)
+        mu = 3 / (2 * dim ** 2)
+        gamma = .3
+        dyk, bts, costs = [], [], []
+        conv_iter, conv_est = 0, None
+        for it in range(n_iters):
+            gradient = T._grad_cost(A, n, est)
+            calls[0] = 0
+            update = T.proj_choi_to_physical(est - gradient / mu, trace_preserving) - est
+            dyk.append(calls[0])
+            alpha = 1
+            new_cost = T._cost(A, n, est + alpha * update)
+            change = gamma * alpha * np.dot(OT.vec(update).conj().T, OT.vec(gradient))
+            bt = 0
+            while new_cost > old_cost + change:
+                alpha = .5 * alpha
+                change = .5 * change
+                new_cost = T._cost(A, n, est + alpha * update)
+                bt += 1
+                if alpha < 1e-15:
+                    break
+            est += alpha * update
+            bts.append(bt)
+            costs.append(float(np.real(new_cost).ravel()[0]))
+            if conv_est is None and old_cost - new_cost < 1e-10:      # tomography.py:589 would stop here
+                conv_iter, conv_est = it + 1, est.copy()
+            old_cost = new_cost
+    finally:
+        PS.proj_choi_to_completely_positive = orig_cp
+    return dict(fixed=est, conv=conv_est if conv_est is not None else np.full_like(est, np.nan), conv_iter=conv_iter,
+                dykstra=np.array(dyk, dtype=np.int32), backtracks=np.array(bts, dtype=np.int32), costs=np.array(costs))
+
+
+def _fixed_worker(job):
+    n, basis, b, n_iters, check_direct = job
+    qubits = list(range(n))
+    design, us, e, c = synthetic.process_batch(n, basis, 1, first_item=b)
+    settings = process_settings(qubits, basis)
+    res = ref_results(settings, e[0], c[0])
+    tr = ref_pgdb_trace(res, qubits, n_iters)
+    if check_direct:
+        direct = T.pgdb_process_estimate(res, qubits)
+        assert tr["conv_iter"] > 0 and np.array_equal(direct, tr["conv"]), "driver loop departs from the reference"
+    print(f"fixed {n}q {basis} item {b}: conv_iter {tr['conv_iter']}, dykstra {tr['dykstra'].sum()}, "
+          f"halvings {tr['backtracks'].sum()}", flush=True)
+    return b, us[0], e[0], c[0], tr
+
+
+def make_process_fixed(n, basis, batch, n_iters=100, n_direct=2, workers=4, tag=None):
+    """`batch` bench items (synthetic.process_batch items 0..batch-1) through ref_pgdb_trace."""
+    import multiprocessing as mp
+    jobs = [(n, basis, b, n_iters, b < n_direct) for b in range(batch)]
+    with mp.Pool(workers) as pool:
+        out = sorted(pool.map(_fixed_worker, jobs, chunksize=1), key=lambda r: r[0])
+    design = synthetic.process_batch(n, basis, 1)[0]
+    np.savez_compressed(os.path.join(HERE, tag or f"process_{n}q_{basis}_fixed{n_iters}.npz"),
+                        n_qubits=n, n_iters=n_iters, in_labels=design.in_labels, paulis=design.paulis,
+                        unitaries=np.array([r[1] for r in out]), expectations=np.array([r[2] for r in out]),
+                        counts=np.array([r[3] for r in out]),
+                        pgdb_fixed=np.array([r[4]["fixed"] for r in out]),
+                        pgdb_conv=np.array([r[4]["conv"] for r in out]),
+                        conv_iter=np.array([r[4]["conv_iter"] for r in out], dtype=np.int32),
+                        dykstra=np.array([r[4]["dykstra"] for r in out]),
+                        backtracks=np.array([r[4]["backtracks"] for r in out]),
+                        costs=np.array([r[4]["costs"] for r in out]))
+    print("fixed", n, basis, batch, "done")
+
+
 if __name__ == "__main__":
     np.random.seed(0)
+    if "--fixed2q" in sys.argv:           # timed-mode fixtures, 2 qubits (a few minutes on 6 cores)
+        make_process_fixed(2, "pauli", 64, workers=6)
+        make_process_fixed(2, "sic", 16, workers=6)
+        sys.exit(0)
+    if "--fixed3q" in sys.argv:           # 3 qubits: 16 items, ~1.5 GB and a few minutes each
+        make_process_fixed(3, "sic", 16, workers=4)
+        sys.exit(0)
     if "--round2" in sys.argv:
         make_round2()
         sys.exit(0)

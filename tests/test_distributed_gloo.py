@@ -84,7 +84,7 @@ def _files_worker(rank, world, rdzv_dir, out_dir):
     for p in (os.path.join(ROOT, "forest-benchmarking_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     from fbx.parallel import FileRendezvous, HostComm
-    r = FileRendezvous(rank, world, directory=rdzv_dir, timeout=60)
+    r = FileRendezvous(rank, world, directory=rdzv_dir, timeout=60, join_timeout=0.5)
     # the hand-off RcclComm needs: rank 0's 128-byte id reaches everybody
     ident = bytes(range(128)) if rank == 0 else b""
     assert r.allgather(ident, tag="rccl_id")[0] == bytes(range(128))
@@ -124,6 +124,32 @@ def test_two_rank_sharding_file_rendezvous(tmp_path):
     a = np.load(tmp_path / "full_host-files_0.npy"); b = np.load(tmp_path / "full_host-files_1.npy")
     assert np.array_equal(a, b) and np.allclose(a, _expected(), atol=1e-14)
     assert not os.path.exists(rd)               # every rank removed what it published
+
+
+def test_file_rendezvous_ignores_a_stale_directory(tmp_path):
+    """A directory left behind by a failed attempt (same path: torchrun restarts, a reused FBX_RDZV_DIR) holds a
+    generation marker, an RCCL id and join / ok files of ranks that no longer exist.  The new attempt must not
+    read any of it: rank 0 opens a fresh generation, a rank that saw the stale marker first re-joins."""
+    import multiprocessing as mp
+    rd = tmp_path / "rdzv"
+    rd.mkdir(mode=0o700)
+    (rd / "gen").write_text("deadbeefdeadbeef")
+    for name in ("deadbeefdeadbeef.join.0", "deadbeefdeadbeef.join.1", "deadbeefdeadbeef.rccl_ok.1", "close.0"):
+        (rd / name).write_bytes(b"1")
+    (rd / "deadbeefdeadbeef.ack.0").write_bytes(b"rank0,0123456789abcdef")       # a complete-looking dead generation
+    (rd / "deadbeefdeadbeef.rccl_id.0").write_bytes(b"\xff" * 128 + b"|")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_files_worker, args=(r, 2, str(rd), str(tmp_path))) for r in (1, 0)]
+    procs[0].start()                            # rank 1 first: it finds only the stale generation
+    import time
+    time.sleep(1.0)
+    procs[1].start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    a = np.load(tmp_path / "full_host-files_0.npy"); b = np.load(tmp_path / "full_host-files_1.npy")
+    assert np.array_equal(a, b) and np.allclose(a, _expected(), atol=1e-14)
+    assert not os.path.exists(rd)
 
 
 def test_shard_bounds_cover_the_batch_exactly():

@@ -1,8 +1,10 @@
-"""The N > 1 path on the hardware a test box has (ONE GPU): libfbx's RCCL communicator with a 1-rank world
-(every collective of include/fbx.h's fbx_comm_* section), and bench.py's own rank spawner with two ranks
-sharing the device -- RCCL refuses two ranks on one GPU, so that run exercises the launcher contract, the
-rendezvous, the sharded workload and the recorded host fallback; the RCCL collectives between ranks are
-covered by construction (same entry points) and by the driver's multi-GPU run."""
+"""The N > 1 path.  On a box with ONE GPU: libfbx's RCCL communicator with a 1-rank world (every collective of
+include/fbx.h's fbx_comm_* section), the bounded wait for a missing peer, and bench.py's own rank spawner with two
+ranks sharing the device (--oversubscribe: RCCL refuses two ranks on one GPU, so that run exercises the launcher
+contract, the rendezvous, the sharded workload and the recorded host fallback) -- and that WITHOUT --oversubscribe
+the same run fails instead of printing a number.  On a box with TWO OR MORE GPUs (skipped otherwise): a real 2-rank
+RcclComm -- all-gather, all-reduce, broadcast, run_sharded against the single-GPU answer -- and bench.py --gpus 2
+over RCCL."""
 import json
 import os
 import subprocess
@@ -76,3 +78,126 @@ def test_bench_single_rank_headline_only(gpu):
     r = line["roofline"]
     assert r["bound"] == "mfma" and 0 < r["executed_frac"] < r["frac"] < 1.5 and r["kernel_ms"] <= line["ms_per_step"] * 1.05
     assert "secondary" not in line and "cpu_baseline" not in line
+
+
+def test_bench_refuses_to_share_a_gpu_without_oversubscribe(gpu):
+    """One GPU per rank or no number: two ranks on a one-GPU box must exit non-zero (no host-files fallback)."""
+    import fbx
+    if fbx.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--total-batch", "64", "--batch", "64", "--iters", "5", "--spawn-timeout", "120"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())
+
+
+_TIMEOUT_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from fbx import _lib, parallel
+_lib.set_device(0)
+ident = parallel.RcclComm.new_unique_id()
+t0 = time.monotonic()
+try:
+    parallel.RcclComm(0, 2, ident, timeout=4.0)          # rank 1 never shows up
+    print("UNEXPECTED: initialised"); sys.stdout.flush(); os._exit(1)
+except _lib.FbxError as exc:
+    waited = time.monotonic() - t0
+    assert exc.code == _lib.FBX_ERR_RCCL and "did not return" in str(exc), str(exc)
+# afterwards nothing blocks: info and destroy return at once, another init is refused with FBX_ERR_RCCL
+t1 = time.monotonic()
+w = _lib.C.c_int(-1)
+_lib.check(_lib.lib().fbx_comm_info(None, _lib.C.byref(w), None))
+assert w.value == 0
+assert _lib.lib().fbx_comm_destroy() == 0
+assert _lib.lib().fbx_comm_barrier() == _lib.FBX_ERR_RCCL
+ident2 = (_lib.C.c_uint8 * 128).from_buffer_copy(ident)
+assert _lib.lib().fbx_comm_init_timeout(ident2, 0, 1, 5.0) == _lib.FBX_ERR_RCCL
+assert time.monotonic() - t1 < 2.0
+# the rest of the library still works in this process
+from fbx import synthetic, tomography
+d, _, e, c = synthetic.process_batch(1, "sic", 2)
+assert tomography.pgdb_process_estimate_batch(d, e, c).shape == (2, 4, 4)
+print("OK waited %.1f" % waited); sys.stdout.flush()
+os._exit(0)                                              # the helper thread still sits inside ncclCommInitRank
+"""
+
+
+def test_comm_init_times_out_on_a_missing_peer(gpu):
+    out = subprocess.run([sys.executable, "-c", _TIMEOUT_WORKER, os.path.join(ROOT, "forest-benchmarking_amd")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK waited" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
+    assert 3.5 < float(out.stdout.split("OK waited")[1].split()[0]) < 30.0
+
+
+_TWO_RANK_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from fbx import _lib, parallel, synthetic, tomography
+comm, rdzv = parallel.init_from_env()                    # no fallback: RCCL or an exception
+assert comm.backend == "rccl" and comm.world == 2 and comm.rank == int(os.environ["RANK"])
+q = comm.query()
+assert q["world"] == 2 and q["rank"] == comm.rank and q["device"] == int(os.environ["LOCAL_RANK"])
+ordinal, pci = _lib.device_id()
+rows = comm.allgather(np.frombuffer(pci.encode().ljust(32, b"\0"), dtype=np.uint8))
+assert rows.shape == (2, 32) and bytes(rows[0]) != bytes(rows[1])               # two physical devices
+# all-reduce: sum / max / min, and a vector longer than one staging chunk
+v = comm.allreduce([1.0 + comm.rank, 10.0 * comm.rank], "sum"); assert np.array_equal(v, [3.0, 10.0])
+assert comm.allreduce([float(comm.rank)], "max")[0] == 1.0 and comm.allreduce([float(comm.rank)], "min")[0] == 0.0
+big = comm.allreduce(np.arange(10000.0) * (comm.rank + 1), "sum"); assert np.array_equal(big, np.arange(10000.0) * 3)
+# all-gather of complex slabs, an odd byte count
+a = (np.arange(12.0).reshape(3, 4) * (comm.rank + 1) + 1j * comm.rank).astype(np.complex128)
+g = comm.allgather(a); assert g.shape == (2, 3, 4) and np.array_equal(g[comm.rank], a) and np.array_equal(g[1 - comm.rank].imag, np.full((3, 4), 1.0 - comm.rank))
+odd = np.arange(7, dtype=np.uint8) + comm.rank; g = comm.allgather(odd); assert np.array_equal(g[0], np.arange(7)) and np.array_equal(g[1], np.arange(7) + 1)
+# broadcast of design-sized constants from rank 1
+buf = _lib.DeviceBuffer.from_array(np.arange(64.0) if comm.rank == 1 else np.zeros(64))
+comm.broadcast_dev(buf.ptr, 512, 1); comm.barrier()
+assert np.array_equal(buf.to_array(np.float64, (64,)), np.arange(64.0))
+# the sharded estimator: 2-qubit PGDB on 37 items (ragged split 19 + 18), gathered on every rank
+design, _, e, c = synthetic.process_batch(2, "sic", 37)
+full, (lo, hi) = parallel.run_sharded(lambda eb, cb: tomography.pgdb_process_estimate_batch(design, eb, cb), [e, c], comm)
+assert (lo, hi) == parallel.shard_bounds(37, comm.rank, 2) and full.shape == (37, 16, 16)
+np.save(os.path.join(sys.argv[2], "full_%d.npy" % comm.rank), full)
+s, m = parallel.reduce_summary([hi - lo, float(np.trace(full[lo:hi], axis1=1, axis2=2).real.sum())], [hi - lo], comm)
+assert s[0] == 37 and m[0] == 19 and abs(s[1] - np.trace(full, axis1=1, axis2=2).real.sum()) < 1e-9
+comm.barrier(); comm.close(); rdzv.close()
+print("RANK_OK", comm.rank)
+"""
+
+
+def _needs_two_gpus():
+    import fbx
+    if fbx.device_count() < 2:
+        pytest.skip("needs at least two GPUs (one process per GPU over RCCL)")
+
+
+def test_two_rank_rccl_collectives_and_sharded_estimator(gpu, tmp_path):
+    """SURVEY 8e on hardware: two processes, two GPUs, libfbx's own communicator; the gathered sharded result equals
+    the single-GPU answer bit for bit (items are independent: the partition cannot change an item's arithmetic)."""
+    _needs_two_gpus()
+    from fbx import synthetic, tomography
+    rd = tmp_path / "rdzv"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
+                   FBX_RDZV_DIR=str(rd), HSA_ENABLE_IPC_MODE_LEGACY="0", FBX_RCCL_INIT_TIMEOUT="120")
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_RANK_WORKER, os.path.join(ROOT, "forest-benchmarking_amd"),
+                                       str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in so, (so[-1000:], se[-3000:])
+    design, _, e, c = synthetic.process_batch(2, "sic", 37)
+    want = tomography.pgdb_process_estimate_batch(design, e, c)
+    a, b = np.load(tmp_path / "full_0.npy"), np.load(tmp_path / "full_1.npy")
+    assert np.array_equal(a, b) and np.array_equal(a, want)
+
+
+def test_bench_two_gpus_over_rccl(gpu):
+    _needs_two_gpus()
+    line = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--total-batch", "4096", "--batch", "256", "--iters", "30")
+    col = line["config"]["collectives"]
+    assert col["backend"] == "rccl" and col["ranks"] == 2 and "rccl_failure" not in col
+    assert len({d["pci_bus_id"] for d in col["rank_devices"]}) == 2 and sorted(d["rank"] for d in col["rank_devices"]) == [0, 1]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["batch_per_gpu"] == 2048
