@@ -35,6 +35,13 @@ bool option_eigh_cooperative();                 // fbx_set_option("eigh_cooperat
 #endif
 int ensure_device();     // FBX_OK or FBX_ERR_NO_DEVICE (message set)
 
+// per-call arguments of fbx_pgdb_process_ex[_dev] beyond those of fbx_pgdb_process
+struct PgdbExtras {
+    double eig_rel_tol = -1.0;     // < 0: the process default (fbx_set_option)
+    int32_t* trace = nullptr;      // DEVICE [B][trace_iters][2]: Dykstra iterations and halvings of every outer iteration
+    int trace_iters = 0;
+};
+
 // Named grow-only device workspaces of the calling thread (kept between calls; released by
 // fbx_release_workspace).  A workspace only ever serves kernels on the calling thread's stream, so
 // growing it (stream sync + hipFree + hipMalloc) cannot pull memory from under another thread's kernel.

@@ -124,7 +124,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
           int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
           double* __restrict__ cost_out, int* __restrict__ work_out,
           long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-          double* __restrict__ ncounts) {
+          double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
@@ -265,6 +265,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
 
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
+        const int dyk_before = dyk, bt_before = backtracks;       // per-iteration trace (fbx_pgdb_process_ex)
         // A stored basis is the product of all rotations applied to its chain since the last cold start, and every
         // rotation costs ~1e-16 of unitarity: the chains are dropped once they have absorbed FBX_BASIS_CHAIN_SWEEPS
         // sweeps per slot (216 sweeps x 120 rotations: < 3e-12 even if every rounding error had the same sign; the
@@ -589,6 +590,10 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
         PH_STOP(pc, 5);
         est = blk_axpy(est, alpha, upd);            // tomography.py:588
         outer_step = alpha * sqrt(uniform(wave_sum(blk_norm2(upd))));
+        if (trace_out && iters < trace_iters && lane == 0) {     // Dykstra iterations and halvings of THIS outer iteration
+            int* tr = trace_out + ((size_t)item * trace_iters + iters) * 2;
+            tr[0] = dyk - dyk_before; tr[1] = backtracks - bt_before;
+        }
         ++iters;
         if (mode == FBX_MODE_CONVERGE) {
             if (!(old_cost - new_cost >= PGDB_STOP)) break;      // tomography.py:589; a NaN cost also ends the loop
@@ -632,11 +637,12 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
             double* __restrict__ cost_out, int* __restrict__ work_out,
             long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-            double* __restrict__ ncounts) {
+            double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     (void)ncounts;
     pgdb_body<NQ, MAXJ, false>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
-                               dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, nullptr);
+                               dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, nullptr,
+                               trace_out, trace_iters);
 }
 
 // The same reconstruction with the lean LDS layout (16.5 KB) and at most 256 registers: TWO wavefronts per
@@ -651,11 +657,11 @@ pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                  int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
                  double* __restrict__ cost_out, int* __restrict__ work_out,
                  long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-                 double* __restrict__ ncounts) {
+                 double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     pgdb_body<NQ, MAXJ, true>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
                               dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
-                              ncounts ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr);
+                              ncounts ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters);
 }
 
 #ifdef FBX_DIAGNOSTICS
@@ -677,7 +683,7 @@ long long* g_phase_out = nullptr;          // diagnostics builds only: set by fb
 template <int NQ, int MAXJ>
 static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                        int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
-                       double* cost, int32_t* sw) {
+                       double* cost, int32_t* sw, const PgdbExtras& ex) {
     // batches that put several reconstructions on a SIMD take the lean two-waves-per-SIMD kernel (2 qubits)
     const bool lean = NQ == 2 && B >= FBX_LEAN_MIN_BATCH;
     size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
@@ -716,14 +722,15 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     }
     const size_t m = des->dev.m;
     DesignDev dev = des->dev;
-    dev.eig_rel_tol = option_pgdb_eig_rel_tol(NQ);
+    dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(NQ);     // per call, else the process default
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, stream(), dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2,
                            it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr,
                            cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr,
-                           FBX_PHASE_OUT(b0), basis, BASIS_CAP, ncounts);
+                           FBX_PHASE_OUT(b0), basis, BASIS_CAP, ncounts,
+                           ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr, ex.trace_iters);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
@@ -731,22 +738,22 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
 
 int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
                    int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost,
-                   int32_t* sw);   // fbx_pgdb3.hip
+                   int32_t* sw, const PgdbExtras& ex);   // fbx_pgdb3.hip
 
 static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                          int mode, int max_iters, double* choi, int32_t* it, int32_t* dy,
-                         int32_t* bt, double* cost, int32_t* sw) {
+                         int32_t* bt, double* cost, int32_t* sw, const PgdbExtras& ex) {
     const int n = des->dev.n, m = des->dev.m;
     if (n == 1) {
-        if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
-        if (m <= 256) return launch_pgdb<1, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+        if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+        if (m <= 256) return launch_pgdb<1, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     } else if (n == 2) {
-        if (m <= 256) return launch_pgdb<2, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
-        if (m <= 576) return launch_pgdb<2, 9>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
-        if (m <= 1024) return launch_pgdb<2, 16>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+        if (m <= 256) return launch_pgdb<2, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+        if (m <= 576) return launch_pgdb<2, 9>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+        if (m <= 1024) return launch_pgdb<2, 16>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     }
     else if (n == 3) {
-        return pgdb3_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+        return pgdb3_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     }
     set_error("fbx_pgdb_process: design outside the supported sizes (1 qubit m <= 256, 2 qubits m <= 1024)");
     return FBX_ERR_UNSUPPORTED;
@@ -790,40 +797,67 @@ int fbx_debug_log(const double* x, double* out, int64_t n) {
 }
 #endif
 
-int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
-                         const double* d_counts, int trace_preserving, int mode, int max_iters,
-                         double* d_choi_out, int32_t* d_iters_out, int32_t* d_dykstra_out,
-                         int32_t* d_backtracks_out, double* d_cost_out, int32_t* d_work_out) {
+static int check_extras(double eig_rel_tol, const void* trace, int trace_iters) {
+    FBX_REQUIRE(eig_rel_tol < 0.0 || eig_rel_tol <= 1e-3, "fbx_pgdb_process_ex: eig_rel_tol must be negative (default) or in [0, 1e-3]");
+    FBX_REQUIRE(eig_rel_tol == eig_rel_tol, "fbx_pgdb_process_ex: eig_rel_tol is NaN");
+    FBX_REQUIRE(trace_iters >= 0 && (trace == nullptr || trace_iters > 0), "fbx_pgdb_process_ex: trace_out needs trace_iters > 0");
+    return FBX_OK;
+}
+
+int fbx_pgdb_process_ex_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                            const double* d_counts, int trace_preserving, int mode, int max_iters,
+                            double eig_rel_tol, double* d_choi_out, int32_t* d_iters_out, int32_t* d_dykstra_out,
+                            int32_t* d_backtracks_out, double* d_cost_out, int32_t* d_work_out,
+                            int32_t* d_trace_out, int trace_iters) {
     int rc = ensure_device();
     if (rc) return rc;
     rc = pgdb_check(design, B, d_expect, d_counts, mode, max_iters, d_choi_out);
     if (rc) return rc;
+    rc = check_extras(eig_rel_tol, d_trace_out, trace_iters);
+    if (rc) return rc;
     if (B == 0) return FBX_OK;
+    PgdbExtras ex; ex.eig_rel_tol = eig_rel_tol; ex.trace = d_trace_out; ex.trace_iters = d_trace_out ? trace_iters : 0;
+    if (ex.trace) FBX_HIP(hipMemsetAsync(ex.trace, 0, sizeof(int32_t) * 2 * (size_t)B * trace_iters, stream()));
     return pgdb_dispatch(design, B, d_expect, d_counts, trace_preserving, mode, max_iters,
-                         d_choi_out, d_iters_out, d_dykstra_out, d_backtracks_out, d_cost_out, d_work_out);
+                         d_choi_out, d_iters_out, d_dykstra_out, d_backtracks_out, d_cost_out, d_work_out, ex);
 }
 
-int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
-                     const double* counts, int trace_preserving, int mode, int max_iters,
-                     double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
-                     int32_t* backtracks_out, double* cost_out, int32_t* work_out) {
+int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                         const double* d_counts, int trace_preserving, int mode, int max_iters,
+                         double* d_choi_out, int32_t* d_iters_out, int32_t* d_dykstra_out,
+                         int32_t* d_backtracks_out, double* d_cost_out, int32_t* d_work_out) {
+    return fbx_pgdb_process_ex_dev(design, B, d_expect, d_counts, trace_preserving, mode, max_iters, -1.0, d_choi_out,
+                                   d_iters_out, d_dykstra_out, d_backtracks_out, d_cost_out, d_work_out, nullptr, 0);
+}
+
+int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expect,
+                        const double* counts, int trace_preserving, int mode, int max_iters, double eig_rel_tol,
+                        double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
+                        int32_t* backtracks_out, double* cost_out, int32_t* work_out,
+                        int32_t* trace_out, int trace_iters) {
     int rc = ensure_device();
     if (rc) return rc;
     rc = pgdb_check(design, B, expect, counts, mode, max_iters, choi_out);
     if (rc) return rc;
+    rc = check_extras(eig_rel_tol, trace_out, trace_iters);
+    if (rc) return rc;
     if (B == 0) return FBX_OK;
     const size_t m = design->dev.m, D = design->dev.D;
-    DevBuf de, dc, dchoi, dit, ddy, dbt, dcost, dsw;
+    const size_t trace_bytes = trace_out ? sizeof(int32_t) * 2 * (size_t)B * trace_iters : 0;
+    DevBuf de, dc, dchoi, dit, ddy, dbt, dcost, dsw, dtr;
     if ((rc = de.alloc(sizeof(double) * B * m)) || (rc = dc.alloc(sizeof(double) * B * m)) ||
         (rc = dchoi.alloc(sizeof(double) * 2 * B * D * D)) || (rc = dit.alloc(sizeof(int32_t) * B)) ||
         (rc = ddy.alloc(sizeof(int32_t) * B)) || (rc = dbt.alloc(sizeof(int32_t) * B)) ||
-        (rc = dcost.alloc(sizeof(double) * B)) || (rc = dsw.alloc(sizeof(int32_t) * 4 * B)))
+        (rc = dcost.alloc(sizeof(double) * B)) || (rc = dsw.alloc(sizeof(int32_t) * 4 * B)) ||
+        (trace_bytes && (rc = dtr.alloc(trace_bytes))))
         return rc;
     FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
     FBX_HIP(hipMemcpyAsync(dc.p, counts, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
+    PgdbExtras ex; ex.eig_rel_tol = eig_rel_tol; ex.trace = trace_bytes ? dtr.as<int32_t>() : nullptr; ex.trace_iters = trace_bytes ? trace_iters : 0;
+    if (ex.trace) FBX_HIP(hipMemsetAsync(ex.trace, 0, trace_bytes, stream()));
     rc = pgdb_dispatch(design, B, de.as<double>(), dc.as<double>(), trace_preserving, mode, max_iters,
                        dchoi.as<double>(), dit.as<int32_t>(), ddy.as<int32_t>(), dbt.as<int32_t>(),
-                       dcost.as<double>(), dsw.as<int32_t>());
+                       dcost.as<double>(), dsw.as<int32_t>(), ex);
     if (rc) { (void)hipStreamSynchronize(stream()); return rc; }
     FBX_HIP(hipMemcpyAsync(choi_out, dchoi.p, sizeof(double) * 2 * B * D * D, hipMemcpyDeviceToHost, stream()));
     if (iters_out) FBX_HIP(hipMemcpyAsync(iters_out, dit.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
@@ -831,8 +865,17 @@ int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
     if (backtracks_out) FBX_HIP(hipMemcpyAsync(backtracks_out, dbt.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
     if (cost_out) FBX_HIP(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
     if (work_out) FBX_HIP(hipMemcpyAsync(work_out, dsw.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, stream()));
+    if (trace_bytes) FBX_HIP(hipMemcpyAsync(trace_out, dtr.p, trace_bytes, hipMemcpyDeviceToHost, stream()));
     FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
+}
+
+int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
+                     const double* counts, int trace_preserving, int mode, int max_iters,
+                     double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
+                     int32_t* backtracks_out, double* cost_out, int32_t* work_out) {
+    return fbx_pgdb_process_ex(design, B, expect, counts, trace_preserving, mode, max_iters, -1.0, choi_out, iters_out,
+                               dykstra_out, backtracks_out, cost_out, work_out, nullptr, 0);
 }
 
 }  // extern "C"

@@ -431,7 +431,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
              int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out,
              int* __restrict__ iters_out, int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
              double* __restrict__ cost_out, cplx* __restrict__ scratch, long long* __restrict__ phase_out, int* __restrict__ sweeps_out,
-             cplx* __restrict__ basis_scratch, int basis_cap) {
+             cplx* __restrict__ basis_scratch, int basis_cap, int* __restrict__ trace_out, int trace_iters) {
     using namespace p3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds L; L.carve(smem);
@@ -504,6 +504,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
     PH_START(pc);
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
+        const int dyk_before = dyk, bt_before = backtracks;       // per-iteration trace (fbx_pgdb_process_ex)
         choi_to_pauli(est, L, t);
         PH_STOP(pc, 3);
         predict_table(des, L, t);
@@ -605,6 +606,10 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         }
         est = blk_axpy(est, alpha, upd);
         outer_step = alpha * sqrt(bsum(blk_norm2(upd), L));
+        if (trace_out && iters < trace_iters && t == 0) {
+            int* tr = trace_out + ((size_t)item * trace_iters + iters) * 2;
+            tr[0] = dyk - dyk_before; tr[1] = backtracks - bt_before;
+        }
         ++iters;
         PH_STOP(pc, 5);
         if (mode == FBX_MODE_CONVERGE) {
@@ -639,7 +644,8 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
 
 template <int MAXJ>
 static int launch3(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
-                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw) {
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw,
+                   const PgdbExtras& ex) {
     const size_t lds = p3::Lds::bytes();
     if ((size_t)des->dev.S * p3::D * sizeof(double) > 2 * sizeof(cplx) * p3::D * p3::D) {
         set_error("fbx_pgdb_process: too many distinct input states for the 3-qubit kernel");
@@ -661,13 +667,14 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     cplx* basis = scratch;                   // (`scratch` itself only tells the kernel that warm starts are on)
     const size_t m = des->dev.m, DD = (size_t)p3::D * p3::D;
     DesignDev dev = des->dev;
-    dev.eig_rel_tol = option_pgdb_eig_rel_tol(3);
+    dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(3);
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
                            dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch,
-                           FBX_PHASE_OUT3(b0), sw ? sw + 4 * b0 : nullptr, basis, BASIS_CAP);
+                           FBX_PHASE_OUT3(b0), sw ? sw + 4 * b0 : nullptr, basis, BASIS_CAP,
+                           ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr, ex.trace_iters);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
@@ -748,10 +755,11 @@ int linv_process3_launch(const fbx_design* des, int64_t B, const double* d_expec
 
 // called from fbx_pgdb.hip's dispatcher
 int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
-                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw) {
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw,
+                   const PgdbExtras& ex) {
     const int m = des->dev.m;
-    if (m <= 4096) return launch3<4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
-    if (m <= 14336) return launch3<14>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw);
+    if (m <= 4096) return launch3<4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+    if (m <= 14336) return launch3<14>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     set_error("fbx_pgdb_process: 3-qubit designs are limited to 14336 settings");
     return FBX_ERR_UNSUPPORTED;
 }

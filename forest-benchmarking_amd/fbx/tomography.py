@@ -275,9 +275,14 @@ def linear_inv_process_estimate(results: List[ExperimentResult], qubits: List[in
 
 
 def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trace_preserving=True,
-                                mode="converge", max_iters=0, return_stats=False):
+                                mode="converge", max_iters=0, return_stats=False, eig_rel_tol=None,
+                                trace_iters=0):
     """Batched pgdb_process_estimate.  ``mode='converge'`` is the reference loop (optionally
-    capped by ``max_iters``); ``mode='fixed'`` runs exactly ``max_iters`` outer iterations."""
+    capped by ``max_iters``); ``mode='fixed'`` runs exactly ``max_iters`` outer iterations.
+    ``eig_rel_tol``: the eigensolver tolerance factor for THIS call (None = the process default,
+    0 = the reference's trajectory iteration by iteration; include/fbx.h fbx_pgdb_process_ex).
+    ``trace_iters`` > 0 adds ``stats['trace']`` [B, trace_iters, 2]: Dykstra iterations and halvings of
+    every outer iteration."""
     if mode not in ("converge", "fixed"):
         raise ValueError("mode must be 'converge' or 'fixed'")
     e, c = _batch_arrays(design, expectations, total_counts)
@@ -288,15 +293,20 @@ def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trac
     bt = np.zeros(B, dtype=np.int32)
     cost = np.zeros(B)
     work = np.zeros((B, 4), dtype=np.int32)
-    _lib.check(_lib.lib().fbx_pgdb_process(
+    trace = np.zeros((B, int(trace_iters), 2), dtype=np.int32) if trace_iters > 0 else None
+    _lib.check(_lib.lib().fbx_pgdb_process_ex(
         design.handle, B, _lib.dptr(e), _lib.dptr(c), int(bool(trace_preserving)),
         _lib.MODE_FIXED if mode == "fixed" else _lib.MODE_CONVERGE, int(max_iters),
+        -1.0 if eig_rel_tol is None else float(eig_rel_tol),
         _lib.dptr(choi.view(np.float64)), _lib.iptr(iters), _lib.iptr(dyk), _lib.iptr(bt),
-        _lib.dptr(cost), _lib.iptr(work)))
+        _lib.dptr(cost), _lib.iptr(work), _lib.iptr(trace), int(trace_iters) if trace is not None else 0))
     if return_stats:
-        return choi, {"iterations": iters, "dykstra": dyk, "backtracks": bt, "cost": cost,
-                      "jacobi_sweeps": work[:, 0], "eig_terms": work[:, 1], "cost_evals": work[:, 2],
-                      "power_sum_passes": work[:, 3]}
+        st = {"iterations": iters, "dykstra": dyk, "backtracks": bt, "cost": cost,
+              "jacobi_sweeps": work[:, 0], "eig_terms": work[:, 1], "cost_evals": work[:, 2],
+              "power_sum_passes": work[:, 3]}
+        if trace is not None:
+            st["trace"] = trace
+        return choi, st
     return choi
 
 

@@ -82,7 +82,8 @@ int         fbx_device_name(char* buf, size_t len, int* compute_units);
 int         fbx_device_id(int* ordinal, char* pci_bus_id, size_t len);   /* the selected device; "0000:05:00.0"-style id (len >= 16) */
 int         fbx_synchronize(void);                  /* the calling thread's stream */
 int         fbx_release_workspace(void);            /* free the calling thread's cached device workspaces / staging pool */
-/* Process-wide tunables, read when a kernel is launched.
+/* Process-wide DEFAULTS, read when a kernel is launched.  A thread that needs its own value passes it per call
+ * (fbx_pgdb_process_ex): changing an option changes the arithmetic of every thread's later launches.
  *   "pgdb_eig_rel_tol"  (default 1e-8), "pgdb3_eig_rel_tol" (default 1e-7; 3 qubits): while the projected-gradient
  *   iteration of fbx_pgdb_process is far from its fixed point, the eigensolver of its CP projections stops at an
  *   off-diagonal norm of <value> x the previous outer step (relative to ||H||_F) instead of always at 1e-13 --
@@ -169,6 +170,24 @@ int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_ex
                          int max_iters, double* d_choi_out, int32_t* d_iters_out,
                          int32_t* d_dykstra_out, int32_t* d_backtracks_out,
                          double* d_cost_out, int32_t* d_work_out);
+
+/* The same estimator with per-call arguments (what concurrent callers use instead of the process-wide option):
+ *   eig_rel_tol   tolerance factor of the CP projections' eigensolver for THIS call (see fbx_set_option
+ *                 "pgdb_eig_rel_tol"); negative = the process default; 0 = the reference's eigh-to-machine-precision
+ *                 trajectory; range [0, 1e-3]
+ *   trace_out     [B][trace_iters][2] int32 (may be NULL): for every outer iteration k < trace_iters of item b the
+ *                 Dykstra iterations (proj_choi_to_physical, project_superoperators.py:112-144) and the step halvings
+ *                 (tomography.py:578-585) of that iteration; rows beyond the item's last iteration are zero. */
+int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expect,
+                        const double* counts, int trace_preserving, int mode, int max_iters,
+                        double eig_rel_tol, double* choi_out, int32_t* iters_out,
+                        int32_t* dykstra_out, int32_t* backtracks_out, double* cost_out,
+                        int32_t* work_out, int32_t* trace_out, int trace_iters);
+int fbx_pgdb_process_ex_dev(const fbx_design* design, int64_t B, const double* d_expect,
+                            const double* d_counts, int trace_preserving, int mode, int max_iters,
+                            double eig_rel_tol, double* d_choi_out, int32_t* d_iters_out,
+                            int32_t* d_dykstra_out, int32_t* d_backtracks_out, double* d_cost_out,
+                            int32_t* d_work_out, int32_t* d_trace_out, int trace_iters);
 
 /* linear_inv_process_estimate (tomography.py:459-491): choi_out[B][D][D]. */
 int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect,

@@ -312,7 +312,9 @@ def make_round2():
 # converged estimate (a snapshot at that iteration, asserted bit-identical to a direct
 # pgdb_process_estimate call for the first items of every set), the fixed-N estimate, and per-iteration
 # Dykstra / halving counts and costs.
-def ref_pgdb_trace(results, qubits, n_iters, trace_preserving=True):
+def ref_pgdb_trace(results, qubits, n_iters, trace_preserving=True, max_iters=400):
+    """Runs until BOTH `n_iters` iterations are done (the fixed-N snapshot) and the stopping rule of :589 has fired
+    once (the converged snapshot) -- three-qubit experiments can need more than 100 iterations to converge."""
     import importlib
     PS = importlib.import_module("forest.benchmarking.operator_tools.project_superoperators")
     calls = [0]
@@ -331,8 +333,9 @@ def ref_pgdb_trace(results, qubits, n_iters, trace_preserving=True):
         mu = 3 / (2 * dim ** 2)
         gamma = .3
         dyk, bts, costs = [], [], []
-        conv_iter, conv_est = 0, None
-        for it in range(n_iters):
+        conv_iter, conv_est, fixed_est = 0, None, None
+        it = 0
+        while it < max_iters and (fixed_est is None or conv_est is None):
             gradient = T._grad_cost(A, n, est)
             calls[0] = 0
             update = T.proj_choi_to_physical(est - gradient / mu, trace_preserving) - est
@@ -349,15 +352,21 @@ def ref_pgdb_trace(results, qubits, n_iters, trace_preserving=True):
                 if alpha < 1e-15:
                     break
             est += alpha * update
+            it += 1
             bts.append(bt)
             costs.append(float(np.real(new_cost).ravel()[0]))
             if conv_est is None and old_cost - new_cost < 1e-10:      # tomography.py:589 would stop here
-                conv_iter, conv_est = it + 1, est.copy()
+                conv_iter, conv_est = it, est.copy()
+            if it == n_iters:
+                fixed_est = est.copy()
             old_cost = new_cost
     finally:
         PS.proj_choi_to_completely_positive = orig_cp
-    return dict(fixed=est, conv=conv_est if conv_est is not None else np.full_like(est, np.nan), conv_iter=conv_iter,
-                dykstra=np.array(dyk, dtype=np.int32), backtracks=np.array(bts, dtype=np.int32), costs=np.array(costs))
+    assert fixed_est is not None and conv_est is not None, "not converged within max_iters"
+    L = 256                                      # common trace length of the fixtures; -1 = iteration not run
+    pad = lambda v, dt: np.concatenate([np.asarray(v, dtype=dt), np.full(L - len(v), -1, dtype=dt)])
+    return dict(fixed=fixed_est, conv=conv_est, conv_iter=conv_iter, dykstra=pad(dyk, np.int32),
+                backtracks=pad(bts, np.int32), costs=pad(costs, np.float64))
 
 
 def _fixed_worker(job):
@@ -366,10 +375,20 @@ def _fixed_worker(job):
     design, us, e, c = synthetic.process_batch(n, basis, 1, first_item=b)
     settings = process_settings(qubits, basis)
     res = ref_results(settings, e[0], c[0])
+    # per-item cache (scratch, outside the repository) so that an interrupted run resumes
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "fbx_fixed_cache", f"{n}q_{basis}_{n_iters}_{b}.npz")
+    if os.path.exists(cache):
+        z = np.load(cache)
+        tr = {k: z[k] for k in z.files}
+        tr["conv_iter"] = int(tr["conv_iter"])
+        return b, us[0], e[0], c[0], tr
     tr = ref_pgdb_trace(res, qubits, n_iters)
     if check_direct:
         direct = T.pgdb_process_estimate(res, qubits)
         assert tr["conv_iter"] > 0 and np.array_equal(direct, tr["conv"]), "driver loop departs from the reference"
+    os.makedirs(os.path.dirname(cache), exist_ok=True)
+    np.savez(cache + ".tmp.npz", **tr)
+    os.replace(cache + ".tmp.npz", cache)
     print(f"fixed {n}q {basis} item {b}: conv_iter {tr['conv_iter']}, dykstra {tr['dykstra'].sum()}, "
           f"halvings {tr['backtracks'].sum()}", flush=True)
     return b, us[0], e[0], c[0], tr
