@@ -195,9 +195,13 @@ constexpr double FBX_JACOBI_TOL2 = FBX_JACOBI_TOL2_VALUE;
 // rounding.  Also returns the rotated diagonal  a' = a + u, d' = d - u,
 // u = |s|^2 (d - a) - 2 c f |b|^2.
 struct JRot { double c, sr, si, an, dn; };
+__device__ __forceinline__ JRot jacobi_rotation_beta(double a, double d, double br, double bi, double beta);
 __device__ __forceinline__ JRot jacobi_rotation(double a, double d, double br, double bi) {
-    const double beta = fma(br, br, bi * bi);
+    return jacobi_rotation_beta(a, d, br, bi, fma(br, br, bi * bi));
+}
+__device__ __forceinline__ JRot jacobi_rotation_beta(double a, double d, double br, double bi, double beta) {
     const double delta = 0.5 * (d - a);
+#ifdef FBX_JACOBI_LIVE_SELECTS      // round-2 form: explicit identity rotation for b == 0 (13 more instructions per round)
     const double h2 = fma(delta, delta, beta);
     const bool live = beta > 1e-290;                   // else: identity rotation
     const double ih = fast_rsqrt(live ? h2 : 1.0);
@@ -214,6 +218,23 @@ __device__ __forceinline__ JRot jacobi_rotation(double a, double d, double br, d
     r.an = live ? a + u : a;
     r.dn = live ? d - u : d;
     return r;
+#else
+    // |delta| + 1e-150 (absorbed by any |delta| > 1e-134, so every ordinary rotation is bit-identical to the form
+    // above) keeps h2 > 0: for b == 0 the formulas then give q = 1, c = 1, s = f b = 0, u = 0 by themselves -- the
+    // identity rotation without a single select.  (b so small that |b|^2 underflows while delta == 0 exactly:
+    // c = 1, |s| <= 1e150 |b| < 1e-10, unitary to 1e-20.)
+    const double ad = fabs(delta) + 1e-150;
+    const double h2 = fma(ad, ad, beta);
+    const double ih = fast_rsqrt(h2);
+    const double x = fma(0.5 * ad, ih, 0.5);           // (1 + q) / 2 in [0.5, 1]
+    const double ic = fast_rsqrt(x);
+    const double f = (delta >= 0.0 ? 0.5 : -0.5) * ih * ic;
+    const double fb = f * beta;
+    const double u = fma(f * fb, 2.0 * delta, -2.0 * (x * ic) * fb);
+    JRot r;
+    r.c = x * ic; r.sr = f * br; r.si = f * bi; r.an = a + u; r.dn = d - u;
+    return r;
+#endif
 }
 
 // 2x2 block update  m <- R_I^H m R_J  and eigenvector columns  v <- v R_J

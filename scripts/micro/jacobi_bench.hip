@@ -1,6 +1,9 @@
 // Micro-benchmark of the in-LDS Jacobi eigensolver (diagnostics; not part of the library).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../forest-benchmarking_amd/csrc jacobi_bench.hip -o jacobi_bench
 #include "fbx_eigh.hpp"
+#ifdef FBX_JACOBI_CHAIN_FIRST
+#include "jacobi_chain_first.hpp"      // round-3 experiment (measured, not adopted)
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -23,7 +26,11 @@ __global__ void __launch_bounds__(64) k_eigh(const double* A, double* W, double*
         }
         __syncthreads();
         long long t0 = __builtin_readcyclecounter();
+#ifdef FBX_JACOBI_CHAIN_FIRST
+        sweeps += jacobi_eigh_wave_chain_first<N>(M, V, lane, true);
+#else
         sweeps += jacobi_eigh_lds<N>(M, V, rot, lane);
+#endif
         total += __builtin_readcyclecounter() - t0;
         __syncthreads();
     }
