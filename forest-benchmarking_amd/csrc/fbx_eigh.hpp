@@ -131,11 +131,32 @@ __host__ __device__ constexpr int sys_plane() { return N == 16 ? 66 : (N / 2) * 
 template <int N>
 __host__ __device__ constexpr int sys_elems() { return 4 * sys_plane<N>(); }
 
+// Position of block (I, K) inside plane e = 2a + b.  N <= 32: row-major, I * NB + K.  N = 64 (round 3): the column
+// index is permuted inside its aligned group of eight so that EVERY b128 access of a Jacobi round is conflict-free --
+// a b128 LDS instruction is served in groups of 8 consecutive lanes = 8 consecutive column pairs of one block row, and
+// the tournament permutation sends such a group to the pairs {0, 2..8}, {9..16}, {17..24}, {25..31 top, 31 bottom}
+// (top entries) resp. {1 top, 0..6 bottom}, {7..14}, {15..22}, {23..30} (bottom entries).  With the row-major layout
+// pairs 0 and 8, and the top / bottom copies of pairs 31 and 1, share a bank group: 2-way conflicts in 3 of 8 lane
+// groups, +37 % write passes (profiles/r02: 27 % of the LDS cycles of the 3-qubit kernel).  Writing a column pair K at
+// residue rho(K) (mod 8) -- K mod 8, with residues 0 and 1 exchanged for K >= 8 -- and rotating the residues of the
+// bottom planes (b = 1) by 2 makes every one of those sets, the aligned read groups and the pivot reads distinct mod 8
+// (checked exhaustively by tests/test_host_logic.py::test_jacobi64_layout_is_conflict_free).
+template <int N>
+__host__ __device__ __forceinline__ constexpr int sys_pos(int I, int K, int e) {
+    constexpr int NB = N / 2;
+    if constexpr (N == 64) {
+        const int r = K & 7;
+        const int rho = (K >= 8 && r < 2) ? (r ^ 1) : r;
+        return I * NB + ((K & ~7) | ((rho + 2 * (e & 1)) & 7));
+    }
+    return I * NB + K;
+}
 // element (r, c) of an N x N matrix in the element-major block layout
 template <int N>
 __device__ __forceinline__ int sys_index(int r, int c) {
-    constexpr int NB = N / 2, PS = sys_plane<N>();
-    return ((r & 1) * 2 + (c & 1)) * PS + (r >> 1) * NB + (c >> 1);
+    constexpr int PS = sys_plane<N>();
+    const int e = (r & 1) * 2 + (c & 1);
+    return e * PS + sys_pos<N>(r >> 1, c >> 1, e);
 }
 // linear entry index (0 .. N*N-1, plane-major as stored without padding) -> offset in the layout
 template <int N>
@@ -148,8 +169,9 @@ template <int N>
 __device__ __forceinline__ void sys_store(cplx* Ms, int lane, const Blk& v) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     if (lane < LS) {
+        const int I = lane / NB, J = lane % NB;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { cplx c; c.re = v.re[e]; c.im = v.im[e]; Ms[e * PS + lane] = c; }
+        for (int e = 0; e < 4; ++e) { cplx c; c.re = v.re[e]; c.im = v.im[e]; Ms[e * PS + sys_pos<N>(I, J, e)] = c; }
     }
 }
 template <int N>
@@ -157,8 +179,9 @@ __device__ __forceinline__ Blk sys_load(const cplx* Ms, int lane) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     Blk v = blk_zero();
     if (lane < LS) {
+        const int I = lane / NB, J = lane % NB;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const cplx c = Ms[e * PS + lane]; v.re[e] = c.re; v.im[e] = c.im; }
+        for (int e = 0; e < 4; ++e) { const cplx c = Ms[e * PS + sys_pos<N>(I, J, e)]; v.re[e] = c.re; v.im[e] = c.im; }
     }
     return v;
 }
@@ -171,7 +194,8 @@ __device__ __forceinline__ Blk sys_load_adjoint(const cplx* Ms, int lane) {
         const int I = lane / NB, J = lane % NB;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const cplx c = Ms[((e & 1) * 2 + (e >> 1)) * PS + J * NB + I];
+            const int et = (e & 1) * 2 + (e >> 1);
+            const cplx c = Ms[et * PS + sys_pos<N>(J, I, et)];
             v.re[e] = c.re; v.im[e] = -c.im;
         }
     }
@@ -377,22 +401,25 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
 #endif
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
-    const int me = act ? lane : 0;
+    // own block of plane e: me0 for the planes with b = 0 (e = 0, 2), me1 for b = 1 (they differ only for N = 64)
+    const int me0 = sys_pos<N>(I, J, 0), me1 = sys_pos<N>(I, J, 1);
     int wm[4], wv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
-        wm[e] = ((sa & 1) * 2 + (sb & 1)) * PS + (sa >> 1) * NB + (sb >> 1);
-        wv[e] = ((e >> 1) * 2 + (sb & 1)) * PS + I * NB + (sb >> 1);
+        const int pm = (sa & 1) * 2 + (sb & 1), pv = (e >> 1) * 2 + (sb & 1);
+        wm[e] = pm * PS + sys_pos<N>(sa >> 1, sb >> 1, pm);
+        wv[e] = pv * PS + sys_pos<N>(I, sb >> 1, pv);
     }
-    const int dI = I * NB + I, dJ = J * NB + J;            // lanes owning the pivot blocks
+    const int dI0 = sys_pos<N>(I, I, 0), dI1 = sys_pos<N>(I, I, 1);    // pivot block of the row pair (two-chain variant only)
+    const int dJ0 = sys_pos<N>(J, J, 0), dJ1 = sys_pos<N>(J, J, 1);    // pivot block of the column pair: planes 0 / 1, 3
     const int src_lane = (lane & 63) - J + I;              // lane (I, I): same row, NB | 64 keeps rows inside a wave
-    (void)dI;
+    (void)dI0; (void)dI1;
     if (act && init_identity) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cplx v; v.re = (2 * I + (e >> 1) == 2 * J + (e & 1)) ? 1.0 : 0.0; v.im = 0.0;
-            Vs[e * PS + me] = v;
+            Vs[e * PS + ((e & 1) ? me1 : me0)] = v;
         }
     }
     if constexpr (NT > 64) __syncthreads(); else FBX_WAVE_SYNC();
@@ -402,7 +429,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             double o2 = 0.0, n2 = 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const cplx v = Ms[e * PS + me];
+                const cplx v = Ms[e * PS + ((e & 1) ? me1 : me0)];
                 const double a2 = v.re * v.re + v.im * v.im;
                 n2 += a2;
                 if (!(I == J && (e == 0 || e == 3))) o2 += a2;
@@ -414,15 +441,15 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
         }
         for (int r = 0; r < N - 1; ++r) {
 #ifdef FBX_JACOBI_TWO_CHAINS
-            const double aI = Ms[0 * PS + dI].re, dI_ = Ms[3 * PS + dI].re;
-            const cplx bI = Ms[1 * PS + dI];
+            const double aI = Ms[0 * PS + dI0].re, dI_ = Ms[3 * PS + dI1].re;
+            const cplx bI = Ms[1 * PS + dI1];
 #endif
-            const double aJ = Ms[0 * PS + dJ].re, dJ_ = Ms[3 * PS + dJ].re;
-            const cplx bJ = Ms[1 * PS + dJ];
-            cplx m00 = Ms[0 * PS + me], m01 = Ms[1 * PS + me];
-            cplx m10 = Ms[2 * PS + me], m11 = Ms[3 * PS + me];
-            cplx v0p = Vs[0 * PS + me], v0q = Vs[1 * PS + me];
-            cplx v1p = Vs[2 * PS + me], v1q = Vs[3 * PS + me];
+            const double aJ = Ms[0 * PS + dJ0].re, dJ_ = Ms[3 * PS + dJ1].re;
+            const cplx bJ = Ms[1 * PS + dJ1];
+            cplx m00 = Ms[0 * PS + me0], m01 = Ms[1 * PS + me1];
+            cplx m10 = Ms[2 * PS + me0], m11 = Ms[3 * PS + me1];
+            cplx v0p = Vs[0 * PS + me0], v0q = Vs[1 * PS + me1];
+            cplx v1p = Vs[2 * PS + me0], v1q = Vs[3 * PS + me1];
             // everything read before anyone overwrites it.  A single wavefront needs no barrier and no
             // wait here or after the writes: its LDS instructions execute in program order, so the
             // reads above see the previous round and the next round's reads see the writes below.
@@ -462,15 +489,15 @@ template <int N>
 __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int lane) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     const bool act = lane < LS;
-    const int I = act ? lane / NB : 0, J = act ? lane % NB : 0, me = act ? lane : 0;
+    const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
     cplx t[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { t[e].re = 0.0; t[e].im = 0.0; }
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int ke = 0; ke < 2; ++ke) {
-            const cplx h0 = Ms[(0 + ke) * PS + I * NB + kb], h1 = Ms[(2 + ke) * PS + I * NB + kb];   // H[2I+a][k]
-            const cplx v0 = Vs[(ke * 2 + 0) * PS + kb * NB + J], v1 = Vs[(ke * 2 + 1) * PS + kb * NB + J]; // V[k][2J+b]
+            const cplx h0 = Ms[(0 + ke) * PS + sys_pos<N>(I, kb, ke)], h1 = Ms[(2 + ke) * PS + sys_pos<N>(I, kb, ke)];   // H[2I+a][k]
+            const cplx v0 = Vs[(ke * 2 + 0) * PS + sys_pos<N>(kb, J, 0)], v1 = Vs[(ke * 2 + 1) * PS + sys_pos<N>(kb, J, 1)]; // V[k][2J+b]
             t[0].re += h0.re * v0.re - h0.im * v0.im; t[0].im += h0.re * v0.im + h0.im * v0.re;
             t[1].re += h0.re * v1.re - h0.im * v1.im; t[1].im += h0.re * v1.im + h0.im * v1.re;
             t[2].re += h1.re * v0.re - h1.im * v0.im; t[2].im += h1.re * v0.im + h1.im * v0.re;
@@ -479,7 +506,7 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     }
     if (act) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ts[e * PS + me] = t[e];
+        for (int e = 0; e < 4; ++e) Ts[e * PS + sys_pos<N>(I, J, e)] = t[e];
     }
     FBX_WAVE_SYNC();
 #pragma unroll
@@ -487,8 +514,8 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int ke = 0; ke < 2; ++ke) {
-            const cplx u0 = Vs[(ke * 2 + 0) * PS + kb * NB + I], u1 = Vs[(ke * 2 + 1) * PS + kb * NB + I]; // V[k][2I+a]
-            const cplx w0 = Ts[(ke * 2 + 0) * PS + kb * NB + J], w1 = Ts[(ke * 2 + 1) * PS + kb * NB + J]; // T[k][2J+b]
+            const cplx u0 = Vs[(ke * 2 + 0) * PS + sys_pos<N>(kb, I, 0)], u1 = Vs[(ke * 2 + 1) * PS + sys_pos<N>(kb, I, 1)]; // V[k][2I+a]
+            const cplx w0 = Ts[(ke * 2 + 0) * PS + sys_pos<N>(kb, J, 0)], w1 = Ts[(ke * 2 + 1) * PS + sys_pos<N>(kb, J, 1)]; // T[k][2J+b]
             // conj(u) * w
             t[0].re += u0.re * w0.re + u0.im * w0.im; t[0].im += u0.re * w0.im - u0.im * w0.re;
             t[1].re += u0.re * w1.re + u0.im * w1.im; t[1].im += u0.re * w1.im - u0.im * w1.re;
@@ -500,7 +527,7 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
     if (act) {
         if (I == J) { t[0].im = 0.0; t[3].im = 0.0; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ms[e * PS + me] = t[e];
+        for (int e = 0; e < 4; ++e) Ms[e * PS + sys_pos<N>(I, J, e)] = t[e];
     }
     FBX_WAVE_SYNC();
 }
@@ -576,8 +603,9 @@ __device__ __forceinline__ Blk reconstruct_blk(const cplx* Vs, const double* lam
         todo &= todo - 1;
         const double l = readlane_f64(mine, k);
         const int kb = k >> 1, ke = k & 1;
-        const cplx r0 = Vs[(0 + ke) * PS + I * NB + kb], r1 = Vs[(2 + ke) * PS + I * NB + kb];
-        const cplx c0 = Vs[(0 + ke) * PS + J * NB + kb], c1 = Vs[(2 + ke) * PS + J * NB + kb];
+        const int rk = sys_pos<N>(I, kb, ke), ck = sys_pos<N>(J, kb, ke);      // column k of the block rows I and J
+        const cplx r0 = Vs[(0 + ke) * PS + rk], r1 = Vs[(2 + ke) * PS + rk];
+        const cplx c0 = Vs[(0 + ke) * PS + ck], c1 = Vs[(2 + ke) * PS + ck];
         const double w0r = l * r0.re, w0i = l * r0.im, w1r = l * r1.re, w1i = l * r1.im;
         // w * conj(c)
         out.re[0] += w0r * c0.re + w0i * c0.im; out.im[0] += w0i * c0.re - w0r * c0.im;

@@ -87,8 +87,8 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int ke = 0; ke < 2; ++ke) {
-            const cplx h0 = L.Ms[(0 + ke) * NT + I * NB + kb], h1 = L.Ms[(2 + ke) * NT + I * NB + kb];
-            const cplx v0 = L.Vs[(ke * 2 + 0) * NT + kb * NB + J], v1 = L.Vs[(ke * 2 + 1) * NT + kb * NB + J];
+            const cplx h0 = L.Ms[sys_index<D>(2 * I, 2 * kb + ke)], h1 = L.Ms[sys_index<D>(2 * I + 1, 2 * kb + ke)];
+            const cplx v0 = L.Vs[sys_index<D>(2 * kb + ke, 2 * J)], v1 = L.Vs[sys_index<D>(2 * kb + ke, 2 * J + 1)];
             acc[0].re += h0.re * v0.re - h0.im * v0.im; acc[0].im += h0.re * v0.im + h0.im * v0.re;
             acc[1].re += h0.re * v1.re - h0.im * v1.im; acc[1].im += h0.re * v1.im + h0.im * v1.re;
             acc[2].re += h1.re * v0.re - h1.im * v0.im; acc[2].im += h1.re * v0.im + h1.im * v0.re;
@@ -98,15 +98,15 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
     // T = Ms V replaces Ms in place: H is dead once every thread has its block of the product
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) L.Ms[e * NT + t] = acc[e];
+    for (int e = 0; e < 4; ++e) L.Ms[sys_index<D>(2 * I + (e >> 1), 2 * J + (e & 1))] = acc[e];
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[e].re = 0.0; acc[e].im = 0.0; }
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int ke = 0; ke < 2; ++ke) {
-            const cplx u0 = L.Vs[(ke * 2 + 0) * NT + kb * NB + I], u1 = L.Vs[(ke * 2 + 1) * NT + kb * NB + I];
-            const cplx w0 = L.Ms[(ke * 2 + 0) * NT + kb * NB + J], w1 = L.Ms[(ke * 2 + 1) * NT + kb * NB + J];
+            const cplx u0 = L.Vs[sys_index<D>(2 * kb + ke, 2 * I)], u1 = L.Vs[sys_index<D>(2 * kb + ke, 2 * I + 1)];
+            const cplx w0 = L.Ms[sys_index<D>(2 * kb + ke, 2 * J)], w1 = L.Ms[sys_index<D>(2 * kb + ke, 2 * J + 1)];
             acc[0].re += u0.re * w0.re + u0.im * w0.im; acc[0].im += u0.re * w0.im - u0.im * w0.re;
             acc[1].re += u0.re * w1.re + u0.im * w1.im; acc[1].im += u0.re * w1.im - u0.im * w1.re;
             acc[2].re += u1.re * w0.re + u1.im * w0.im; acc[2].im += u1.re * w0.im - u1.im * w0.re;
@@ -116,7 +116,7 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
     __syncthreads();                                   // every thread is done reading Ms
     if (I == J) { acc[0].im = 0.0; acc[3].im = 0.0; }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) L.Ms[e * NT + t] = acc[e];
+    for (int e = 0; e < 4; ++e) L.Ms[sys_index<D>(2 * I + (e >> 1), 2 * J + (e & 1))] = acc[e];
     __syncthreads();
 }
 

@@ -88,3 +88,47 @@ def test_hinton_geometry_follows_the_reference_formulas():
     assert plotting.pauli_labels(2)[:6] == ["II", "IX", "IY", "IZ", "XI", "XX"]
     with pytest.raises(ValueError):
         plotting.pauli_labels(0)
+
+
+def test_jacobi64_layout_is_conflict_free():
+    """The LDS layout of the 64 x 64 Jacobi matrices (csrc/fbx_eigh.hpp sys_pos<64>, restated here): every b128 access
+    of a round -- the permuted writes of the matrix and eigenvector blocks, the read-back of the own block, the pivot
+    reads -- touches 8 distinct bank groups per group of 8 lanes; the row-major layout it replaces does not."""
+    NB, PS = 32, 1024
+
+    def seat(s):
+        k = s >> 1
+        if s & 1 == 0:
+            return 0 if k == 0 else (2 * (NB - 1) + 1 if k == NB - 1 else 2 * (k + 1))
+        return 2 if k == 0 else 2 * (k - 1) + 1
+
+    def pos(I, K, e, new):
+        if not new:
+            return I * NB + K
+        r = K & 7
+        rho = (r ^ 1) if (K >= 8 and r < 2) else r
+        return I * NB + ((K & ~7) | ((rho + 2 * (e & 1)) & 7))
+
+    def extra_passes(groups):
+        return sum(max(len({a for a in g if a % 8 == b}) for b in range(8)) - 1 for g in groups)
+
+    for new in (False, True):
+        assert len({(pl, pos(I, K, pl, new)) for pl in range(4) for I in range(NB) for K in range(NB)}) == 4 * NB * NB
+        total = 0
+        for e in range(4):
+            a, b = e >> 1, e & 1
+            mw, vw, own = [], [], []
+            for I in range(NB):
+                for J0 in range(0, NB, 8):
+                    gm, gv = [], []
+                    for J in range(J0, J0 + 8):
+                        sa, sb = seat(2 * I + a), seat(2 * J + b)
+                        pm, pv = (sa & 1) * 2 + (sb & 1), a * 2 + (sb & 1)
+                        gm.append(pm * PS + pos(sa >> 1, sb >> 1, pm, new))
+                        gv.append(pv * PS + pos(I, sb >> 1, pv, new))
+                    mw.append(gm); vw.append(gv)
+                    own.append([e * PS + pos(I, J, e, new) for J in range(J0, J0 + 8)])
+            total += extra_passes(mw) + extra_passes(vw) + extra_passes(own)
+        for pl in (0, 1, 3):
+            total += extra_passes([[pl * PS + pos(J, J, pl, new) for J in range(J0, J0 + 8)] for J0 in range(0, NB, 8)])
+        assert (total == 0) if new else (total == 384), total       # row-major: +37.5 % write passes
