@@ -283,17 +283,19 @@ def sweep_cpu_baseline(ks, ref, n_items):
                       f"rebuilt per call, choi2chi through eigh), {dt:.1f} s"}
 
 
-def pgdb3_cpu_baseline(design, e, c, iters):
-    """One 3-qubit item, 2 outer iterations of the oracle (dense 8064 x 4096 design matrix, hoisted),
-    scaled to `iters` iterations: the per-iteration cost is constant."""
+def pgdb3_cpu_baseline(design, e, c, iters, n_iters=10):
+    """One 3-qubit item, `n_iters` outer iterations of the oracle (dense 8064 x 4096 design matrix, hoisted; ~2 s per
+    iteration on one core), scaled to `iters` iterations: every iteration is one gradient (two dense mat-vecs), one
+    Dykstra projection and a line search, so the per-iteration cost of the first ten is that of the run (the stalled
+    iterations of a converged run are MORE expensive in the reference: ~50 cost evaluations each)."""
     od, oe, _, _ = _oracle()
     d = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)
     A = oe.design_matrix_A(d)
     t0 = time.perf_counter()
-    oe.pgdb_process_estimate(d, e[0], c[0], mode="fixed", max_iters=2, A=A)
+    oe.pgdb_process_estimate(d, e[0], c[0], mode="fixed", max_iters=n_iters, A=A)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / (dt * iters / 2.0), "unit": "reconstructions/s", "cores": 1, "kind": "port",
-            "sample": f"item 0, 2 outer iterations of the numpy oracle ({dt:.1f} s, design matrix hoisted), "
+    return {"value": 1.0 / (dt * iters / float(n_iters)), "unit": "reconstructions/s", "cores": 1, "kind": "port",
+            "sample": f"item 0, {n_iters} outer iterations of the numpy oracle ({dt:.1f} s, design matrix hoisted), "
                       f"extrapolated linearly to {iters} iterations"}
 
 
@@ -351,8 +353,7 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
     in-basis (4032 settings) unless --in-basis pauli (13 608), 100 fixed iterations."""
     B = 256
     basis = args.in_basis or "sic"
-    design, _, e32, c32 = synthetic.process_batch(3, basis, 32, first_item=32 * comm.rank)
-    e = np.tile(e32, (B // 32, 1)); c = np.tile(c32, (B // 32, 1))
+    design, _, e, c = synthetic.process_batch(3, basis, B, first_item=B * comm.rank)       # 256 DISTINCT experiments
     lib = _lib.lib()
     d_e, d_c = _lib.DeviceBuffer.from_array(e), _lib.DeviceBuffer.from_array(c)
     d_choi = _lib.DeviceBuffer(B * 64 * 64 * 16)
@@ -362,7 +363,7 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
         _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, _lib.MODE_FIXED, args.iters,
                                             d_choi.ptr, d_it.ptr, d_dy.ptr, None, None, d_w.ptr))
 
-    steps = max(1, min(args.steps, 3))
+    steps = max(1, min(args.steps, 5))
     elapsed, kms = timed_steps(step, steps, min(args.warmup, 1), comm, _lib)
     dyk = d_dy.to_array(np.int32, (B,)); its = d_it.to_array(np.int32, (B,)); work = d_w.to_array(np.int32, (B, 4))
     ksec = kms / 1e3 / steps
@@ -380,9 +381,11 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
             "data": "synthetic",
             "config": {"workload": f"{B} independent 3-qubit process tomographies per GPU, {basis} in-basis "
                                    f"({m} settings, 1000 shots), {args.iters} fixed PGDB iterations, inputs "
-                                   f"resident in HBM (32 distinct experiments, tiled)", "batch_per_gpu": B,
+                                   f"resident in HBM ({B} distinct experiments: items {B * comm.rank}..{B * comm.rank + B - 1} of the "
+                                   f"SURVEY 8d recipe)", "batch_per_gpu": B,
                        "iters": args.iters, "parallelism": f"shard{comm.world}",
-                       "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean())},
+                       "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean()),
+                       "max_over_mean_jacobi_sweeps": float(work[:, 0].max() / work[:, 0].mean())},
             "roofline": {"bound": "mfma", "pipe": "fp64 VALU + LDS", "achieved": tflops, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch"),
                          "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
@@ -539,6 +542,36 @@ def strong_anchor(args, comm, _lib, synthetic):
            "mean_jacobi_sweeps": float(st["work"][:, 0].mean()), "host_input_generation_s": t_gen,
            "note": "compare bench.py --gpus N (value = the same 65 536 items block-partitioned over N ranks) with THIS "
                    "figure, not with the 1024-item headline"}
+    # ---- the same with the transfers inside (SURVEY 8d's metric): page-locked host buffers, pipelined in stages
+    from fbx import tomography
+    incl = {}
+    pe, pc_ = _lib.pinned_copy(batch.e), _lib.pinned_copy(batch.c)
+    pout = _lib.pinned_empty((total, 16, 16), np.complex128)
+    for nb, calls in ((8192, 10), (total, 4)):
+        if nb > total:
+            continue
+        # resident reference for this batch size: the same items, inputs in HBM
+        L = _lib
+        def resident():
+            L.check(L.lib().fbx_pgdb_process_dev(batch.design.handle, nb, batch.d_e.ptr, batch.d_c.ptr, 1, L.MODE_FIXED, args.iters,
+                                                 batch.d_choi.ptr, batch.d_it.ptr, batch.d_dy.ptr, batch.d_bt.ptr,
+                                                 batch.d_cost.ptr, batch.d_work.ptr))
+        el, _ = timed_steps(resident, 3, 1, comm, _lib)
+        res_ms = 1e3 * el / 3
+        ts = []
+        for k in range(calls + 1):
+            t0 = time.perf_counter()
+            tomography.pgdb_process_estimate_batch(batch.design, pe[:nb], pc_[:nb], mode="fixed", max_iters=args.iters, out=pout[:nb])
+            ts.append(time.perf_counter() - t0)
+        th = float(np.median(ts[1:]))
+        incl[str(nb)] = {"value": nb / th, "unit": "reconstructions/s", "ms_per_call": 1e3 * th, "resident_ms": res_ms,
+                         "fraction_of_resident": res_ms / (1e3 * th), "calls": calls,
+                         "stages": -(-nb // int(_lib.get_option("pgdb_host_chunk")))}
+    out["pcie_inclusive"] = incl
+    out["pcie_inclusive_note"] = ("fbx_pgdb_process on page-locked host buffers: H2D of stage k + 1 and D2H of stage k - 1 under the "
+                                  "kernel of stage k (three streams, stages of fbx_set_option('pgdb_host_chunk') items); median of the "
+                                  "calls after one warm-up, against the HBM-resident launch of the same items")
+    del pe, pc_, pout
     batch.free()
     return out
 
@@ -561,16 +594,30 @@ def single_gpu_extras(args, comm, _lib, synthetic, batch, line):
                              "mean_dykstra_iters": float(stc["dykstra"].mean()),
                              "note": "FBX_MODE_CONVERGE: the reference loop (tomography.py:570-592); the mode the 1e-9 / "
                                      "1e-8 parity claim is made in"}
-    # ---- host-pointer entry point: H2D of expectations + counts, kernel, D2H of the Choi matrices
-    t_host = []
-    for k in range(4):
-        t0 = time.perf_counter()
-        tomography.pgdb_process_estimate_batch(batch.design, batch.e, batch.c, mode="fixed", max_iters=iters)
-        t_host.append(time.perf_counter() - t0)
-    th = float(np.median(t_host[1:]))
+    # ---- host-pointer entry point: H2D of expectations + counts, kernel, D2H of the Choi matrices (SURVEY.md 8d's
+    # definition of the metric).  Page-locked caller buffers (fbx_host_alloc): 8.8 MB in + 4.2 MB out at the PCIe rate.
+    # At B = 1024 there is exactly one reconstruction per SIMD, so the batch is ONE pipeline stage and nothing overlaps
+    # (a kernel reads its inputs in its first microseconds and writes its result in its last); the larger batches of
+    # the strong-scaling leg below are pipelined.  The pageable-numpy figure is kept next to it.
+    def host_calls(e_h, c_h, out_h, n):
+        ts = []
+        for k in range(n + 1):
+            t0 = time.perf_counter()
+            tomography.pgdb_process_estimate_batch(batch.design, e_h, c_h, mode="fixed", max_iters=iters, out=out_h)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts[1:]))
+    pe, pc_, pout = _lib.pinned_copy(batch.e), _lib.pinned_copy(batch.c), _lib.pinned_empty((B, 16, 16), np.complex128)
+    th = host_calls(pe, pc_, pout, 10)
+    tp = host_calls(batch.e, batch.c, None, 4)
+    resident_ms = line["ms_per_step"]
     line["pcie_inclusive"] = {"value": B / th, "unit": "reconstructions/s", "ms_per_call": 1e3 * th,
-                              "note": "fbx_pgdb_process on host buffers (pageable numpy arrays): 8.8 MB H2D + 4.2 MB "
-                                      "D2H per call, staging buffers from the library's pool; median of 3 calls after one warm-up"}
+                              "fraction_of_resident": resident_ms / (1e3 * th),
+                              "pageable": {"value": B / tp, "ms_per_call": 1e3 * tp},
+                              "note": "fbx_pgdb_process on page-locked host buffers (fbx_host_alloc): H2D of 8.8 MB, kernel, D2H of "
+                                      "4.2 MB, host call overhead; median of 10 calls after one warm-up.  `value` of this line "
+                                      "is the HBM-resident rate (the bench contract); this is SURVEY 8d's transfer-inclusive "
+                                      "rate.  One stage at B = 1024 (nothing to overlap); see strong_65536.pcie_inclusive"}
+    del pe, pc_, pout
     # ---- one experiment at a time through the reference signature (List[ExperimentResult], qubits)
     from fbx.observable_estimation import ExperimentResult
     settings = tomography.generate_process_tomography_settings([0, 1], args.in_basis)
@@ -639,6 +686,8 @@ def main():
             secondary.append(run_sweep(args, comm, _lib, synthetic, with_cpu))
             args.in_basis = None
             secondary.append(run_pgdb3(args, comm, _lib, synthetic, with_cpu))
+            args.in_basis = "pauli"                          # the stretch form of configs[3]: 13 608 settings
+            secondary.append(run_pgdb3(args, comm, _lib, synthetic, False))
             args.in_basis = basis
             _lib.release_workspace()
         line, batch = run_pgdb(args, comm, _lib, synthetic, rank_info)

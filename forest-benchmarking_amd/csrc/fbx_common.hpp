@@ -34,12 +34,20 @@ bool option_eigh_cooperative();                 // fbx_set_option("eigh_cooperat
 #define FBX3_JTOL_REL 1e-7
 #endif
 int ensure_device();     // FBX_OK or FBX_ERR_NO_DEVICE (message set)
+int copy_streams(hipStream_t* in, hipStream_t* out, hipStream_t* compute2);   // the calling thread's H2D / D2H / second compute stream (created on first use)
+int ordering_events(int n, hipEvent_t** out);            // >= n reusable events of the calling thread (no timing)
+bool host_pointer_is_pinned(const void* p);              // page-locked (fbx_host_alloc / hipHostMalloc / hipHostRegister)
+long long option_pgdb_host_chunk();                      // fbx_set_option("pgdb_host_chunk")
 
 // per-call arguments of fbx_pgdb_process_ex[_dev] beyond those of fbx_pgdb_process
 struct PgdbExtras {
     double eig_rel_tol = -1.0;     // < 0: the process default (fbx_set_option)
     int32_t* trace = nullptr;      // DEVICE [B][trace_iters][2]: Dykstra iterations and halvings of every outer iteration
     int trace_iters = 0;
+    // set by the pipelined host-pointer entry point only: the stream a stage's kernels go to, and the stage's share of
+    // the per-item workspace (two stages are in flight, each with its own `ws_items` slots starting at `ws_offset`)
+    hipStream_t launch_stream = nullptr;
+    int64_t ws_items = 0, ws_offset = 0;
 };
 
 // Named grow-only device workspaces of the calling thread (kept between calls; released by

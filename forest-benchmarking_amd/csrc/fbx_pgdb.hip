@@ -696,36 +696,44 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     if constexpr (NQ == 2) { if (lean) kern = pgdb_lean_kernel<NQ, MAXJ>; }
     FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each = 128 KiB per 2-qubit
-    // item, at most 1 GiB): a grow-only workspace of the calling thread (released by
-    // fbx_release_workspace); larger batches go in chunks that reuse it.  A single outer iteration has
-    // no previous iteration to take a basis from: no store then.
+    // item): a grow-only workspace of the calling thread (released by fbx_release_workspace).  A single
+    // outer iteration has no previous iteration to take a basis from: no store then.
     constexpr int D = 1 << (2 * NQ);
-    constexpr int64_t CHUNK = 8192;
-    const int64_t in_flight = B < CHUNK ? B : CHUNK;
-    cplx* basis = nullptr;
-    double* ncounts = nullptr;
-    {
-        // one workspace: [basis store | normalised counts of the lean kernel (2 x MAXJ x 64 doubles per item)]
-        const bool want_basis = !(mode == FBX_MODE_FIXED && max_iters <= 1) && !(mode == FBX_MODE_CONVERGE && max_iters == 1);
-        const size_t basis_bytes = want_basis ? sizeof(cplx) * D * D * BASIS_CAP * (size_t)in_flight : 0;
-        const size_t counts_bytes = lean ? sizeof(double) * 2 * MAXJ * 64 * (size_t)in_flight : 0;
-        if (basis_bytes + counts_bytes) {
+    // One launch for up to 65 536 reconstructions: the store is 128 KiB per 2-qubit item (8 GiB for 65 536 -- this part
+    // has 288 GB), and a launch that holds the whole batch keeps every SIMD busy until the last items, where a
+    // sequence of 8192-item launches idles at the end of each (the items of a launch differ by +-15 % in work).
+    // When the device cannot give that much, the launch size is halved until the store fits.
+    const bool want_basis = !(mode == FBX_MODE_FIXED && max_iters <= 1) && !(mode == FBX_MODE_CONVERGE && max_iters == 1);
+    const size_t basis_item = want_basis ? sizeof(cplx) * D * D * BASIS_CAP : 0;
+    const size_t counts_item = lean ? sizeof(double) * 2 * MAXJ * 64 : 0;
+    int64_t CHUNK = 65536;
+    char* wsp = nullptr;
+    int64_t ws_items = ex.ws_items > 0 ? ex.ws_items : (B < CHUNK ? B : CHUNK);
+    if (basis_item + counts_item) {
+        for (;;) {
+            // the pipelined host entry point owns 2 x ws_items slots; everybody else min(B, CHUNK)
+            const size_t total = (basis_item + counts_item) * (size_t)(ex.ws_items > 0 ? 2 * ex.ws_items : ws_items);
             void* w = nullptr;
-            const int rc = workspace(WS_PGDB_BASIS, basis_bytes + counts_bytes, &w);
-            if (rc) return rc;
-            if (want_basis) basis = (cplx*)w;
-            if (lean) ncounts = (double*)((char*)w + basis_bytes);
+            const int rc = workspace(WS_PGDB_BASIS, total, &w);
+            if (rc == FBX_OK) { wsp = (char*)w; break; }
+            if (rc != FBX_ERR_NOMEM || ex.ws_items > 0 || ws_items <= 1024) return rc;
+            (void)hipGetLastError();
+            ws_items /= 2; CHUNK = ws_items;
         }
-#ifdef FBX_LEAN_RECOUNT      // experiment: the lean kernel recomputes the counts from the inputs at every use
-        ncounts = nullptr;
-#endif
     }
+    const int64_t n_slots = ex.ws_items > 0 ? 2 * ex.ws_items : ws_items;
+    cplx* basis = basis_item ? (cplx*)wsp + (size_t)ex.ws_offset * D * D * BASIS_CAP : nullptr;
+    double* ncounts = counts_item ? (double*)(wsp + basis_item * (size_t)n_slots) + (size_t)ex.ws_offset * 2 * MAXJ * 64 : nullptr;
+#ifdef FBX_LEAN_RECOUNT      // experiment: the lean kernel recomputes the counts from the inputs at every use
+    ncounts = nullptr;
+#endif
     const size_t m = des->dev.m;
     DesignDev dev = des->dev;
     dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(NQ);     // per call, else the process default
+    hipStream_t st = ex.launch_stream ? ex.launch_stream : stream();
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, stream(), dev, (long long)nb,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, st, dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2,
                            it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr,
                            cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr,
@@ -851,10 +859,66 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
         (rc = dcost.alloc(sizeof(double) * B)) || (rc = dsw.alloc(sizeof(int32_t) * 4 * B)) ||
         (trace_bytes && (rc = dtr.alloc(trace_bytes))))
         return rc;
-    FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
-    FBX_HIP(hipMemcpyAsync(dc.p, counts, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
     PgdbExtras ex; ex.eig_rel_tol = eig_rel_tol; ex.trace = trace_bytes ? dtr.as<int32_t>() : nullptr; ex.trace_iters = trace_bytes ? trace_iters : 0;
     if (ex.trace) FBX_HIP(hipMemsetAsync(ex.trace, 0, trace_bytes, stream()));
+    // Page-locked caller buffers and more than one stage of work: a three-stream pipeline -- H2D of stage k + 1 and D2H
+    // of stage k - 1 run under the kernel of stage k (SURVEY.md 8d prices the path including both transfers).  A stage
+    // is fbx_set_option("pgdb_host_chunk") items (default 4096: every SIMD keeps at least two reconstructions).
+    const int64_t CH = option_pgdb_host_chunk();
+    if (B > CH && host_pointer_is_pinned(expect) && host_pointer_is_pinned(counts) && host_pointer_is_pinned(choi_out)) {
+        hipStream_t s_in, s_out, s_c2;
+        if ((rc = copy_streams(&s_in, &s_out, &s_c2))) return rc;
+        const int nst = (int)((B + CH - 1) / CH);
+        hipEvent_t* ev = nullptr;
+        if ((rc = ordering_events(2 * nst + 1, &ev))) return rc;
+        // (the staging buffers may still be in use by earlier work of this thread's stream)
+        FBX_HIP(hipEventRecord(ev[2 * nst], stream()));
+        FBX_HIP(hipStreamWaitEvent(s_in, ev[2 * nst], 0));
+        FBX_HIP(hipStreamWaitEvent(s_out, ev[2 * nst], 0));
+        FBX_HIP(hipStreamWaitEvent(s_c2, ev[2 * nst], 0));
+        auto h2d = [&](int k) -> int {
+            const int64_t b0 = (int64_t)k * CH, nb = B - b0 < CH ? B - b0 : CH;
+            FBX_HIP(hipMemcpyAsync(de.as<double>() + b0 * m, expect + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
+            FBX_HIP(hipMemcpyAsync(dc.as<double>() + b0 * m, counts + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
+            FBX_HIP(hipEventRecord(ev[2 * k], s_in));
+            return FBX_OK;
+        };
+        if ((rc = h2d(0))) return rc;
+        for (int k = 0; k < nst; ++k) {
+            const int64_t b0 = (int64_t)k * CH, nb = B - b0 < CH ? B - b0 : CH;
+            if (k + 1 < nst && (rc = h2d(k + 1))) break;
+            // even stages on the thread's stream, odd ones on a second compute stream, each with its own half of the
+            // per-item workspace: the tail of stage k (its slowest items) runs next to the head of stage k + 1
+            hipStream_t s_k = (k & 1) ? s_c2 : stream();
+            FBX_HIP(hipStreamWaitEvent(s_k, ev[2 * k], 0));
+            PgdbExtras exk = ex;
+            if (exk.trace) exk.trace += (size_t)b0 * exk.trace_iters * 2;
+            exk.launch_stream = s_k; exk.ws_items = CH; exk.ws_offset = (k & 1) ? CH : 0;
+            rc = pgdb_dispatch(design, nb, de.as<double>() + b0 * m, dc.as<double>() + b0 * m, trace_preserving, mode, max_iters,
+                               dchoi.as<double>() + b0 * 2 * D * D, dit.as<int32_t>() + b0, ddy.as<int32_t>() + b0,
+                               dbt.as<int32_t>() + b0, dcost.as<double>() + b0, dsw.as<int32_t>() + 4 * b0, exk);
+            if (rc) break;
+            FBX_HIP(hipEventRecord(ev[2 * k + 1], s_k));
+            FBX_HIP(hipStreamWaitEvent(s_out, ev[2 * k + 1], 0));
+            FBX_HIP(hipMemcpyAsync(choi_out + b0 * 2 * D * D, dchoi.as<double>() + b0 * 2 * D * D, sizeof(double) * 2 * nb * D * D,
+                                   hipMemcpyDeviceToHost, s_out));
+        }
+        if (rc) { (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(stream()); (void)hipStreamSynchronize(s_c2); (void)hipStreamSynchronize(s_out); return rc; }
+        FBX_HIP(hipEventRecord(ev[2 * nst], s_c2));            // the small outputs below follow BOTH compute streams
+        FBX_HIP(hipStreamWaitEvent(stream(), ev[2 * nst], 0));
+        if (iters_out) FBX_HIP(hipMemcpyAsync(iters_out, dit.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+        if (dykstra_out) FBX_HIP(hipMemcpyAsync(dykstra_out, ddy.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+        if (backtracks_out) FBX_HIP(hipMemcpyAsync(backtracks_out, dbt.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+        if (cost_out) FBX_HIP(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
+        if (work_out) FBX_HIP(hipMemcpyAsync(work_out, dsw.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, stream()));
+        if (trace_bytes) FBX_HIP(hipMemcpyAsync(trace_out, dtr.p, trace_bytes, hipMemcpyDeviceToHost, stream()));
+        FBX_HIP(hipStreamSynchronize(stream()));
+        FBX_HIP(hipStreamSynchronize(s_out));
+        FBX_HIP(hipStreamSynchronize(s_in));
+        return FBX_OK;
+    }
+    FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(dc.p, counts, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
     rc = pgdb_dispatch(design, B, de.as<double>(), dc.as<double>(), trace_preserving, mode, max_iters,
                        dchoi.as<double>(), dit.as<int32_t>(), ddy.as<int32_t>(), dbt.as<int32_t>(),
                        dcost.as<double>(), dsw.as<int32_t>(), ex);

@@ -20,6 +20,8 @@ struct ThreadCtx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
+    hipStream_t copy_in = nullptr, copy_out = nullptr, compute2 = nullptr;   // H2D / D2H / odd stages of the pipelined host-pointer entry points
+    std::vector<hipEvent_t> events;                        // ordering events of that pipeline (no timing)
     struct Block { void* p; size_t bytes; bool busy; };
     std::vector<Block> pool;
     void* ws[WS_COUNT] = {};
@@ -35,6 +37,11 @@ struct ThreadCtx {
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        if (copy_in) { (void)hipStreamDestroy(copy_in); copy_in = nullptr; }
+        if (copy_out) { (void)hipStreamDestroy(copy_out); copy_out = nullptr; }
+        if (compute2) { (void)hipStreamDestroy(compute2); compute2 = nullptr; }
+        for (auto e : events) (void)hipEventDestroy(e);
+        events.clear();
         timing = false;
     }
 };
@@ -86,12 +93,42 @@ hipStream_t stream() { ThreadCtx* c = ctx(); return c ? c->stream : nullptr; }
 int device_epoch() { return g_epoch.load(); }
 int current_device() { return g_device.load(); }
 
+int copy_streams(hipStream_t* in, hipStream_t* out, hipStream_t* compute2) {
+    ThreadCtx* c = ctx();
+    if (!c) { set_error("libfbx: no device context"); return FBX_ERR_HIP; }
+    if (!c->copy_in) FBX_HIP(hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+    if (!c->copy_out) FBX_HIP(hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+    if (!c->compute2) FBX_HIP(hipStreamCreateWithFlags(&c->compute2, hipStreamNonBlocking));
+    *in = c->copy_in; *out = c->copy_out; *compute2 = c->compute2;
+    return FBX_OK;
+}
+
+int ordering_events(int n, hipEvent_t** out) {
+    ThreadCtx* c = ctx();
+    if (!c) { set_error("libfbx: no device context"); return FBX_ERR_HIP; }
+    while ((int)c->events.size() < n) {
+        hipEvent_t e = nullptr;
+        FBX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->events.push_back(e);
+    }
+    *out = c->events.data();
+    return FBX_OK;
+}
+
+bool host_pointer_is_pinned(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable memory
+    return a.type == hipMemoryTypeHost;
+}
+
 int workspace(WorkspaceSlot slot, size_t bytes, void** out) {
     ThreadCtx* c = ctx();
     if (!c) { set_error("libfbx: no device context"); return FBX_ERR_HIP; }
     if (bytes > c->ws_bytes[slot]) {
         if (c->ws[slot]) {
             FBX_HIP(hipStreamSynchronize(c->stream));       // kernels of this thread may still read the old block
+            if (c->compute2) FBX_HIP(hipStreamSynchronize(c->compute2));
             (void)hipFree(c->ws[slot]);
             c->ws[slot] = nullptr; c->ws_bytes[slot] = 0;
         }
@@ -154,7 +191,9 @@ namespace {
 std::atomic<double> g_eig_rel_tol2{FBX_JTOL_REL};     // 1- and 2-qubit PGDB (fbx_pgdb.hip)
 std::atomic<double> g_eig_rel_tol3{FBX3_JTOL_REL};     // 3-qubit PGDB (fbx_pgdb3.hip)
 std::atomic<int> g_eigh_coop{1};                      // large eigendecompositions may use a cooperative launch
+std::atomic<long long> g_host_chunk{8192};            // items per stage of the pipelined host-pointer PGDB entry point
 }
+long long option_pgdb_host_chunk() { return g_host_chunk.load(); }
 double option_pgdb_eig_rel_tol(int n_qubits) { return n_qubits >= 3 ? g_eig_rel_tol3.load() : g_eig_rel_tol2.load(); }
 bool option_eigh_cooperative() { return g_eigh_coop.load() != 0; }
 }  // namespace fbx
@@ -229,6 +268,10 @@ int fbx_set_option(const char* name, double value) {
         return FBX_OK;
     }
     if (n == "eigh_cooperative") { fbx::g_eigh_coop.store(value != 0.0 ? 1 : 0); return FBX_OK; }
+    if (n == "pgdb_host_chunk") {
+        FBX_REQUIRE(value >= 256.0 && value <= 1048576.0, "fbx_set_option: pgdb_host_chunk must be in [256, 1048576]");
+        fbx::g_host_chunk.store((long long)value); return FBX_OK;
+    }
     set_error("fbx_set_option: unknown option '" + n + "'");
     return FBX_ERR_BAD_ARG;
 }
@@ -239,6 +282,7 @@ int fbx_get_option(const char* name, double* value) {
     if (n == "pgdb_eig_rel_tol") { *value = fbx::g_eig_rel_tol2.load(); return FBX_OK; }
     if (n == "pgdb3_eig_rel_tol") { *value = fbx::g_eig_rel_tol3.load(); return FBX_OK; }
     if (n == "eigh_cooperative") { *value = fbx::g_eigh_coop.load(); return FBX_OK; }
+    if (n == "pgdb_host_chunk") { *value = (double)fbx::g_host_chunk.load(); return FBX_OK; }
     set_error("fbx_get_option: unknown option '" + n + "'");
     return FBX_ERR_BAD_ARG;
 }
@@ -262,6 +306,22 @@ int fbx_malloc(void** dev_ptr, size_t bytes) {
 int fbx_free(void* dev_ptr) {
     if (!dev_ptr) return FBX_OK;
     FBX_HIP(hipFree(dev_ptr));
+    return FBX_OK;
+}
+
+// Page-locked host memory: buffers a caller allocates here move at the full PCIe rate and asynchronously, and the
+// host-pointer PGDB entry point pipelines them (include/fbx.h).
+int fbx_host_alloc(void** host_ptr, size_t bytes) {
+    FBX_REQUIRE(host_ptr != nullptr, "fbx_host_alloc: NULL argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    FBX_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return FBX_OK;
+}
+
+int fbx_host_free(void* host_ptr) {
+    if (!host_ptr) return FBX_OK;
+    FBX_HIP(hipHostFree(host_ptr));
     return FBX_OK;
 }
 

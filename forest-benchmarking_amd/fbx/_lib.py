@@ -60,6 +60,8 @@ PROTOTYPES = {
     "fbx_comm_barrier": [],
     "fbx_malloc": [C.POINTER(_vp), C.c_size_t],
     "fbx_free": [_vp],
+    "fbx_host_alloc": [C.POINTER(_vp), C.c_size_t],
+    "fbx_host_free": [_vp],
     "fbx_memcpy_h2d": [_vp, _vp, C.c_size_t],
     "fbx_memcpy_d2h": [_vp, _vp, C.c_size_t],
     "fbx_timer_begin": [],
@@ -272,6 +274,41 @@ def matmul_batch(a, b, conj_t_a=False, conj_t_b=False, scale=None):
     out = np.empty((B, N, N), dtype=np.complex128)
     check(lib().fbx_matmul(N, B, dptr(a.view(np.float64)), int(bool(conj_t_a)), dptr(sc), dptr(b.view(np.float64)),
                            int(bool(conj_t_b)), dptr(out.view(np.float64))))
+    return out
+
+
+class _PinnedBlock:
+    """Owner of one fbx_host_alloc block; freed when the last numpy view of it goes away."""
+
+    def __init__(self, nbytes):
+        p = _vp()
+        check(lib().fbx_host_alloc(C.byref(p), int(nbytes)))
+        self.ptr, self.nbytes = p, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr is not None:
+                lib().fbx_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A numpy array in page-locked host memory (fbx_host_alloc): hand such arrays to the host-pointer entry points and
+    the transfers run at the full PCIe rate, overlapped with the kernels (fbx_pgdb_process pipelines them)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    blk = _PinnedBlock(max(n, 16))
+    buf = (C.c_char * max(n, 16)).from_address(blk.ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    buf._owner = blk
+    return arr
+
+
+def pinned_copy(a):
+    out = pinned_empty(np.shape(a), np.asarray(a).dtype)
+    out[...] = a
     return out
 
 

@@ -276,18 +276,24 @@ def linear_inv_process_estimate(results: List[ExperimentResult], qubits: List[in
 
 def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trace_preserving=True,
                                 mode="converge", max_iters=0, return_stats=False, eig_rel_tol=None,
-                                trace_iters=0):
+                                trace_iters=0, out=None):
     """Batched pgdb_process_estimate.  ``mode='converge'`` is the reference loop (optionally
     capped by ``max_iters``); ``mode='fixed'`` runs exactly ``max_iters`` outer iterations.
     ``eig_rel_tol``: the eigensolver tolerance factor for THIS call (None = the process default,
     0 = the reference's trajectory iteration by iteration; include/fbx.h fbx_pgdb_process_ex).
     ``trace_iters`` > 0 adds ``stats['trace']`` [B, trace_iters, 2]: Dykstra iterations and halvings of
-    every outer iteration."""
+    every outer iteration.  ``out``: a C-contiguous complex128 [B, D, D] array for the result; when it and both inputs
+    are page-locked (``fbx._lib.pinned_empty`` / ``pinned_copy``) the library overlaps transfers and kernels."""
     if mode not in ("converge", "fixed"):
         raise ValueError("mode must be 'converge' or 'fixed'")
     e, c = _batch_arrays(design, expectations, total_counts)
     B, D = e.shape[0], design.dim ** 2
-    choi = np.empty((B, D, D), dtype=np.complex128)
+    if out is None:
+        choi = np.empty((B, D, D), dtype=np.complex128)
+    else:
+        if out.shape != (B, D, D) or out.dtype != np.complex128 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous complex128 array of shape {(B, D, D)}")
+        choi = out
     iters = np.zeros(B, dtype=np.int32)
     dyk = np.zeros(B, dtype=np.int32)
     bt = np.zeros(B, dtype=np.int32)

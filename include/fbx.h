@@ -12,7 +12,8 @@
  *    available per thread through fbx_last_error().  No exceptions / abort() cross the ABI.
  *  - threading: the library is re-entrant.  Every host thread that calls in owns its own HIP
  *    stream, timer events, staging-buffer pool and cached device workspaces (the 2-qubit PGDB
- *    kernel keeps up to 1 GiB of Dykstra bases per calling thread, the 3-qubit one 768 MiB);
+ *    kernel keeps 128 KiB of Dykstra bases per reconstruction of a launch -- 8 GiB for a 65 536-item
+ *    batch, less when the device cannot give that much -- the 3-qubit one 768 MiB);
  *    fbx_release_workspace() gives the calling thread's cached device memory back.  The only
  *    process-wide state is the selected device (one process per GPU: fbx_set_device once,
  *    before other threads use the library) and the RCCL communicator (fbx_comm_*, one thread
@@ -90,6 +91,7 @@ int         fbx_release_workspace(void);            /* free the calling thread's
  *   an inexact projection whose error is that fraction of the distance the estimate still moves per iteration.
  *   0 reproduces the reference's eigh-to-machine-precision trajectory iteration by iteration (tests use it);
  *   the defaults leave the converged estimates within 1e-9 of the reference's.  Range [0, 1e-3].
+ *   "pgdb_host_chunk" (default 4096): items per stage of the pipelined host-pointer form of fbx_pgdb_process (see fbx_host_alloc).
  *   "eigh_cooperative" (default 1): fbx_eigh of a few matrices with N >= 128 spreads each matrix over the whole chip with a
  *   cooperative launch; 0 keeps one workgroup per matrix. */
 int         fbx_set_option(const char* name, double value);
@@ -131,6 +133,12 @@ int fbx_malloc(void** dev_ptr, size_t bytes);
 int fbx_free(void* dev_ptr);
 int fbx_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 int fbx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+
+/* page-locked host memory: caller buffers allocated here cross PCIe at the full rate and asynchronously; when
+ * expect, counts and choi_out of fbx_pgdb_process[_ex] are all page-locked and the batch exceeds one stage
+ * (fbx_set_option "pgdb_host_chunk", default 4096 items), the call pipelines H2D, kernel and D2H on three streams */
+int fbx_host_alloc(void** host_ptr, size_t bytes);
+int fbx_host_free(void* host_ptr);
 
 /* HIP-event timing of everything enqueued on the library stream between begin and end */
 int fbx_timer_begin(void);

@@ -260,3 +260,28 @@ def test_survey_outliers_stay_within_the_reference_own_spread(gpu):
         dev = np.abs(got[0] - want).max()
         assert spread > 5e-10, (basis, item, spread)             # these ARE the rounding-defined items
         assert dev <= 2 * spread, (basis, item, dev, spread)
+
+
+def test_pipelined_host_entry_point_equals_the_staged_one(gpu):
+    """Page-locked caller buffers + more than one stage: H2D / kernel / D2H on three streams.  Same results, bit for bit,
+    as the staged path on pageable arrays (items are independent), counters and per-iteration trace included; a ragged
+    last stage; fbx_host_alloc memory behaves like any numpy array."""
+    from fbx import synthetic, tomography
+    design, _, e, c = synthetic.process_batch(2, "sic", 700)
+    want, wst = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, trace_iters=80)
+    pe, pc = gpu.pinned_copy(e), gpu.pinned_copy(c)
+    out = gpu.pinned_empty((700, 16, 16), np.complex128)
+    assert np.array_equal(pe, e) and pe.flags.c_contiguous and out.dtype == np.complex128
+    old = gpu.get_option("pgdb_host_chunk")
+    try:
+        gpu.set_option("pgdb_host_chunk", 256)                # 3 stages: 256 + 256 + 188
+        got, st = tomography.pgdb_process_estimate_batch(design, pe, pc, return_stats=True, trace_iters=80, out=out)
+    finally:
+        gpu.set_option("pgdb_host_chunk", old)
+    assert got is out and np.array_equal(got, want)
+    for k in ("iterations", "dykstra", "backtracks", "cost", "trace"):
+        assert np.array_equal(st[k], wst[k]), k
+    with pytest.raises(ValueError):
+        tomography.pgdb_process_estimate_batch(design, pe, pc, out=np.empty((700, 16, 16), dtype=np.complex64))
+    with pytest.raises(ValueError):
+        gpu.set_option("pgdb_host_chunk", 3)
