@@ -411,8 +411,16 @@ def calibrate_observable_estimates_from_moments(expt_results, calibrations) -> L
         index.append(keys.index(k))
     means = [calibrations[k][0] for k in keys]
     variances = [calibrations[k][1] for k in keys]
-    e = [np.real(r.expectation) for r in expt_results]
-    se = [np.real(r.std_err) for r in expt_results]
+    def _real(x, what):
+        # The reference keeps complex expectations complex here (observables with complex coefficients).  The device
+        # rescale is real arithmetic: an imaginary part that is not rounding noise is refused, not dropped silently.
+        if abs(np.imag(x)) > 1e-12 * max(1.0, abs(np.real(x))):
+            raise ValueError(f"calibrate_observable_estimates_from_moments: {what} {x!r} has a non-negligible imaginary "
+                             f"part; the calibration rescale works on real expectations")
+        return float(np.real(x))
+    e = [_real(r.expectation, "expectation") for r in expt_results]
+    se = [_real(r.std_err, "std_err") for r in expt_results]
+    means = [_real(x, "calibration expectation") for x in means]
     mean, err = calibrate_expectations_batch(e, se, means, variances, index)
     out = []
     for r, k, m_, s_ in zip(expt_results, [keys[i] for i in index], mean[0], err[0]):

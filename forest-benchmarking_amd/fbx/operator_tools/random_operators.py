@@ -103,36 +103,47 @@ def _qubits_of(dim):
     return n
 
 
+def _stream_seed(seed) -> int:
+    """The Philox key of one batched call.  The device streams are keyed by (seed, item id, element) only, NOT by the
+    kind of operator: two calls with the same seed and item ids draw from the same normals (a Haar unitary is then the Q
+    factor of the Ginibre matrix of the same call signature).  ``seed=None`` therefore takes a fresh 64-bit key from
+    numpy's global stream -- independent calls, like the reference's functions, and reproducible under ``np.random.seed``;
+    pass explicit, DIFFERENT seeds to name streams yourself."""
+    if seed is None:
+        return int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64)) * 2 + int(np.random.randint(0, 2))
+    return _stream_seed(seed)
+
+
 def _device_random(kind, dim, cols_or_rank, batch, seed, first_item, shape):
     from .. import _lib
     out = np.empty((int(batch),) + shape, dtype=np.complex128)
     _lib.check(_lib.lib().fbx_random_operators(kind, int(dim), int(cols_or_rank), int(batch),
-                                               int(seed) & (2 ** 64 - 1), int(first_item),
+                                               _stream_seed(seed), int(first_item),
                                                _lib.dptr(out.view(np.float64))))
     return out
 
 
-def ginibre_matrix_complex_batch(dim: int, k: int, batch: int, seed: int = 0, first_item: int = 0) -> np.ndarray:
+def ginibre_matrix_complex_batch(dim: int, k: int, batch: int, seed: Optional[int] = None, first_item: int = 0) -> np.ndarray:
     """``[batch, dim, k]`` complex Ginibre matrices (random_operators.py:21-46)."""
     from .. import _lib
     return _device_random(_lib.RAND_GINIBRE, dim, k, batch, seed, first_item, (int(dim), int(k)))
 
 
-def haar_rand_unitary_batch(dim: int, batch: int, seed: int = 0, first_item: int = 0) -> np.ndarray:
+def haar_rand_unitary_batch(dim: int, batch: int, seed: Optional[int] = None, first_item: int = 0) -> np.ndarray:
     """``[batch, dim, dim]`` Haar unitaries (random_operators.py:49-72)."""
     from .. import _lib
     _qubits_of(dim)
     return _device_random(_lib.RAND_UNITARY, dim, 0, batch, seed, first_item, (dim, dim))
 
 
-def haar_rand_state_batch(dim: int, batch: int, seed: int = 0, first_item: int = 0) -> np.ndarray:
+def haar_rand_state_batch(dim: int, batch: int, seed: Optional[int] = None, first_item: int = 0) -> np.ndarray:
     """``[batch, dim, 1]`` Haar-random kets (random_operators.py:75-89)."""
     from .. import _lib
     _qubits_of(dim)
     return _device_random(_lib.RAND_STATE_VECTOR, dim, 0, batch, seed, first_item, (dim,))[:, :, None]
 
 
-def ginibre_state_matrix_batch(dim: int, rank: int, batch: int, seed: int = 0, first_item: int = 0) -> np.ndarray:
+def ginibre_state_matrix_batch(dim: int, rank: int, batch: int, seed: Optional[int] = None, first_item: int = 0) -> np.ndarray:
     """``[batch, dim, dim]`` rank-``rank`` states of the Ginibre ensemble (random_operators.py:92-112)."""
     from .. import _lib
     _qubits_of(dim)
@@ -141,24 +152,24 @@ def ginibre_state_matrix_batch(dim: int, rank: int, batch: int, seed: int = 0, f
     return _device_random(_lib.RAND_GINIBRE_STATE, dim, rank, batch, seed, first_item, (dim, dim))
 
 
-def bures_measure_state_matrix_batch(dim: int, batch: int, seed: int = 0, first_item: int = 0) -> np.ndarray:
+def bures_measure_state_matrix_batch(dim: int, batch: int, seed: Optional[int] = None, first_item: int = 0) -> np.ndarray:
     """``[batch, dim, dim]`` states of the Bures measure (random_operators.py:115-132)."""
     from .. import _lib
     _qubits_of(dim)
     return _device_random(_lib.RAND_BURES_STATE, dim, 0, batch, seed, first_item, (dim, dim))
 
 
-def random_kraus_batch(dim: int, kraus_rank: int, batch: int, seed: int = 0, first_item: int = 0) -> np.ndarray:
+def random_kraus_batch(dim: int, kraus_rank: int, batch: int, seed: Optional[int] = None, first_item: int = 0) -> np.ndarray:
     """``[batch, kraus_rank, dim, dim]`` CPTP Kraus sets K_j = G_j S^{-1/2} (BCSZ ensemble in Kraus form)."""
     from .. import _lib
     n = _qubits_of(dim)
     out = np.empty((int(batch), int(kraus_rank), dim, dim), dtype=np.complex128)
-    _lib.check(_lib.lib().fbx_random_kraus(n, int(batch), int(kraus_rank), int(seed) & (2 ** 64 - 1),
+    _lib.check(_lib.lib().fbx_random_kraus(n, int(batch), int(kraus_rank), _stream_seed(seed),
                                            int(first_item), _lib.dptr(out.view(np.float64))))
     return out
 
 
-def rand_map_with_BCSZ_dist_batch(dim: int, kraus_rank: int, batch: int, seed: int = 0, first_item: int = 0) -> np.ndarray:
+def rand_map_with_BCSZ_dist_batch(dim: int, kraus_rank: int, batch: int, seed: Optional[int] = None, first_item: int = 0) -> np.ndarray:
     """``[batch, dim^2, dim^2]`` Choi matrices of random CPTP maps (random_operators.py:135-157): the Kraus
     sets are generated and converted without leaving HBM."""
     from .. import _lib
@@ -166,7 +177,7 @@ def rand_map_with_BCSZ_dist_batch(dim: int, kraus_rank: int, batch: int, seed: i
     B, K, D = int(batch), int(kraus_rank), dim * dim
     lib = _lib.lib()
     d_k, d_c = _lib.DeviceBuffer(max(16, B * K * D * 16)), _lib.DeviceBuffer(max(16, B * D * D * 16))
-    _lib.check(lib.fbx_random_kraus_dev(n, B, K, int(seed) & (2 ** 64 - 1), int(first_item), d_k.ptr))
+    _lib.check(lib.fbx_random_kraus_dev(n, B, K, _stream_seed(seed), int(first_item), d_k.ptr))
     _lib.check(lib.fbx_convert_dev(_lib.REP_KRAUS, _lib.REP_CHOI, n, B, d_k.ptr, K, d_c.ptr))
     _lib.synchronize()
     out = d_c.to_array(np.complex128, (B, D, D))

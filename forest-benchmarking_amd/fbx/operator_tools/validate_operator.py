@@ -2,8 +2,9 @@
 
 The comparisons are ``np.allclose`` predicates exactly as in the reference; the
 positive-(semi)definiteness checks take their eigenvalues from the device eigensolver
-(``fbx_eigh``: any N up to 64, i.e. up to 3-qubit Choi matrices, qutrits included; larger
-matrices raise ``FbxError`` -- not the ``ValueError`` the reference reserves for non-Hermitian input)."""
+(``fbx_eigh``: any N up to 1024 -- qutrits and 3- to 5-qubit Choi matrices included; N <= 64 in LDS, above that
+with the matrix in HBM; larger matrices raise ``FbxError`` -- not the ``ValueError`` the reference reserves for
+non-Hermitian input)."""
 import numpy as np
 
 from .. import _lib
