@@ -36,7 +36,7 @@ struct Lds {
     double* T;       // = Ms..: prediction table [S][64] / gradient accumulator W[64][S]
     double* Rt;      // [4096] Pauli coefficients, TRANSPOSED: Rt[j * 64 + i] = R[i][j]
     // overlay on Rt (alive only while R is dead):
-    cplx* pt; cplx* pts; cplx* ptV; double* lam; double* red;
+    cplx* pt; cplx* pts; cplx* ptV; cplx* ptold; double* lam; double* red;
     PhaseClock* pc;  // diagnostics (-DFBX_PHASE_TIMERS)
     int terms = 0;   // work accounting: eigenvalue terms rebuilt by the CP projections
     double jtol2 = FBX_JACOBI_TOL2;   // eigensolver tolerance of the CP projections (see fbx_pgdb.hip, FBX_JTOL_REL)
@@ -47,6 +47,7 @@ struct Lds {
         pt = (cplx*)q; q += sizeof(cplx) * d * LDs;
         pts = (cplx*)q; q += sizeof(cplx) * d * d;
         ptV = (cplx*)q; q += sizeof(cplx) * d * d;
+        ptold = (cplx*)q; q += sizeof(cplx) * d * LDs;
         lam = (double*)q; q += sizeof(double) * D;
         red = (double*)q;
     }
@@ -172,9 +173,17 @@ __device__ void rotate_into_basis_mfma(Lds& L, int t) {
 }
 #endif
 
+// The 64 x 64 eigensolver as a REAL function call: inlined into the 1024-thread kernels, its per-thread address
+// constants and those of every other phase are hoisted out of the Dykstra loop together and spilled -- with scratch
+// reloads inside the Jacobi round loop.  Behind a call boundary the solver is allocated on its own (80 registers, no
+// scratch, as in eigh_kernel<64, 1024>) and the caller's live values are saved around the call, once per decomposition.
+__device__ __attribute__((noinline)) int jacobi64(cplx* Ms, cplx* Vs, int t, bool init_identity, double* red, double tol2) {
+    return jacobi_eigh_simple<D, NT>(Ms, Vs, t, init_identity, red, tol2);
+}
+
 // ---- CP projection (project_superoperators.py:19-34)
-__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr,
-                       bool check_basis = false) {
+// Hermitised copy of x into Ms (element-major layout); returns ||h||_F^2's per-thread part when asked
+__device__ __forceinline__ double hermitise_into_ms(const Blk& x, Lds& L, int t, bool want_norm) {
     __syncthreads();
     sys_store<D>(L.Ms, t, x);
     __syncthreads();
@@ -185,13 +194,19 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
     __syncthreads();
     sys_store<D>(L.Ms, t, h);
     __syncthreads();
+    return want_norm ? blk_norm2(h) : 0.0;
+}
+__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr,
+                       bool check_basis = false) {
+    // (the Hermitised matrix lives in LDS only: a register copy kept for the rare rejected basis would stay live
+    // across the eigensolver -- 16 of 128 registers; the rejection path rebuilds it from x instead)
+    double n2[2] = {0.0, 0.0};
+    n2[0] = hermitise_into_ms(x, L, t, warm && check_basis);
     PH_STOP(*L.pc, 2);
     if (warm) {
         // a basis loaded from the store is only trusted if the change of basis kept ||.||_F^2 (unitary
         // similarity); otherwise the matrix is restored and the decomposition starts from the identity
         // (same guard as proj_cp_blk, fbx_choi.hpp)
-        double n2[2] = {0.0, 0.0};
-        if (check_basis) n2[0] = blk_norm2(h);
 #ifndef FBX3_ROTATE_VALU
         (void)Tg; rotate_into_basis_mfma(L, t);
 #else
@@ -202,15 +217,13 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
             for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * NT + t]; n2[1] = fma(v.re, v.re, fma(v.im, v.im, n2[1])); }
             bsum_multi<2>(n2, L);
             if (!(fabs(n2[1] - n2[0]) <= FBX_BASIS_NORM_TOL * n2[0])) {
-                __syncthreads();
-                sys_store<D>(L.Ms, t, h);
-                __syncthreads();
+                (void)hermitise_into_ms(x, L, t, false);
                 warm = false;
             }
         }
     }
     PH_STOP(*L.pc, 6);
-    sweeps += jacobi_eigh_simple<D, NT>(L.Ms, L.Vs, t, !warm, L.red, L.jtol2);
+    sweeps += jacobi64(L.Ms, L.Vs, t, !warm, L.red, L.jtol2);
     PH_STOP(*L.pc, 0);
     if (t < D) {
         const double l = L.Ms[sys_index<D>(t, t)].re;
@@ -280,15 +293,41 @@ __device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project
     return subtract_kron_pt(x, L, t);
 }
 
-// ---- Dykstra (project_superoperators.py:87-144)
+// block of kron(C, I_d) for the d x d matrix C staged in LDS (leading dimension LDs)
+__device__ __forceinline__ Blk kron_id_blk(const cplx* C, int t) {
+    Blk r = blk_zero();
+    const int I = t / NB, J = t % NB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+        if ((row % d) == (col % d)) { const cplx c = C[(row / d) * LDs + (col / d)]; r.re[e] = c.re; r.im[e] = c.im; }
+    }
+    return r;
+}
+
+// ---- Dykstra (project_superoperators.py:87-144), carried with TWO matrices per thread.
+// The reference's loop state is (last_state, old_CP_change, old_TP_change, last_CP_projection).  Here:
+//   * old_TP_change = new_state - pre_TP = -kron(corr / d, I_d) with corr the d x d correction the TP / TNI projection
+//     subtracted (proj_tp / proj_tni leave it in L.pt): kept as that 8 x 8 matrix in LDS (L.ptold), rebuilt per entry
+//     where it is used;
+//   * last_CP_projection only enters through <old_CP_change, CP_projection - last_CP_projection>: the second half is
+//     the scalar <new_CP_change, CP_projection> of the previous iteration (one more term of the block reduction);
+//   * last_state = pre_CP + old_CP_change.
+// What stays live in registers across the eigensolver is pre_CP and old_CP_change -- 32 of the 128 registers a
+// thread of a 1024-thread workgroup has, next to the solver's 80 (rounds 1-2 carried four matrices + the caller's
+// estimate, gradient and counts: 1.4 KB of scratch per lane and 235 GB of spill traffic per 256-item launch).
+// Differences to the literal expressions are rounding-level terms of the stopping functional (threshold 1e-4).
 __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, int& sweeps, cplx* Tg,
                              BasisStore* store = nullptr) {
-    Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
-    Blk last_state = x, new_state = x;
+    Blk u = x;                       // pre_CP = last_state - old_CP_change
+    Blk p = blk_zero();              // old_CP_change
+    Blk new_state = x;
+    double c0r = 0.0, c0i = 0.0;     // <old_CP_change, last_CP_projection>
+    __syncthreads();
+    if (t < d * LDs) { cplx z; z.re = 0.0; z.im = 0.0; L.ptold[t] = z; }     // old_TP_change = 0
     int it = 0;
     for (; it < 100000; ++it) {
         ++iters;
-        const Blk pre_cp = blk_sub(last_state, old_cp);
         // consecutive Dykstra iterates are close: start from the previous eigenvectors; when the
         // outer step was small, from the basis the previous call found at the same Dykstra
         // iteration (BasisStore, fbx_choi.hpp) -- the first projection always, it has no other
@@ -303,31 +342,34 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
             __syncthreads();
             warm = true;
         }
-        const Blk cp = proj_cp(pre_cp, L, t, sweeps, warm, Tg, from_slot);
+        const Blk cp = proj_cp(u, L, t, sweeps, warm, Tg, from_slot);
         if (store && it < store->cap && (it == 0 || store->write_all)) {      // write-back policy: BasisStore, fbx_choi.hpp
             fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const cplx v = L.Vs[e * NT + t]; dst[e * NT + t] = fbx_v2d{v.re, v.im}; }
         }
-        // (per-thread parts of the stop test as early as their operands exist: old_cp and last_cp die
-        // before the TP projection instead of staying live -- in scratch -- across it)
-        const Blk new_cp = blk_sub(cp, pre_cp);
-        double s1 = blk_norm2(blk_sub(new_cp, old_cp));
-        double i2r, i2i;
-        blk_dotc(old_cp, blk_sub(cp, last_cp), i2r, i2i);
-        old_cp = new_cp; last_cp = cp;
+        double red8[8];
+        const Blk new_cp = blk_sub(cp, u);
+        red8[0] = blk_norm2(blk_sub(new_cp, p));                           // ||new_CP_change - old_CP_change||^2
+        blk_dotc(p, cp, red8[4], red8[5]);                                 // <old_CP_change, CP_projection>
+        blk_dotc(new_cp, cp, red8[6], red8[7]);                            // next iteration's <old_CP_change, last_CP_projection>
+        const Blk last_state = blk_axpy(u, 1.0, p);
+        // pre_TP = CP_projection - old_TP_change = CP_projection + kron(corr_old / d, I)
+        const Blk old_tp = blk_axpy(blk_zero(), -1.0 / d, kron_id_blk(L.ptold, t));
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = tp ? proj_tp(pre_tp, L, t) : proj_tni(pre_tp, L, t, sweeps);
-        const Blk new_tp = blk_sub(new_state, pre_tp);
-        double s2 = blk_norm2(blk_sub(new_tp, old_tp));
-        double i1r, i1i;
-        blk_dotc(old_tp, blk_sub(new_state, last_state), i1r, i1i);
-        old_tp = new_tp; last_state = new_state;
-        double red6[6] = {s1, s2, i1r, i1i, i2r, i2i};
-        bsum_multi<6>(red6, L);
-        s1 = red6[0]; s2 = red6[1]; i1r = red6[2]; i1i = red6[3]; i2r = red6[4]; i2i = red6[5];
-        const double crit = s1 + s2 + 2.0 * sqrt(i1r * i1r + i1i * i1i) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
+        const Blk new_tp = blk_axpy(blk_zero(), -1.0 / d, kron_id_blk(L.pt, t));
+        red8[1] = blk_norm2(blk_sub(new_tp, old_tp));                      // ||new_TP_change - old_TP_change||^2
+        blk_dotc(old_tp, blk_sub(new_state, last_state), red8[2], red8[3]); // <old_TP_change, state_change>
+        bsum_multi<8>(red8, L);
+        const double i2r = red8[4] - c0r, i2i = red8[5] - c0i;
+        const double crit = red8[0] + red8[1] + 2.0 * sqrt(red8[2] * red8[2] + red8[3] * red8[3]) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
         if (!(crit >= 1e-4)) { ++it; break; }        // converged -- or not finite (NaN input): never spin
+        c0r = red8[6]; c0i = red8[7];
+        p = new_cp;
+        u = blk_sub(new_state, new_cp);
+        if (t < d * LDs) L.ptold[t] = L.pt[t];       // (bsum_multi's barriers separate this from the readers above; the next
+                                                     //  reader is behind the barriers of proj_cp)
     }
     if (store) {
         const int written = store->write_all ? it : 1;
@@ -425,13 +467,28 @@ __device__ void gradient_coefficients(const DesignDev& des, Lds& L, const double
 }
 }  // namespace p3
 
+// Per-workgroup slab in HBM / L2 for what must survive the projection but is not touched by it -- the estimate, the
+// gradient's Pauli coefficients, the model probabilities of the estimate and the normalised counts: written once and
+// read once (counts: twice) per OUTER iteration with coalesced 8 / 16-byte accesses, instead of living in registers the
+// compiler then spills around every one of the ~10 eigendecompositions of the projection.
+template <int MAXJ>
+struct Park3 {
+    static constexpr size_t doubles() { return 2 * (size_t)p3::D * p3::D + (size_t)p3::D * p3::D + 4 * (size_t)MAXJ * p3::NT; }
+    double* base;
+    __device__ cplx* est() const { return (cplx*)base; }                              // [4][1024] blocks, element-major
+    __device__ double* rg() const { return base + 2 * p3::D * p3::D; }                // [4096] gradient coefficients (Rt layout)
+    __device__ double* pp() const { return rg() + p3::D * p3::D; }                    // [2 MAXJ][1024] probabilities of the estimate
+    __device__ double* nn() const { return pp() + 2 * MAXJ * p3::NT; }                // [2 MAXJ][1024] normalised counts
+};
+
 template <int MAXJ>
 __global__ void __launch_bounds__(1024)
 pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
              int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out,
              int* __restrict__ iters_out, int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
              double* __restrict__ cost_out, cplx* __restrict__ scratch, long long* __restrict__ phase_out, int* __restrict__ sweeps_out,
-             cplx* __restrict__ basis_scratch, int basis_cap, int* __restrict__ trace_out, int trace_iters) {
+             cplx* __restrict__ basis_scratch, int basis_cap, int* __restrict__ trace_out, int trace_iters,
+             double* __restrict__ park_base) {
     using namespace p3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds L; L.carve(smem);
@@ -440,55 +497,41 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
     const long long item = blockIdx.x;
     const int m = des.m, S = des.S;
     const bool unit_coefs = des.unit_coefs != 0;
+    Park3<MAXJ> park; park.base = park_base + (size_t)blockIdx.x * Park3<MAXJ>::doubles();
 
-    double npl[MAXJ], nmi[MAXJ];
-    uint32_t spw[MAXJ];
-    double tot = 0.0;
+    // ---- data: n+-[k] = counts * (1 +- e)/2 / grand_total   (tomography.py:528-538), parked
+    {
+        double npl[MAXJ], nmi[MAXJ];
+        double tot = 0.0;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int g = t * MAXJ + j;
-        npl[j] = 0.0; nmi[j] = 0.0; spw[j] = 0u;
-        if (g < m) {
-            const int k = des.order[g];
-            const double e = expect[item * m + k], c = counts[item * m + k];
-            const double plus = (1.0 + e) / 2.0;
-            npl[j] = c * plus; nmi[j] = c * (1.0 - plus);
-            tot += c;
-            spw[j] = des.sp[g];
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = t * MAXJ + j;
+            npl[j] = 0.0; nmi[j] = 0.0;
+            if (g < m) {
+                const int k = des.order[g];
+                const double e = expect[item * m + k], c = counts[item * m + k];
+                const double plus = (1.0 + e) / 2.0;
+                npl[j] = c * plus; nmi[j] = c * (1.0 - plus);
+                tot += c;
+            }
         }
-    }
-    tot = bsum(tot, L);
+        tot = bsum(tot, L);
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) { npl[j] /= tot; nmi[j] /= tot; }
+        for (int j = 0; j < MAXJ; ++j) { park.nn()[(2 * j) * NT + t] = npl[j] / tot; park.nn()[(2 * j + 1) * NT + t] = nmi[j] / tot; }
+    }
     const double half_dd = 0.5 / (double)(d * d), inv_mu = (2.0 * d * d) / 3.0;
 
-    double pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
-    auto load_probs = [&](double (&pp)[MAXJ], double (&pm)[MAXJ]) {
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = t * MAXJ + j;
-            if (g < m) {
-                const int s = spw[j] >> 16, p = spw[j] & 0xffff;
-                const double cf = unit_coefs ? 1.0 : des.coef[g];
-                const double tr = L.T[s * D], ex = cf * L.T[s * D + p];
-                pp[j] = (tr + ex) * half_dd; pm[j] = (tr - ex) * half_dd;
-            }
+    // model probabilities of this thread's outcomes from the prediction table in LDS
+    auto probs_of = [&](int j, double& pp, double& pm, double missing) __attribute__((always_inline)) {
+        const int g = t * MAXJ + j;
+        pp = missing; pm = missing;
+        if (g < m) {
+            const uint32_t w = des.sp[g];
+            const int s = w >> 16, p = w & 0xffff;
+            const double cf = unit_coefs ? 1.0 : des.coef[g];
+            const double tr = L.T[s * D], ex = cf * L.T[s * D + p];
+            pp = (tr + ex) * half_dd; pm = (tr - ex) * half_dd;
         }
-    };
-    auto cost_at = [&](double alpha) -> double {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = t * MAXJ + j;
-            if (g < m) {
-                double pp = fma(alpha, pup[j], pep[j]), pm = fma(alpha, pum[j], pem[j]);
-                pp = pp < EPS ? EPS : pp; pm = pm < EPS ? EPS : pm;
-                acc -= npl[j] * fast_log_pos(pp) + nmi[j] * fast_log_pos(pm);
-            }
-        }
-        return bsum(acc, L);
     };
 
     Blk est = blk_zero();
@@ -508,20 +551,34 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         choi_to_pauli(est, L, t);
         PH_STOP(pc, 3);
         predict_table(des, L, t);
-        load_probs(pep, pem);
         PH_STOP(pc, 7);
-        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; ++cost_evals; }
-        PH_STOP(pc, 5);
 
-        // ---- gradient (tomography.py:617-633): W[i][s] = sum over the settings of state s.
+        // ---- probabilities of the estimate (parked for the line search), initial cost, and the gradient
+        // (tomography.py:617-633): W[i][s] = sum over the settings of state s.
         // Threads own CONTIGUOUS runs of the state-grouped settings, so the identity row W[0][s]
         // (one term per setting of the state) is reduced deterministically: a run that lies inside
         // one thread is written directly, the first / last run of every thread goes to a partial
         // array that one thread per state adds up in thread order.  The W[p][s] cells receive one
         // term each (LDS atomics only matter for designs that repeat a setting).
+        double ep[MAXJ], em[MAXJ];                     // eta = n / clip(p) of this thread's outcomes
+        {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                double pp, pm;
+                probs_of(j, pp, pm, 1.0);
+                park.pp()[(2 * j) * NT + t] = pp; park.pp()[(2 * j + 1) * NT + t] = pm;
+                pp = pp < EPS ? EPS : pp; pm = pm < EPS ? EPS : pm;
+                const double np_ = park.nn()[(2 * j) * NT + t], nm_ = park.nn()[(2 * j + 1) * NT + t];
+                if (!have_cost && t * MAXJ + j < m) acc -= np_ * fast_log_pos(pp) + nm_ * fast_log_pos(pm);
+                ep[j] = np_ / pp; em[j] = nm_ / pm;
+            }
+            if (!have_cost) { old_cost = bsum(acc, L); have_cost = true; ++cost_evals; }   // tomography.py:565
+        }
+        PH_STOP(pc, 5);
         __syncthreads();                              // T fully consumed
         double* W = L.T;
-        double* pfirst = L.Rt + 512;                  // overlays R (dead here), past the small scratch
+        double* pfirst = L.Rt + 768;                  // overlays R (dead here), past the small scratch
         double* plast = pfirst + NT;
         int* sfirst = (int*)(plast + NT);
         int* slast = sfirst + NT;
@@ -534,11 +591,10 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
             for (int j = 0; j < MAXJ; ++j) {
                 const int g = t * MAXJ + j;
                 if (g < m) {
-                    const int s = spw[j] >> 16, p = spw[j] & 0xffff;
+                    const uint32_t w = des.sp[g];
+                    const int s = w >> 16, p = w & 0xffff;
                     const double cf = unit_coefs ? 1.0 : des.coef[g];
-                    const double pp = pep[j] < EPS ? EPS : pep[j], pm = pem[j] < EPS ? EPS : pem[j];
-                    const double ep = npl[j] / pp, em = nmi[j] / pm;
-                    atomicAdd(&W[p * S + s], cf * 0.5 * (ep - em));
+                    atomicAdd(&W[p * S + s], cf * 0.5 * (ep[j] - em[j]));
                     if (s != run_state) {
                         if (run_state >= 0) {                      // flush the finished run
                             if (!first_done) { pfirst[t] = run; sfirst[t] = run_state; first_done = true; }
@@ -547,7 +603,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
                         run_state = s; run = 0.0;
                         if (first_state < 0) first_state = s;
                     }
-                    run += 0.5 * (ep + em);
+                    run += 0.5 * (ep[j] + em[j]);
                 }
             }
             if (run_state >= 0) {
@@ -569,11 +625,19 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         }
         __syncthreads();
         gradient_coefficients(des, L, W, t);
+        // the gradient is needed once more after the projection, for <update, gradient>: as its Pauli coefficients
+        // (the transform is unitary up to the factor d: <E1, E2> = sum_ij R1_ij R2_ij), parked
+        for (int idx = t; idx < D * D; idx += NT) park.rg()[idx] = L.Rt[idx];
         PH_STOP(pc, 4);
-        const Blk grad = pauli_to_choi(L, t);
+        Blk x;
+        {
+            const Blk grad = pauli_to_choi(L, t);
+            x = blk_axpy(est, -inv_mu, grad);
+        }
         PH_STOP(pc, 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cplx v; v.re = est.re[e]; v.im = est.im[e]; park.est()[e * NT + t] = v; }
 
-        const Blk x = blk_axpy(est, -inv_mu, grad);
         // bounds the accumulated loss of unitarity of the chained bases: a cold restart once the chains have
         // absorbed 54 sweeps per slot (what 16 converging iterations apply; see fbx_pgdb.hip)
         if (iters == 0 || sweeps - chain_start >= FBX3_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) { basis.nprev = 0; chain_start = sweeps; }
@@ -583,26 +647,49 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch,
                                        basis.g ? &basis : nullptr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const cplx v = park.est()[e * NT + t]; est.re[e] = v.re; est.im[e] = v.im; }
         const Blk upd = blk_sub(proj, est);
         PH_STOP(pc, 2);
 
         choi_to_pauli(upd, L, t);
         PH_STOP(pc, 3);
+        double ipr = 0.0;                             // <update, gradient> = sum_ij R^upd_ij R^grad_ij
+        for (int idx = t; idx < D * D; idx += NT) ipr = fma(L.Rt[idx], park.rg()[idx], ipr);
         predict_table(des, L, t);
-        load_probs(pup, pum);
+        ipr = bsum(ipr, L);                           // (after the table product: the reduction scratch overlays Rt)
         PH_STOP(pc, 7);
 
-        double ipr, ipi;
-        blk_dotc(upd, grad, ipr, ipi);
-        ipr = bsum(ipr, L);
+        // ---- backtracking line search (tomography.py:575-585)
         double alpha = 1.0;
-        new_cost = cost_at(alpha); ++cost_evals;
-        double change = GAMMA * alpha * ipr;
-        while (new_cost > old_cost + change) {
-            alpha *= 0.5; change *= 0.5;
+        {
+            double npl[MAXJ], nmi[MAXJ], pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                probs_of(j, pup[j], pum[j], 0.0);
+                pep[j] = park.pp()[(2 * j) * NT + t]; pem[j] = park.pp()[(2 * j + 1) * NT + t];
+                npl[j] = park.nn()[(2 * j) * NT + t]; nmi[j] = park.nn()[(2 * j + 1) * NT + t];
+            }
+            auto cost_at = [&](double a) -> double {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {
+                    if (t * MAXJ + j < m) {
+                        double pp = fma(a, pup[j], pep[j]), pm = fma(a, pum[j], pem[j]);
+                        pp = pp < EPS ? EPS : pp; pm = pm < EPS ? EPS : pm;
+                        acc -= npl[j] * fast_log_pos(pp) + nmi[j] * fast_log_pos(pm);
+                    }
+                }
+                return bsum(acc, L);
+            };
             new_cost = cost_at(alpha); ++cost_evals;
-            ++backtracks;
-            if (alpha < ALPHA_MIN) break;
+            double change = GAMMA * alpha * ipr;
+            while (new_cost > old_cost + change) {
+                alpha *= 0.5; change *= 0.5;
+                new_cost = cost_at(alpha); ++cost_evals;
+                ++backtracks;
+                if (alpha < ALPHA_MIN) break;
+            }
         }
         est = blk_axpy(est, alpha, upd);
         outer_step = alpha * sqrt(bsum(blk_norm2(upd), L));
@@ -662,9 +749,12 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     constexpr int BASIS_CAP = FBX_BASIS_CAP3;   // Dykstra iterations per projection with a stored basis (64 KiB each)
     // (a grow-only workspace of the calling thread, released by fbx_release_workspace)
     void* w = nullptr;
-    { const int rc = workspace(WS_PGDB3_BASIS, sizeof(cplx) * p3::D * p3::D * (size_t)(B < CHUNK ? B : CHUNK) * BASIS_CAP, &w); if (rc) return rc; }
+    const size_t in_flight = (size_t)(B < CHUNK ? B : CHUNK);
+    const size_t basis_bytes = sizeof(cplx) * p3::D * p3::D * in_flight * BASIS_CAP;
+    { const int rc = workspace(WS_PGDB3_BASIS, basis_bytes + sizeof(double) * Park3<MAXJ>::doubles() * in_flight, &w); if (rc) return rc; }
     cplx* scratch = (cplx*)w;
     cplx* basis = scratch;                   // (`scratch` itself only tells the kernel that warm starts are on)
+    double* park = (double*)((char*)w + basis_bytes);
     const size_t m = des->dev.m, DD = (size_t)p3::D * p3::D;
     DesignDev dev = des->dev;
     dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(3);
@@ -674,7 +764,7 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
                            dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch,
                            FBX_PHASE_OUT3(b0), sw ? sw + 4 * b0 : nullptr, basis, BASIS_CAP,
-                           ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr, ex.trace_iters);
+                           ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr, ex.trace_iters, park);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;

@@ -111,7 +111,7 @@ def _stream_seed(seed) -> int:
     pass explicit, DIFFERENT seeds to name streams yourself."""
     if seed is None:
         return int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64)) * 2 + int(np.random.randint(0, 2))
-    return _stream_seed(seed)
+    return int(seed) & (2 ** 64 - 1)
 
 
 def _device_random(kind, dim, cols_or_rank, batch, seed, first_item, shape):
