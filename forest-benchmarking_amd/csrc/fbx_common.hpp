@@ -149,6 +149,22 @@ struct __attribute__((aligned(16))) cplx { double re, im; };
 #define FBX_WAVE_SYNC() asm volatile("" ::: "memory")
 #endif
 
+// Workgroup barrier of the multi-wave kernels.  __syncthreads() is a release / acquire fence on ALL memory plus
+// s_barrier: it waits for every outstanding global load and store of the wave (s_waitcnt vmcnt(0)) at every barrier.
+// A translation unit whose threads never communicate through global memory inside a kernel (fbx_pgdb3.hip: the
+// basis store and the parked state are private per thread) defines FBX_LDS_ONLY_BARRIERS before including the
+// headers: the barrier then orders LDS only, and write-backs / prefetches stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#ifdef FBX_LDS_ONLY_BARRIERS
+#define FBX_BLOCK_SYNC() fbx::lds_barrier()
+#else
+#define FBX_BLOCK_SYNC() __syncthreads()
+#endif
+
 // Wavefront reductions on the VALU: four DPP butterfly steps inside each row of 16 lanes (quad
 // swaps, half-row and row mirrors -- no LDS crossbar round trips as with ds_bpermute), then the four
 // row results through v_readlane.  Every lane gets the same value (already wave-uniform); the
@@ -204,9 +220,9 @@ template <int NT>
 __device__ __forceinline__ double block_sum(double v, double* red) {
     v = wave_sum(v);
     if constexpr (NT > 64) {
-        __syncthreads();                       // earlier readers of `red` are done
+        FBX_BLOCK_SYNC();                       // earlier readers of `red` are done
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
+        FBX_BLOCK_SYNC();
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) s += red[w];
@@ -220,9 +236,9 @@ template <int NT>
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
     a = wave_sum(a); b = wave_sum(b);
     if constexpr (NT > 64) {
-        __syncthreads();
+        FBX_BLOCK_SYNC();
         if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[NT / 64 + (threadIdx.x >> 6)] = b; }
-        __syncthreads();
+        FBX_BLOCK_SYNC();
         double sa = 0.0, sb = 0.0;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) { sa += red[w]; sb += red[NT / 64 + w]; }

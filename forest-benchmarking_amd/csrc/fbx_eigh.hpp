@@ -422,7 +422,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             Vs[e * PS + ((e & 1) ? me1 : me0)] = v;
         }
     }
-    if constexpr (NT > 64) __syncthreads(); else FBX_WAVE_SYNC();
+    if constexpr (NT > 64) FBX_BLOCK_SYNC(); else FBX_WAVE_SYNC();
     int sweep = 0;
     for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
         {
@@ -453,7 +453,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             // everything read before anyone overwrites it.  A single wavefront needs no barrier and no
             // wait here or after the writes: its LDS instructions execute in program order, so the
             // reads above see the previous round and the next round's reads see the writes below.
-            if constexpr (NT > 64) __syncthreads();
+            if constexpr (NT > 64) FBX_BLOCK_SYNC();
             const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
 #ifdef FBX_JACOBI_TWO_CHAINS
             const JRot rI = jacobi_rotation(aI, dI_, bI.re, bI.im);
@@ -475,7 +475,7 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
                 Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;
                 Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
             }
-            if constexpr (NT > 64) __syncthreads();
+            if constexpr (NT > 64) FBX_BLOCK_SYNC();
         }
         if constexpr (NT <= 64) FBX_WAVE_SYNC();
     }

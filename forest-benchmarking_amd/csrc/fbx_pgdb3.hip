@@ -10,6 +10,9 @@
 // The Bloch matrix C (D x S doubles, 108 KiB for the Pauli in-basis) is read from L2.
 //
 // Reference: tomography.py:542-633, operator_tools/project_superoperators.py:19-144.
+// no thread of these kernels reads global memory another thread of the same launch wrote (basis store and parked state
+// are per thread, tables go through LDS): barriers order LDS only and leave global traffic in flight (fbx_common.hpp)
+#define FBX_LDS_ONLY_BARRIERS
 #include "fbx_choi.hpp"
 #include <cstdlib>
 
@@ -60,12 +63,12 @@ template <int K>
 __device__ __forceinline__ void bsum_multi(double (&v)[K], Lds& L) {
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
-    __syncthreads();                                   // earlier readers of `red` are done
+    FBX_BLOCK_SYNC();                                   // earlier readers of `red` are done
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) L.red[k * (NT / 64) + (threadIdx.x >> 6)] = v[k];
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double s = 0.0;
@@ -97,10 +100,10 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
         }
     }
     // T = Ms V replaces Ms in place: H is dead once every thread has its block of the product
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 #pragma unroll
     for (int e = 0; e < 4; ++e) L.Ms[sys_index<D>(2 * I + (e >> 1), 2 * J + (e & 1))] = acc[e];
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[e].re = 0.0; acc[e].im = 0.0; }
     for (int kb = 0; kb < NB; ++kb) {
@@ -114,11 +117,11 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
             acc[3].re += u1.re * w1.re + u1.im * w1.im; acc[3].im += u1.re * w1.im - u1.im * w1.re;
         }
     }
-    __syncthreads();                                   // every thread is done reading Ms
+    FBX_BLOCK_SYNC();                                   // every thread is done reading Ms
     if (I == J) { acc[0].im = 0.0; acc[3].im = 0.0; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) L.Ms[sys_index<D>(2 * I + (e >> 1), 2 * J + (e & 1))] = acc[e];
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 }
 
 // The same change of basis on the fp64 matrix cores: wavefront w owns the 16 x 16 output tile (w >> 2, w & 3) of
@@ -144,13 +147,13 @@ __device__ void rotate_into_basis_mfma(Lds& L, int t) {
         tre = __builtin_amdgcn_mfma_f64_16x16x4f64(h.im, v.im, tre, 0, 0, 0);      // -(-im) im
         tim = __builtin_amdgcn_mfma_f64_16x16x4f64(-h.im, v.re, tim, 0, 0, 0);
     }
-    __syncthreads();                                    // H is dead: T takes its place
+    FBX_BLOCK_SYNC();                                    // H is dead: T takes its place
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         cplx o; o.re = tre[r]; o.im = tim[r];
         L.Ms[sys_index<D>(16 * tm + g + 4 * r, colB)] = o;
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     v4d mre = {0.0, 0.0, 0.0, 0.0}, mim = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
     for (int ks = 0; ks < 16; ++ks) {                   // M' = V^H T
@@ -162,14 +165,14 @@ __device__ void rotate_into_basis_mfma(Lds& L, int t) {
         mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v.im, q.im, mre, 0, 0, 0);
         mim = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.im, q.re, mim, 0, 0, 0);
     }
-    __syncthreads();                                    // every wavefront is done reading T
+    FBX_BLOCK_SYNC();                                    // every wavefront is done reading T
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * tm + g + 4 * r;
         cplx o; o.re = mre[r]; o.im = row == colB ? 0.0 : mim[r];
         L.Ms[sys_index<D>(row, colB)] = o;
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 }
 #endif
 
@@ -184,16 +187,16 @@ __device__ __attribute__((noinline)) int jacobi64(cplx* Ms, cplx* Vs, int t, boo
 // ---- CP projection (project_superoperators.py:19-34)
 // Hermitised copy of x into Ms (element-major layout); returns ||h||_F^2's per-thread part when asked
 __device__ __forceinline__ double hermitise_into_ms(const Blk& x, Lds& L, int t, bool want_norm) {
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     sys_store<D>(L.Ms, t, x);
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     const Blk xa = sys_load_adjoint<D>(L.Ms, t);
     Blk h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (x.re[e] + xa.re[e]); h.im[e] = 0.5 * (x.im[e] + xa.im[e]); }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     sys_store<D>(L.Ms, t, h);
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     return want_norm ? blk_norm2(h) : 0.0;
 }
 __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr,
@@ -229,7 +232,7 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
         const double l = L.Ms[sys_index<D>(t, t)].re;
         L.lam[t] = l < 0.0 ? 0.0 : l;
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     {   // work accounting: eigenvalue terms the reconstruction walks (same count in every thread)
         int cnt = 0;
         for (int k = 0; k < D; ++k) cnt += L.lam[k] != 0.0;
@@ -245,9 +248,9 @@ __device__ void partial_trace_out(const Blk& x, Lds& L, int t) {
     // staged row-major through Ms (dead between the reconstruction and the next projection), NOT
     // through Mw = Vs: the eigenvectors in Vs must survive for the warm start of the next projection
     cplx* St = L.Ms;
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     blk_store<D, LD>(St, t, x);
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     if (t < d * d) {
         const int i = t / d, ip = t % d;
         cplx s; s.re = 0.0; s.im = 0.0;
@@ -255,7 +258,7 @@ __device__ void partial_trace_out(const Blk& x, Lds& L, int t) {
         for (int o = 0; o < d; ++o) { const cplx v = St[(i * d + o) * LD + ip * d + o]; s.re += v.re; s.im += v.im; }
         L.pt[i * LDs + ip] = s;
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 }
 __device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const Lds& L, int t) {
     Blk r = x;
@@ -270,7 +273,7 @@ __device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const Lds& L, int 
 __device__ Blk proj_tp(const Blk& x, Lds& L, int t) {                 // project_superoperators.py:62-84
     partial_trace_out(x, L, t);
     if (t < d) L.pt[t * LDs + t].re -= 1.0;
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     return subtract_kron_pt(x, L, t);
 }
 __device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project_superoperators.py:37-59
@@ -280,19 +283,35 @@ __device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project
     Blk h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (ptb.re[e] + pta.re[e]); h.im[e] = 0.5 * (ptb.im[e] + pta.im[e]); }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     sys_store<d>(L.pts, t, h);
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     sweeps += jacobi_eigh_simple<d, NT>(L.pts, L.ptV, t, true, L.red);
     if (t < d) { const double l = L.pts[sys_index<d>(t, t)].re; L.lam[t] = l > 1.0 ? 1.0 : l; }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     const Blk proj = reconstruct_blk<d>(L.ptV, L.lam, t);
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     blk_store<d, LDs>(L.pt, t, blk_sub(ptb, proj));
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     return subtract_kron_pt(x, L, t);
 }
 
+// -DFBX3_DYK_DETAIL (diagnostics, with FBX_PHASE_TIMERS): the phases of a Dykstra iteration take over the timer slots of
+// the outer phases -- 3 basis load, 7 basis write-back, 4 TP / TNI projection, 5 stopping functional (2 then = Hermitise only)
+#ifdef FBX3_DYK_DETAIL
+#define PH3(ph) PH_STOP(*L.pc, ph)
+#else
+#define PH3(ph)
+#endif
+// one stored basis (64 KiB, the layout of Vs) from HBM / L2 into LDS without passing through registers: every lane moves
+// four 16-byte entries; the LDS address of a global_load_lds is wave-uniform base + lane * 16
+__device__ __forceinline__ void basis_fetch(const cplx* g, cplx* Vs, int t) {
+    typedef __attribute__((address_space(1))) const void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        __builtin_amdgcn_global_load_lds((gptr)(g + e * NT + t), (lptr)(Vs + e * NT + (t & ~63)), 16, 0, 0);
+}
 // block of kron(C, I_d) for the d x d matrix C staged in LDS (leading dimension LDs)
 __device__ __forceinline__ Blk kron_id_blk(const cplx* C, int t) {
     Blk r = blk_zero();
@@ -323,7 +342,8 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
     Blk p = blk_zero();              // old_CP_change
     Blk new_state = x;
     double c0r = 0.0, c0i = 0.0;     // <old_CP_change, last_CP_projection>
-    __syncthreads();
+    bool pf_pending = false;         // the next iteration's stored basis is on its way from HBM / L2 into Vs
+    FBX_BLOCK_SYNC();
     if (t < d * LDs) { cplx z; z.re = 0.0; z.im = 0.0; L.ptold[t] = z; }     // old_TP_change = 0
     int it = 0;
     for (; it < 100000; ++it) {
@@ -335,19 +355,20 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         bool from_slot = false;
         if (store && Tg && it < store->nprev && (it == 0 || store->use_prev)) {
             from_slot = true;
-            __syncthreads();
-            const fbx_global_cplx_ptr src = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const fbx_v2d w = src[e * NT + t]; cplx v; v.re = w.x; v.im = w.y; L.Vs[e * NT + t] = v; }
-            __syncthreads();
+            if (!pf_pending) { FBX_BLOCK_SYNC(); basis_fetch(store->g + (size_t)it * D * D, L.Vs, t); }
+            __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0): this wave's share of the basis has landed in LDS
+            FBX_BLOCK_SYNC();
+            pf_pending = false;
             warm = true;
         }
+        PH3(3);
         const Blk cp = proj_cp(u, L, t, sweeps, warm, Tg, from_slot);
         if (store && it < store->cap && (it == 0 || store->write_all)) {      // write-back policy: BasisStore, fbx_choi.hpp
             fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const cplx v = L.Vs[e * NT + t]; dst[e * NT + t] = fbx_v2d{v.re, v.im}; }
         }
+        PH3(7);
         double red8[8];
         const Blk new_cp = blk_sub(cp, u);
         red8[0] = blk_norm2(blk_sub(new_cp, p));                           // ||new_CP_change - old_CP_change||^2
@@ -358,10 +379,12 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         const Blk old_tp = blk_axpy(blk_zero(), -1.0 / d, kron_id_blk(L.ptold, t));
         const Blk pre_tp = blk_sub(cp, old_tp);
         new_state = tp ? proj_tp(pre_tp, L, t) : proj_tni(pre_tp, L, t, sweeps);
+        PH3(4);
         const Blk new_tp = blk_axpy(blk_zero(), -1.0 / d, kron_id_blk(L.pt, t));
         red8[1] = blk_norm2(blk_sub(new_tp, old_tp));                      // ||new_TP_change - old_TP_change||^2
         blk_dotc(old_tp, blk_sub(new_state, last_state), red8[2], red8[3]); // <old_TP_change, state_change>
         bsum_multi<8>(red8, L);
+        PH3(5);
         const double i2r = red8[4] - c0r, i2i = red8[5] - c0i;
         const double crit = red8[0] + red8[1] + 2.0 * sqrt(red8[2] * red8[2] + red8[3] * red8[3]) + 2.0 * sqrt(i2r * i2r + i2i * i2i);
         if (!(crit >= 1e-4)) { ++it; break; }        // converged -- or not finite (NaN input): never spin
@@ -370,6 +393,10 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         u = blk_sub(new_state, new_cp);
         if (t < d * LDs) L.ptold[t] = L.pt[t];       // (bsum_multi's barriers separate this from the readers above; the next
                                                      //  reader is behind the barriers of proj_cp)
+        // The eigenvectors in Vs are dead when the next decomposition starts from a stored basis (reconstruction and
+        // write-back have read them, behind the barriers above): that basis is requested NOW, straight into LDS
+        // (global_load_lds_dwordx4), and arrives while the next iteration Hermitises its matrix.
+        if (store && Tg && it + 1 < store->nprev && store->use_prev) { basis_fetch(store->g + (size_t)(it + 1) * D * D, L.Vs, t); pf_pending = true; }
     }
     if (store) {
         const int written = store->write_all ? it : 1;
@@ -380,24 +407,24 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
 
 // ---- Choi (in registers) -> transposed Pauli coefficients Rt (uses Mw = Vs as staging)
 __device__ void choi_to_pauli(const Blk& x, Lds& L, int t) {
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     blk_store<D, LD>(L.Mw, t, x);
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 #pragma unroll
-    for (int s = NQ - 1; s >= 0; --s) { pauli_site_stage<NQ, false, LD>(L.Mw, t, 2 * NQ + NQ + s, NQ + s, -1.0); __syncthreads(); }
+    for (int s = NQ - 1; s >= 0; --s) { pauli_site_stage<NQ, false, LD>(L.Mw, t, 2 * NQ + NQ + s, NQ + s, -1.0); FBX_BLOCK_SYNC(); }
 #pragma unroll
-    for (int s = NQ - 1; s >= 0; --s) { pauli_site_stage<NQ, false, LD>(L.Mw, t, 2 * NQ + s, s, +1.0); __syncthreads(); }
+    for (int s = NQ - 1; s >= 0; --s) { pauli_site_stage<NQ, false, LD>(L.Mw, t, 2 * NQ + s, s, +1.0); FBX_BLOCK_SYNC(); }
     for (int idx = t; idx < D * D; idx += NT) {
         const int i = idx % D, j = idx / D;           // idx = j * 64 + i: coalesced Rt writes
         int row, col;
         pauli_coeff_position<NQ>(i, j, row, col);
         L.Rt[idx] = L.Mw[row * LD + col].re / d;
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 }
 // ---- transposed Pauli coefficients Rt -> Choi block (Mw = Vs as scratch)
 __device__ Blk pauli_to_choi(Lds& L, int t) {
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     for (int idx = t; idx < D * D; idx += NT) {
         const int i = idx % D, j = idx / D;
         int row, col;
@@ -405,13 +432,13 @@ __device__ Blk pauli_to_choi(Lds& L, int t) {
         cplx v; v.re = L.Rt[idx] * d; v.im = 0.0;
         L.Mw[row * LD + col] = v;
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) { pauli_site_stage<NQ, true, LD>(L.Mw, t, 2 * NQ + s, s, +1.0); __syncthreads(); }
+    for (int s = 0; s < NQ; ++s) { pauli_site_stage<NQ, true, LD>(L.Mw, t, 2 * NQ + s, s, +1.0); FBX_BLOCK_SYNC(); }
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) { pauli_site_stage<NQ, true, LD>(L.Mw, t, 2 * NQ + NQ + s, NQ + s, -1.0); __syncthreads(); }
+    for (int s = 0; s < NQ; ++s) { pauli_site_stage<NQ, true, LD>(L.Mw, t, 2 * NQ + NQ + s, NQ + s, -1.0); FBX_BLOCK_SYNC(); }
     const Blk out = blk_load<D, LD>(L.Mw, t);
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     return out;
 }
 // ---- T[s][i] = sum_j R[i][j] C[j][s]: the dense basis-change GEMM of the 3-qubit path
@@ -424,7 +451,7 @@ __device__ void predict_table(const DesignDev& des, Lds& L, int t) {
     const int S = des.S;
     const int lane = t & 63, wave = t >> 6;
     const int mtiles = (S + 15) / 16;
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     for (int tile = wave; tile < mtiles * 4; tile += NT / 64) {
         const int ms = tile / 4, ni = tile % 4;
         const int srow = ms * 16 + (lane & 15);
@@ -442,7 +469,7 @@ __device__ void predict_table(const DesignDev& des, Lds& L, int t) {
             if (srw < S) L.T[srw * D + ni * 16 + (lane & 15)] = acc[r];
         }
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 }
 // ---- Rt[j][i] = -(1/d^2) sum_s W[i][s] C[j][s]  ([64 x 64] = W [64 x S] . C^T [S x 64]), one
 // 16 x 16 output tile per wave; W from LDS, C from L2.  S is padded with zero terms to a multiple of 4.
@@ -457,13 +484,13 @@ __device__ void gradient_coefficients(const DesignDev& des, Lds& L, const double
         const double b = k < S ? des.C[(nj * 16 + (lane & 15)) * S + k] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
-    __syncthreads();                                   // Rt overlays the partial arrays read above
+    FBX_BLOCK_SYNC();                                   // Rt overlays the partial arrays read above
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = mi * 16 + (lane >> 4) + 4 * r, j = nj * 16 + (lane & 15);
         L.Rt[j * D + i] = -acc[r] / (double)(d * d);
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
 }
 }  // namespace p3
 
@@ -576,7 +603,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
             if (!have_cost) { old_cost = bsum(acc, L); have_cost = true; ++cost_evals; }   // tomography.py:565
         }
         PH_STOP(pc, 5);
-        __syncthreads();                              // T fully consumed
+        FBX_BLOCK_SYNC();                              // T fully consumed
         double* W = L.T;
         double* pfirst = L.Rt + 768;                  // overlays R (dead here), past the small scratch
         double* plast = pfirst + NT;
@@ -584,7 +611,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         int* slast = sfirst + NT;
         for (int idx = t; idx < D * S; idx += NT) W[idx] = 0.0;
         sfirst[t] = -1; slast[t] = -1; pfirst[t] = 0.0; plast[t] = 0.0;
-        __syncthreads();
+        FBX_BLOCK_SYNC();
         {
             int run_state = -1, first_state = -1; double run = 0.0; bool first_done = false;
 #pragma unroll
@@ -611,7 +638,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
                 else { plast[t] = run; slast[t] = run_state; }
             }
         }
-        __syncthreads();
+        FBX_BLOCK_SYNC();
         for (int s = t; s < S; s += NT) {
             const int g0 = des.sptr[s], g1 = des.sptr[s + 1];
             if (g1 > g0) {
@@ -623,7 +650,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
                 W[s] += acc;
             }
         }
-        __syncthreads();
+        FBX_BLOCK_SYNC();
         gradient_coefficients(des, L, W, t);
         // the gradient is needed once more after the projection, for <update, gradient>: as its Pauli coefficients
         // (the transform is unitary up to the factor d: <E1, E2> = sum_ij R1_ij R2_ij), parked
@@ -817,7 +844,7 @@ linv_process3_kernel(DesignDev des, long long B, const double* __restrict__ expe
             acc += expect[item * des.m + des.porder[g]] * des.pinvT[(size_t)g * D + j];
         L.Rt[idx] = acc + ((idx == 0) ? 1.0 : 0.0);
     }
-    __syncthreads();
+    FBX_BLOCK_SYNC();
     const Blk c = pauli_to_choi(L, t);
     const int I = t / NB, J = t % NB;
 #pragma unroll

@@ -9,8 +9,7 @@ basis = sys.argv[1] if len(sys.argv) > 1 else 'sic'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 mode = sys.argv[3] if len(sys.argv) > 3 else 'fixed'
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 100
-design, us, e, c = synthetic.process_batch(3, basis, 32)
-e = np.tile(e, (B // 32, 1)); c = np.tile(c, (B // 32, 1))
+design, us, e, c = synthetic.process_batch(3, basis, B)
 _lib.set_device(0)
 lib = _lib.lib()
 buf = _lib.DeviceBuffer(B * 8 * 8)
