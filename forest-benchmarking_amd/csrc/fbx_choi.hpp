@@ -11,6 +11,10 @@
 #pragma once
 #include "fbx_eigh.hpp"
 
+#ifndef FBX_COMPACT_DYKSTRA
+#define FBX_COMPACT_DYKSTRA 0   // 1: Dykstra carried with two matrices per lane in EVERY 1- / 2-qubit kernel, not only in the two-waves-per-SIMD
+                               // ones (measured: the one-wave kernel, which has the registers, is 3.5 % slower with it at B = 1024)
+#endif
 #ifndef FBX_WARM_START
 #define FBX_WARM_START 1     // reuse the previous eigenvectors inside one Dykstra run (reset per run)
 #endif
@@ -35,12 +39,13 @@ struct ChoiLds {
     cplx* pt;      // [d * LDs]  partial trace (d x d), row-major
     cplx* pts;     // [d * d]    partial trace in the Jacobi layout (TNI only)
     cplx* ptV;     // [d * d]    its eigenvectors (TNI only)
+    cplx* ptold;   // [d * LDs]  the previous Dykstra iteration's TP / TNI correction (old_TP_change as a d x d matrix)
     PhaseClock* pc = nullptr;   // diagnostics (FBX_PHASE_TIMERS builds)
     int terms = 0;              // work accounting: eigenvalue terms rebuilt by the CP projections (wave-uniform)
     double jtol2 = FBX_JACOBI_TOL2;   // off-norm^2 / norm^2 at which the CP projections' eigensolver stops
     static constexpr size_t bytes() {
         static_assert(!LEAN || 2 * sys_elems<D>() >= D * LD, "the transforms' staging matrix must fit into Ms + Vs");
-        return sizeof(cplx) * ((LEAN ? 0 : D * LD) + 2 * sys_elems<D>() + d * LDs + 2 * d * d) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
+        return sizeof(cplx) * ((LEAN ? 0 : D * LD) + 2 * sys_elems<D>() + d * LDs + 2 * d * d + d * LDs) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
     }
     __device__ void carve(char*& p) {
         if constexpr (!LEAN) { Mw = (cplx*)p; p += sizeof(cplx) * D * LD; }
@@ -50,6 +55,7 @@ struct ChoiLds {
         pt = (cplx*)p; p += sizeof(cplx) * d * LDs;
         pts = (cplx*)p; p += sizeof(cplx) * d * d;
         ptV = (cplx*)p; p += sizeof(cplx) * d * d;
+        ptold = (cplx*)p; p += sizeof(cplx) * d * LDs;
         rec = (JRec*)p; p += sizeof(JRec) * (D / 2 + 1);
         lam = (double*)p; p += sizeof(double) * D;
     }
@@ -243,10 +249,110 @@ struct BasisStore {
     }
 };
 
+// block of -kron(C / d, I_d) for the d x d matrix C staged in LDS: what a TP / TNI projection adds to its argument
+template <class LdsT>
+__device__ __forceinline__ Blk tp_change_blk(const cplx* C, int lane) {
+    constexpr int d = LdsT::d, D = LdsT::D, LDs = LdsT::LDs, NB = D / 2;
+    Blk r = blk_zero();
+    if (lane < NB * NB) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+            if ((row % d) == (col % d)) { const cplx c = C[(row / d) * LDs + (col / d)]; r.re[e] = -(c.re / d); r.im[e] = -(c.im / d); }
+        }
+    }
+    return r;
+}
+
+// Dykstra carried with TWO matrices per lane (the two-waves-per-SIMD kernels, 256 registers): pre_CP and old_CP_change
+// stay in registers across the eigensolver; old_TP_change = -kron(corr / d, I_d) is kept as the d x d correction the TP /
+// TNI projection subtracted (L.pt -> L.ptold), last_CP_projection only enters as the scalar <old_CP_change,
+// last_CP_projection>, last_state = pre_CP + old_CP_change (see fbx_pgdb3.hip, where the same form removed the spills of
+// the 3-qubit kernel's projection).  Same projections, same stopping rule; the stopping functional differs from the
+// four-matrix form in rounding-level terms only (threshold 1e-4).
+template <int NQ, class LdsT>
+__device__ Blk proj_physical_blk_compact(const Blk& x, bool trace_preserving, LdsT& L, int lane,
+                                         int& iters, int& sweeps, int max_iter, BasisStore* store) {
+    constexpr int DD = LdsT::D * LdsT::D, d = LdsT::d, LDs = LdsT::LDs;
+    Blk u = x, p = blk_zero(), new_state = x;
+    double c0r = 0.0, c0i = 0.0;
+    const bool have_store = store != nullptr && store->g != nullptr;
+    constexpr int PF = (DD + 63) / 64;
+    static_assert(PF <= 4, "BasisStore::pf holds one basis of at most 256 entries");
+    FBX_WAVE_SYNC();
+    if (lane < d * LDs) { cplx z; z.re = 0.0; z.im = 0.0; L.ptold[lane] = z; }
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        ++iters;
+        bool warm = FBX_WARM_START && it > 0;
+        bool from_slot = false;
+        const int sweeps_before = sweeps;
+        if (FBX_WARM_START && have_store && it < store->nprev && (it == 0 || store->use_prev)) {
+            from_slot = true;
+            FBX_WAVE_SYNC();
+            if (store->pf_slot != it) store->template prefetch<DD>(it, lane);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int idx = lane + 64 * q;
+                if (idx < DD) L.Vs[sys_linear<LdsT::D>(idx)] = store->pf[q];
+            }
+            store->pf_slot = -1;
+            warm = true;
+        }
+        if (FBX_WARM_START && have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
+            store->template prefetch<DD>(it + 1, lane);
+        const Blk cp = proj_cp_blk<NQ>(u, L, lane, sweeps, warm, from_slot);
+        if (FBX_WARM_START && have_store && it < store->cap && (it == 0 || store->write_all)) {
+            if (!(from_slot && sweeps == sweeps_before)) {
+                fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * DD);
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const int idx = lane + 64 * q;
+                    if (idx < DD) { const cplx w = L.Vs[sys_linear<LdsT::D>(idx)]; dst[idx] = fbx_v2d{w.re, w.im}; }
+                }
+            }
+        }
+        const Blk new_cp = blk_sub(cp, u);
+        double s1 = blk_norm2(blk_sub(new_cp, p));
+        double pcr, pci, ncr, nci;
+        blk_dotc(p, cp, pcr, pci);
+        blk_dotc(new_cp, cp, ncr, nci);
+        const Blk last_state = blk_axpy(u, 1.0, p);
+        const Blk old_tp = tp_change_blk<LdsT>(L.ptold, lane);
+        const Blk pre_tp = blk_sub(cp, old_tp);
+        new_state = trace_preserving ? proj_tp_blk<NQ>(pre_tp, L, lane) : proj_tni_blk<NQ>(pre_tp, L, lane, sweeps);
+        const Blk new_tp = tp_change_blk<LdsT>(L.pt, lane);
+        double s2 = blk_norm2(blk_sub(new_tp, old_tp));
+        double i1r, i1i;
+        blk_dotc(old_tp, blk_sub(new_state, last_state), i1r, i1i);
+        s1 = wave_sum(s1); s2 = wave_sum(s2); i1r = wave_sum(i1r); i1i = wave_sum(i1i);
+        pcr = wave_sum(pcr); pci = wave_sum(pci); ncr = wave_sum(ncr); nci = wave_sum(nci);
+        const double i2r = pcr - c0r, i2i = pci - c0i;
+        const double a1 = i1r * i1r + i1i * i1i, a2 = i2r * i2r + i2i * i2i;
+        const double m1 = a1 > 1e-300 ? a1 * fast_rsqrt(a1) : 0.0, m2 = a2 > 1e-300 ? a2 * fast_rsqrt(a2) : 0.0;
+        const double crit = uniform(s1 + s2 + 2.0 * m1 + 2.0 * m2);
+        if (!(crit >= 1e-4)) { ++it; break; }
+        c0r = ncr; c0i = nci;
+        p = new_cp;
+        u = blk_sub(new_state, new_cp);
+        FBX_WAVE_SYNC();
+        if (lane < d * LDs) L.ptold[lane] = L.pt[lane];
+        FBX_WAVE_SYNC();
+    }
+    if (have_store) {
+        const int written = store->write_all ? it : 1;
+        store->nprev = written < store->cap ? written : store->cap;
+        store->pf_slot = -1;
+    }
+    return new_state;
+}
+
 template <int NQ, class LdsT>
 __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, int lane,
                                  int& iters, int& sweeps, int max_iter = 100000,
                                  BasisStore* store = nullptr) {
+    if constexpr (LdsT::lean || FBX_COMPACT_DYKSTRA) return proj_physical_blk_compact<NQ>(x, trace_preserving, L, lane, iters, sweeps, max_iter, store);
     constexpr int DD = LdsT::D * LdsT::D;
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;

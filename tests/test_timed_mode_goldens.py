@@ -66,16 +66,25 @@ def _fid(choi, u):
     return om.process_fidelity(so.kraus2pauli_liouville(u), so.choi2pauli_liouville(choi))
 
 
-def _run(n, basis, tol, mode, items=None):
+def _run(n, basis, tol, mode, items=None, tile_to=0):
+    """tile_to: repeat the fixture items up to that batch size (>= 2048 selects the two-waves-per-SIMD kernel for two
+    qubits); the first copy is returned."""
     from fbx import tomography
     from fbx.design import process_design
     g = _load(n, basis)
     design = process_design(n, basis)
     sl = slice(None) if items is None else slice(0, items)
     e, c = g["expectations"][sl], g["counts"][sl]
+    nb = e.shape[0]
+    if tile_to > nb:
+        reps = -(-tile_to // nb)
+        e, c = np.tile(e, (reps, 1)), np.tile(c, (reps, 1))
     got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode=mode, max_iters=100 if mode == "fixed" else 0,
                                                      return_stats=True, eig_rel_tol=tol,
                                                      trace_iters=max(100, int(g["conv_iter"].max())))
+    if tile_to > nb:
+        assert np.array_equal(got[:nb], got[-nb:])
+        got, st = got[:nb], {k: v[:nb] for k, v in st.items()}
     return g, got, st
 
 
@@ -95,10 +104,11 @@ def _check_traces(g, st, nb, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tile_to", [0, 2048], ids=["one-wave-kernel", "two-waves-per-simd-kernel"])
 @pytest.mark.parametrize("tol", [None, 0.0])
 @pytest.mark.parametrize("basis,nb", [("pauli", 64), ("sic", 16)])
-def test_two_qubit_fixed_100_against_the_reference(gpu, basis, nb, tol):
-    g, got, st = _run(2, basis, tol, "fixed")
+def test_two_qubit_fixed_100_against_the_reference(gpu, basis, nb, tol, tile_to):
+    g, got, st = _run(2, basis, tol, "fixed", tile_to=tile_to)
     assert got.shape[0] == nb
     _check_traces(g, st, nb, "fixed")
     dev = np.abs(got - g["pgdb_fixed"]).reshape(nb, -1).max(axis=1)
@@ -113,10 +123,13 @@ def test_two_qubit_fixed_100_against_the_reference(gpu, basis, nb, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tile_to", [0, 2048], ids=["one-wave-kernel", "two-waves-per-simd-kernel"])
 @pytest.mark.parametrize("tol", [None, 0.0])
 @pytest.mark.parametrize("n,basis,nb", [(2, "pauli", 64), (2, "sic", 16), (3, "sic", 16)])
-def test_converge_mode_against_the_reference_snapshots(gpu, n, basis, nb, tol):
-    g, got, st = _run(n, basis, tol, "converge")
+def test_converge_mode_against_the_reference_snapshots(gpu, n, basis, nb, tol, tile_to):
+    if n == 3 and tile_to:
+        pytest.skip("one kernel for three qubits")
+    g, got, st = _run(n, basis, tol, "converge", tile_to=tile_to)
     _check_traces(g, st, nb, "converge")
     dev = np.abs(got - g["pgdb_conv"]).reshape(nb, -1).max(axis=1)
     assert (dev <= 1e-9).mean() >= 0.9 and dev.max() <= 1e-8, sorted(dev)[-5:]
