@@ -23,6 +23,7 @@ int device_epoch();      // increases whenever fbx_set_device selects a differen
 int current_device();    // device selected for the process, -1 before the first use
 double option_pgdb_eig_rel_tol(int n_qubits);   // fbx_set_option("pgdb_eig_rel_tol" / "pgdb3_eig_rel_tol")
 bool option_eigh_cooperative();                 // fbx_set_option("eigh_cooperative")
+int option_pgdb_packed_1q();                     // fbx_set_option("pgdb_packed_1q"): single-qubit PGDB on the lane-per-item kernel: 0 never, 1 large batches (default), 2 always
 // Defaults of those options: the eigensolver of PGDB's CP projections stops at an off-diagonal norm of
 // <this> x the previous outer step (relative to ||H||_F), never tighter than 1e-13; 0 = always 1e-13.
 // Surveys against the oracle: 2 qubits, 704 items -- identical deviation histogram at 1e-8
@@ -53,7 +54,7 @@ struct PgdbExtras {
 // Named grow-only device workspaces of the calling thread (kept between calls; released by
 // fbx_release_workspace).  A workspace only ever serves kernels on the calling thread's stream, so
 // growing it (stream sync + hipFree + hipMalloc) cannot pull memory from under another thread's kernel.
-enum WorkspaceSlot { WS_PGDB_BASIS = 0, WS_PGDB3_BASIS = 1, WS_SWEEP_REF = 2, WS_COMM = 3, WS_CONVERT = 4, WS_COUNT = 5 };
+enum WorkspaceSlot { WS_PGDB_BASIS = 0, WS_PGDB3_BASIS = 1, WS_SWEEP_REF = 2, WS_COMM = 3, WS_CONVERT = 4, WS_PGDB1_COUNTER = 5, WS_COUNT = 6 };
 int workspace(WorkspaceSlot slot, size_t bytes, void** out);
 // staging blocks of the host-pointer entry points: taken from / returned to the calling thread's pool
 int pool_take(size_t bytes, void** out);

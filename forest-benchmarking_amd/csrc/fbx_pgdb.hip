@@ -22,6 +22,9 @@
 #ifndef FBX_LEAN_MIN_BATCH
 #define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
 #endif
+#ifndef FBX_PACKED_1Q_MIN_BATCH
+#define FBX_PACKED_1Q_MIN_BATCH 8192  // single-qubit batches from which the lane-per-item kernel is used (fbx_pgdb1.hip)
+#endif
 #ifndef FBX_BASIS_CHAIN_SWEEPS
 #define FBX_BASIS_CHAIN_SWEEPS 216  // Jacobi sweeps a chain of stored bases may accumulate (per slot, on average) before a cold restart
 #endif
@@ -747,12 +750,25 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
 int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
                    int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost,
                    int32_t* sw, const PgdbExtras& ex);   // fbx_pgdb3.hip
+bool pgdb1_eligible(const fbx_design* des);               // fbx_pgdb1.hip: the lane-per-item single-qubit kernel
+int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode,
+                   int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost,
+                   int32_t* sw, const PgdbExtras& ex);
 
 static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                          int mode, int max_iters, double* choi, int32_t* it, int32_t* dy,
                          int32_t* bt, double* cost, int32_t* sw, const PgdbExtras& ex) {
     const int n = des->dev.n, m = des->dev.m;
     if (n == 1) {
+        // Large batches: 64 reconstructions per wavefront, one per lane (fbx_pgdb1.hip; the eigensolver at its full tolerance --
+        // eig_rel_tol does not apply).  A lane is ~3x slower on one reconstruction than a wavefront, so the wave-per-item kernel
+        // below keeps the batches that do not fill the lanes of the chip (measured crossover between 4096 and 16 384 items,
+        // scripts/pgdb1_time.py); fbx_set_option("pgdb_packed_1q", 0 | 2) forces one or the other.
+        {
+            const int packed = option_pgdb_packed_1q();
+            if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && B >= FBX_PACKED_1Q_MIN_BATCH)))
+                return pgdb1_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+        }
         if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         if (m <= 256) return launch_pgdb<1, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     } else if (n == 2) {

@@ -196,6 +196,8 @@ std::atomic<long long> g_host_chunk{8192};            // items per stage of the 
 long long option_pgdb_host_chunk() { return g_host_chunk.load(); }
 double option_pgdb_eig_rel_tol(int n_qubits) { return n_qubits >= 3 ? g_eig_rel_tol3.load() : g_eig_rel_tol2.load(); }
 bool option_eigh_cooperative() { return g_eigh_coop.load() != 0; }
+std::atomic<int> g_packed_1q{1};                      // single-qubit PGDB: 64 reconstructions per wavefront (fbx_pgdb1.hip)
+int option_pgdb_packed_1q() { return g_packed_1q.load(); }
 }  // namespace fbx
 
 extern "C" {
@@ -268,6 +270,10 @@ int fbx_set_option(const char* name, double value) {
         return FBX_OK;
     }
     if (n == "eigh_cooperative") { fbx::g_eigh_coop.store(value != 0.0 ? 1 : 0); return FBX_OK; }
+    if (n == "pgdb_packed_1q") {
+        FBX_REQUIRE(value == 0.0 || value == 1.0 || value == 2.0, "fbx_set_option: pgdb_packed_1q must be 0 (never), 1 (large batches) or 2 (always)");
+        fbx::g_packed_1q.store((int)value); return FBX_OK;
+    }
     if (n == "pgdb_host_chunk") {
         FBX_REQUIRE(value >= 256.0 && value <= 1048576.0, "fbx_set_option: pgdb_host_chunk must be in [256, 1048576]");
         fbx::g_host_chunk.store((long long)value); return FBX_OK;
@@ -282,6 +288,7 @@ int fbx_get_option(const char* name, double* value) {
     if (n == "pgdb_eig_rel_tol") { *value = fbx::g_eig_rel_tol2.load(); return FBX_OK; }
     if (n == "pgdb3_eig_rel_tol") { *value = fbx::g_eig_rel_tol3.load(); return FBX_OK; }
     if (n == "eigh_cooperative") { *value = fbx::g_eigh_coop.load(); return FBX_OK; }
+    if (n == "pgdb_packed_1q") { *value = fbx::g_packed_1q.load(); return FBX_OK; }
     if (n == "pgdb_host_chunk") { *value = (double)fbx::g_host_chunk.load(); return FBX_OK; }
     set_error("fbx_get_option: unknown option '" + n + "'");
     return FBX_ERR_BAD_ARG;

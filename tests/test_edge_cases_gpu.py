@@ -142,14 +142,16 @@ def test_state_estimators_on_ragged_designs(gpu):
 
 
 def test_batches_beyond_one_launch_chunk(gpu):
-    """More than 8192 items go through several launches that share the basis-store workspace."""
-    from fbx import synthetic, tomography
+    """More than 8192 items go through several launches that share the basis-store workspace (the wavefront-per-item
+    kernel: single-qubit batches of this size would otherwise take the lane-per-item kernel, tests/test_pgdb1_gpu.py)."""
+    from fbx import synthetic, tomography, _lib
     design, us, e, c = synthetic.process_batch(1, "sic", 7)
     B = 8192 + 300
     reps = -(-B // 7)
     eb, cb = np.tile(e, (reps, 1))[:B], np.tile(c, (reps, 1))[:B]
-    got, st = tomography.pgdb_process_estimate_batch(design, eb, cb, return_stats=True)
-    ref, rst = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True)
+    with _lib.option("pgdb_packed_1q", 0.0):
+        got, st = tomography.pgdb_process_estimate_batch(design, eb, cb, return_stats=True)
+        ref, rst = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True)
     idx = np.arange(B) % 7
     assert np.array_equal(got, ref[idx])
     assert np.array_equal(st["iterations"], rst["iterations"][idx]) and np.array_equal(st["dykstra"], rst["dykstra"][idx])

@@ -1,0 +1,156 @@
+"""The packed single-qubit PGDB kernel (csrc/fbx_pgdb1.hip: one reconstruction per LANE, 64 per wavefront) through the C
+ABI, against the reference-generated goldens, the oracle, and the wavefront-per-reconstruction kernel it replaces for
+single-qubit designs (reference: tomography.py:542-594; what tests/test_process_tomography.py:72-112 runs)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _oracle(design, e, c, **kw):
+    from fbx_oracle import design as od, estimators as oe
+    d = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)
+    A = oe.design_matrix_A(d)
+    outs, stats = [], []
+    for b in range(e.shape[0]):
+        est, st = oe.pgdb_process_estimate(d, e[b], c[b], A=A, return_stats=True, **kw)
+        outs.append(est); stats.append(st)
+    return np.array(outs), stats
+
+
+def _packed(on):
+    """2 = the lane-per-item kernel whatever the batch size (the default, 1, uses it from 8192 experiments on), 0 = never"""
+    from fbx import _lib
+    return _lib.option("pgdb_packed_1q", 2.0 if on else 0.0)
+
+
+@pytest.fixture(autouse=True)
+def _force_packed(gpu):
+    with _packed(True):
+        yield
+
+
+@pytest.mark.parametrize("basis", ["pauli", "sic"])
+def test_goldens_from_the_reference(gpu, basis):
+    from fbx import tomography, design as fd, _lib
+    z = np.load(os.path.join(GOLD, f"process_1q_{basis}.npz"))
+    design = fd.process_design(1, basis)
+    assert np.array_equal(design.in_labels, z["in_labels"]) and np.array_equal(design.paulis, z["paulis"])
+    assert _lib.get_option("pgdb_packed_1q") == 2.0            # the lane-per-item kernel (forced: 6 items)
+    got, st = tomography.pgdb_process_estimate_batch(design, z["expectations"], z["counts"], return_stats=True)
+    assert np.abs(got - z["pgdb"]).max() < 1e-9
+    want, wst = _oracle(design, z["expectations"], z["counts"])
+    for b in range(got.shape[0]):
+        assert (st["iterations"][b], st["dykstra"][b]) == (wst[b]["iterations"], wst[b]["dykstra"])
+        assert abs(st["cost"][b] - wst[b]["cost"]) < 1e-10
+    n_tni = z["pgdb_tni"].shape[0]
+    got = tomography.pgdb_process_estimate_batch(design, z["expectations"][:n_tni], z["counts"][:n_tni], trace_preserving=False)
+    assert np.abs(got - z["pgdb_tni"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("basis", ["pauli", "sic"])
+def test_oracle_parity_with_equal_counts(gpu, basis):
+    from fbx import synthetic, tomography
+    B = 48
+    design, _, e, c = synthetic.process_batch(1, basis, B)
+    got, st = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, trace_iters=8)
+    want, wst = _oracle(design, e, c)
+    dev = np.abs(got - want).reshape(B, -1).max(axis=1)
+    assert dev.max() < 1e-8 and np.mean(dev < 1e-9) >= 0.9
+    for b in range(B):
+        assert (st["iterations"][b], st["dykstra"][b]) == (wst[b]["iterations"], wst[b]["dykstra"])
+        # halvings: small steps are tested on the exact cost difference; only a final stalled iteration may differ
+        assert abs(int(st["backtracks"][b]) - wst[b]["backtracks"]) <= 50
+        k = min(8, st["iterations"][b])
+        assert st["trace"][b, :k, 0].sum() <= st["dykstra"][b] and np.all(st["trace"][b, :k, 0] >= 1)
+        assert np.all(st["trace"][b, st["iterations"][b]:] == 0)
+
+
+def test_fixed_mode_trajectory_and_counts(gpu):
+    from fbx import synthetic, tomography
+    design, _, e, c = synthetic.process_batch(1, "pauli", 12)
+    got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=6, return_stats=True, trace_iters=6)
+    want, wst = _oracle(design, e, c, mode="fixed", max_iters=6)
+    assert np.abs(got - want).max() < 1e-11
+    for b in range(12):
+        assert (st["iterations"][b], st["dykstra"][b], st["backtracks"][b]) == (6, wst[b]["dykstra"], wst[b]["backtracks"])
+        assert st["trace"][b, :, 0].sum() == st["dykstra"][b] and st["trace"][b, :, 1].sum() == st["backtracks"][b]
+
+
+@pytest.mark.parametrize("basis,tp", [("pauli", True), ("sic", True), ("pauli", False)])
+def test_agrees_with_the_wave_per_item_kernel(gpu, basis, tp):
+    from fbx import synthetic, tomography
+    B = 300
+    design, _, e, c = synthetic.process_batch(1, basis, B)
+    a, sa = tomography.pgdb_process_estimate_batch(design, e, c, trace_preserving=tp, return_stats=True)
+    with _packed(False):
+        b, sb = tomography.pgdb_process_estimate_batch(design, e, c, trace_preserving=tp, return_stats=True, eig_rel_tol=0.0)
+    assert np.array_equal(sa["iterations"], sb["iterations"]) and np.array_equal(sa["dykstra"], sb["dykstra"])
+    dev = np.abs(a - b).reshape(B, -1).max(axis=1)
+    assert dev.max() < 1e-8 and np.mean(dev < 1e-9) >= 0.95
+
+
+def test_default_dispatch_takes_the_packed_kernel_for_large_batches(gpu):
+    from fbx import synthetic, tomography, _lib
+    design, _, e, c = synthetic.process_batch(1, "sic", 256)
+    E, C = np.tile(e, (32, 1)), np.tile(c, (32, 1))                  # 8192 experiments
+    with _lib.option("pgdb_packed_1q", 1.0):
+        big, sb = tomography.pgdb_process_estimate_batch(design, E, C, return_stats=True)
+        small, ss = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, eig_rel_tol=0.0)
+    forced, sf = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True)
+    assert np.array_equal(big[:256], forced)                         # packed kernel: bit-identical whatever the batch
+    assert not np.array_equal(small, forced) and np.abs(small - forced).max() < 1e-8     # the wave-per-item kernel took the small one
+    assert np.array_equal(ss["iterations"], sf["iterations"]) and np.array_equal(ss["dykstra"], sf["dykstra"])
+
+
+def test_persistent_lanes_large_batch_is_batch_size_independent(gpu):
+    """More items than lanes in flight: finished lanes take the next item from the counter.  Every item's result must be
+    what the same item gives in a small batch (all arithmetic is per lane)."""
+    from fbx import synthetic, tomography
+    design, _, e, c = synthetic.process_batch(1, "sic", 512)
+    ref, sr = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True)
+    reps = 400                                     # 204 800 items: > 1024 wavefronts x 64 lanes
+    E, C = np.tile(e, (reps, 1)), np.tile(c, (reps, 1))
+    got, sg = tomography.pgdb_process_estimate_batch(design, E, C, return_stats=True)
+    assert np.array_equal(got.reshape(reps, 512, 4, 4), np.broadcast_to(ref, (reps, 512, 4, 4)))
+    assert np.array_equal(sg["iterations"].reshape(reps, 512), np.broadcast_to(sr["iterations"], (reps, 512)))
+    assert np.array_equal(sg["dykstra"].reshape(reps, 512), np.broadcast_to(sr["dykstra"], (reps, 512)))
+
+
+def test_edge_cases(gpu):
+    from fbx import synthetic, tomography
+    design, _, e, c = synthetic.process_batch(1, "pauli", 70)
+    one = tomography.pgdb_process_estimate_batch(design, e[:1], c[:1])
+    full = tomography.pgdb_process_estimate_batch(design, e, c)
+    assert np.array_equal(one[0], full[0])
+    assert tomography.pgdb_process_estimate_batch(design, e[:0], c[:0]).shape == (0, 4, 4)
+    # zero iterations: the starting point I / d
+    z = tomography.pgdb_process_estimate_batch(design, e[:3], c[:3], mode="fixed", max_iters=0)
+    assert np.array_equal(z, np.broadcast_to(np.eye(4) / 2, (3, 4, 4)))
+    # a poisoned item ends (non-finite) and its neighbours are untouched
+    e2 = e.copy(); e2[5, 3] = np.nan
+    bad, st = tomography.pgdb_process_estimate_batch(design, e2, c, return_stats=True)
+    assert not np.all(np.isfinite(bad[5]))
+    keep = np.arange(70) != 5
+    assert np.array_equal(bad[keep], full[keep])
+    # physicality of the estimates the reference returns (un-projected last iterate: CP and TP to the Dykstra tolerance)
+    ev = np.linalg.eigvalsh(full)
+    assert ev.min() > -1e-2
+    pt = np.einsum('biojo->bij', full.reshape(70, 2, 2, 2, 2))
+    assert np.abs(pt - np.eye(2)).max() < 1e-2
+
+
+def test_reference_signature_single_experiment(gpu):
+    """pgdb_process_estimate(results, qubits) -- one experiment, the call of the reference's tests."""
+    from fbx import tomography, design as fd
+    from fbx.observable_estimation import ExperimentResult
+    z = np.load(os.path.join(GOLD, "process_1q_pauli.npz"))
+    design = fd.process_design(1, "pauli")
+    settings = tomography.generate_process_tomography_settings([0], "pauli")
+    results = [ExperimentResult(setting=s, expectation=float(z["expectations"][0, k]), total_counts=int(z["counts"][0, k]),
+                                std_err=0.0) for k, s in enumerate(settings)]
+    got = tomography.pgdb_process_estimate(results, [0])
+    assert np.abs(got - z["pgdb"][0]).max() < 1e-9
