@@ -63,9 +63,9 @@ def parse():
                     help="input-state basis of the process design (default: pauli for pgdb, sic for pgdb3)")
     ap.add_argument("--cpu-sample", type=int, default=6,
                     help="items run through the oracle for cpu_baseline and the parity self-check (0 = skip)")
-    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "pgdb3"],
+    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "pgdb3", "pgdb1"],
                     help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "
-                         "sweep / pgdb3 = that workload as the primary line")
+                         "sweep / pgdb3 / pgdb1 = that workload as the primary line")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
     ap.add_argument("--anchor-items", type=int, default=65536,
                     help="N = 1, workload all: also time this many items (BASELINE configs[4]'s whole batch) on the one "
@@ -386,18 +386,77 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
                        "iters": args.iters, "parallelism": f"shard{comm.world}",
                        "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean()),
                        "max_over_mean_jacobi_sweeps": float(work[:, 0].max() / work[:, 0].mean())},
-            "roofline": {"bound": "mfma", "pipe": "fp64 VALU + LDS", "achieved": tflops, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch"),
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU + LDS", "achieved": B * ex / ksec / 1e12, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
+                         "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch") if basis == "sic" else None,
                          "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
-                         "executed_flop": ex, "executed_tflops": B * ex / ksec / 1e12,
-                         "executed_frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
-                         "executed_breakdown": {k: round(v) for k, v in parts.items()},
-                         "note": "achieved = algorithmic flops of the reference's dense formulation (3 x 2m x 4096 "
-                                 "complex MACs per outer iteration + ~25 N^3 per 64 x 64 eigendecomposition) / "
-                                 "HIP-event kernel time; executed_* = flops the Kronecker-form kernel really "
-                                 "performs, from its work counters (DESIGN.md 2.2)"}}
+                         "executed_flop": ex, "executed_breakdown": {k: round(v) for k, v in parts.items()},
+                         "dense_formulation_tflops": tflops,
+                         "note": "achieved / frac = flops the Kronecker-form kernel really performs per reconstruction, from its "
+                                 "work counters (DESIGN.md 2.2), x batch / HIP-event kernel time.  dense_formulation_tflops = the "
+                                 "same launch priced in the reference's dense formulation (3 x 2m x 4096 complex MACs per outer "
+                                 "iteration + ~25 N^3 per 64 x 64 eigendecomposition): an accounting figure that exceeds the fp64 "
+                                 "peak for the Pauli in-basis, because the dense A products it counts are never executed"}}
     if with_cpu and comm.rank == 0 and basis == "sic":
         line["cpu_baseline"] = pgdb3_cpu_baseline(design, e, c, args.iters)
+    for buf in (d_e, d_c, d_choi, d_it, d_dy, d_w):
+        buf.free()
+    return line
+
+
+def run_pgdb1(args, comm, _lib, synthetic, with_cpu):
+    """Single-qubit process tomography to convergence (what the reference's own tests and notebook run,
+    tests/test_process_tomography.py:72-112), 2^20 experiments per GPU on the lane-per-reconstruction kernel
+    (csrc/fbx_pgdb1.hip): 16 384 distinct experiments of the SURVEY 8d recipe, each 64 times."""
+    distinct, reps = 16384, 64
+    B = distinct * reps
+    design, _, e0, c0 = synthetic.process_batch(1, "pauli", distinct, first_item=distinct * comm.rank)
+    lib = _lib.lib()
+    d_e, d_c = _lib.DeviceBuffer.from_array(np.tile(e0, (reps, 1))), _lib.DeviceBuffer.from_array(np.tile(c0, (reps, 1)))
+    d_choi = _lib.DeviceBuffer(B * 16 * 16)
+    d_it, d_dy, d_w = _lib.DeviceBuffer(B * 4), _lib.DeviceBuffer(B * 4), _lib.DeviceBuffer(B * 16)
+
+    def step():
+        _lib.check(lib.fbx_pgdb_process_dev(design.handle, B, d_e.ptr, d_c.ptr, 1, _lib.MODE_CONVERGE, 0,
+                                            d_choi.ptr, d_it.ptr, d_dy.ptr, None, None, d_w.ptr))
+
+    steps = max(1, min(args.steps, 5))
+    elapsed, kms = timed_steps(step, steps, min(args.warmup, 1), comm, _lib)
+    its = d_it.to_array(np.int32, (B,))[:distinct]; dyk = d_dy.to_array(np.int32, (B,))[:distinct]
+    work = d_w.to_array(np.int32, (B, 4))[:distinct]
+    ksec = kms / 1e3 / steps
+    m, S = design.m, design.n_states
+    # flops a lane executes (fma = 2), from the work counters: a 4 x 4 Jacobi sweep = 6 rotations x (36 + 2 x 24 + 4 x 24) ~ 1080,
+    # a warm basis change 2 x 64 + 40 complex MACs ~ 1350, V L V^H + Dykstra bookkeeping ~ 700 per Dykstra iteration; a full
+    # cost evaluation 2 m x 45 + 32 S; a gradient 2 m x 30 + 64 S; a power-sum pass 2 m x 40; three Pauli transforms of 130
+    ex = float(np.mean(work[:, 0] * 1080.0 + dyk * (1350.0 + 700.0) + work[:, 2] * (90.0 * m + 32.0 * S)
+                       + its * (60.0 * m + 64.0 * S + 390.0) + work[:, 3] * 80.0 * m))
+    line = {"metric": "process-tomography MLE reconstructions/sec (1-qubit, to convergence)",
+            "value": comm.world * B * steps / elapsed, "unit": "reconstructions/s", "n_gpus": comm.world,
+            "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{B} single-qubit process tomographies per GPU ({distinct} distinct experiments x {reps}), pauli "
+                                   f"in-basis ({m} settings, 1000 shots), PGDB to convergence (the reference's stopping rule), "
+                                   "inputs resident in HBM", "batch_per_gpu": B, "parallelism": f"shard{comm.world}",
+                       "mean_outer_iters": float(its.mean()), "max_outer_iters": int(its.max()),
+                       "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean())},
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU (one reconstruction per lane)", "achieved": B * ex / ksec / 1e12,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
+                         "traffic": None, "kernel": "pgdb1_packed_kernel", "kernel_ms": 1e3 * ksec, "executed_flop": ex,
+                         "note": "flops executed per reconstruction (work counters x per-unit counts from the source) x batch / "
+                                 "HIP-event kernel time; lanes idle through divergence (a wavefront runs the longest Dykstra / "
+                                 "line-search trip count of its 64 lanes) are not counted as work"}}
+    if with_cpu and comm.rank == 0:
+        od, oe, _, _ = _oracle()
+        d = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)
+        A = oe.design_matrix_A(d)
+        n, t0 = 0, time.perf_counter()
+        while n < 256 and time.perf_counter() - t0 < max(2.0, args.cpu_sample / 4):
+            oe.pgdb_process_estimate(d, e0[n], c0[n], A=A)
+            n += 1
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": n / dt, "unit": "reconstructions/s", "cores": 1, "kind": "port",
+                                "sample": f"first {n} experiments to convergence, numpy oracle with the design matrix hoisted, {dt:.1f} s"}
     for buf in (d_e, d_c, d_choi, d_it, d_dy, d_w):
         buf.free()
     return line
@@ -679,6 +738,8 @@ def main():
         line = run_sweep(args, comm, _lib, synthetic, with_cpu)
     elif args.workload == "pgdb3":
         line = run_pgdb3(args, comm, _lib, synthetic, with_cpu)
+    elif args.workload == "pgdb1":
+        line = run_pgdb1(args, comm, _lib, synthetic, with_cpu)
     else:
         secondary = []
         if args.workload == "all" and comm.world == 1:
@@ -688,6 +749,7 @@ def main():
             secondary.append(run_pgdb3(args, comm, _lib, synthetic, with_cpu))
             args.in_basis = "pauli"                          # the stretch form of configs[3]: 13 608 settings
             secondary.append(run_pgdb3(args, comm, _lib, synthetic, False))
+            secondary.append(run_pgdb1(args, comm, _lib, synthetic, with_cpu))
             args.in_basis = basis
             _lib.release_workspace()
         line, batch = run_pgdb(args, comm, _lib, synthetic, rank_info)

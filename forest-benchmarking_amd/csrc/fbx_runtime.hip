@@ -437,8 +437,9 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
                       const uint8_t* paulis, const double* coefs, fbx_design** out) {
     FBX_REQUIRE(out != nullptr, "fbx_design_create: NULL out");
     *out = nullptr;
-    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_design_create: n_qubits must be 1..3");
     FBX_REQUIRE(kind == FBX_KIND_STATE || kind == FBX_KIND_PROCESS, "fbx_design_create: bad kind");
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= (kind == FBX_KIND_STATE ? 5 : 3),
+                "fbx_design_create: n_qubits must be 1..3 for process designs, 1..5 for state designs");
     FBX_REQUIRE(m >= 1 && m < 65536, "fbx_design_create: m must be in [1, 65535]");
     FBX_REQUIRE(paulis != nullptr, "fbx_design_create: NULL paulis");
     FBX_REQUIRE(kind == FBX_KIND_STATE || in_labels != nullptr,

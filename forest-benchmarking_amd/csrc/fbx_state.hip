@@ -894,6 +894,251 @@ using namespace fbx;
 #define FBX_MLE_UNPACKED 0      // diagnostics: 1 = always one reconstruction per wavefront
 #endif
 
+// =====================================================================================================
+// 4 and 5 qubits (16 x 16 and 32 x 32 density matrices, 255 / 1023 settings): ONE WORKGROUP OF d*d THREADS per state
+// (256 / 1024), thread t owns matrix entry (t / d, t % d) as a lane does above, the same device routines
+// (pauli_expectations, pauli_synthesis, the block Jacobi) with workgroup barriers and workgroup sums.  A 16 x 16
+// density matrix has the size of a 2-qubit Choi matrix: its Hermitian functions (logm for the entropy penalty,
+// pinv for hedging) run on the solver of the 2- / 3-qubit process kernels (jacobi_eigh_simple<d, NT>).
+// Settings are held one per thread (m <= d*d for every design of the reference); weights of the R operator
+// are summed with LDS atomics (several settings on the same Pauli operator -- not in the reference's designs --
+// would add in an order that differs between runs at rounding level).
+template <int NQ>
+struct StateBigLds {
+    static constexpr int d = 1 << NQ, D = d * d, NT = D;
+    cplx *rho, *U, *tmp, *aux, *Ms, *Vs;
+    double *w, *r, *lam, *red;
+    static constexpr size_t bytes() { return sizeof(cplx) * (4 * (size_t)D + 2 * (size_t)sys_elems<d>()) + sizeof(double) * (2 * (size_t)D + d + 2 * (NT / 64) + 8); }
+    __device__ void carve(char* p) {
+        rho = (cplx*)p; p += sizeof(cplx) * D;  U = (cplx*)p; p += sizeof(cplx) * D;
+        tmp = (cplx*)p; p += sizeof(cplx) * D;  aux = (cplx*)p; p += sizeof(cplx) * D;
+        Ms = (cplx*)p; p += sizeof(cplx) * sys_elems<d>();  Vs = (cplx*)p; p += sizeof(cplx) * sys_elems<d>();
+        w = (double*)p; p += sizeof(double) * D; r = (double*)p; p += sizeof(double) * D;
+        lam = (double*)p; p += sizeof(double) * d; red = (double*)p;
+    }
+};
+
+template <int NQ>
+__device__ __forceinline__ double big_sum(double v, StateBigLds<NQ>& L) { return block_sum<StateBigLds<NQ>::NT>(v, L.red); }
+
+// R operator (tomography.py:273-338) of the state in L.rho; element of this thread.  Ends behind a barrier.
+template <int NQ>
+__device__ cplx r_operator_big(const DesignDev& des, const double* __restrict__ e, StateBigLds<NQ>& L, int t) {
+    constexpr int d = 1 << NQ, NT = d * d;
+    const int m = des.m;
+    pauli_expectations<NQ>(L.rho, L.r, t);
+    L.w[t] = 0.0;
+    __syncthreads();
+    double s0 = 0.0;
+    for (int g = t; g < m; g += NT) {
+        const int p = des.sp[g] & 0xffff;
+        const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+        const double me = e[des.order[g]], pe = cf * L.r[p];
+        const double gp = ((1.0 + me) * 0.5) / ((1.0 + pe) * 0.5 + DBL_MIN);
+        const double gm = ((1.0 - me) * 0.5) / ((1.0 - pe) * 0.5 + DBL_MIN);
+        s0 += 0.5 * (gp + gm);
+        atomicAdd(&L.w[p], cf * 0.5 * (gp - gm));
+    }
+    s0 = big_sum<NQ>(s0, L);                            // (two barriers: the atomics above are complete behind them)
+    L.w[t] = L.w[t] / m;
+    __syncthreads();
+    const cplx out = pauli_synthesis<NQ>(L.w, s0 / m + 0.0, t / d, t % d);
+    __syncthreads();
+    return out;
+}
+
+// dst = V f(lambda) V^H of the Hermitian part of `src` (row-major); fn as herm_function
+template <int NQ>
+__device__ void herm_function_big(const cplx* src, cplx* dst, int fn, StateBigLds<NQ>& L, int t) {
+    constexpr int d = 1 << NQ, NB = d / 2, NT = d * d;
+    Blk h = blk_zero();
+    if (t < NB * NB) {
+        const int I = t / NB, J = t % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * I + (e >> 1), c = 2 * J + (e & 1);
+            const cplx a = src[r * d + c], b = src[c * d + r];
+            h.re[e] = 0.5 * (a.re + b.re); h.im[e] = 0.5 * (a.im - b.im);
+        }
+    }
+    __syncthreads();
+    sys_store<d>(L.Ms, t, h);
+    __syncthreads();
+    jacobi_eigh_simple<d, NT>(L.Ms, L.Vs, t, true, L.red);
+    __syncthreads();
+    double lmax = 0.0;
+    if (t < d) lmax = fabs(L.Ms[sys_index<d>(t, t)].re);
+    lmax = wave_max(lmax);                                   // d <= 32: the diagonal sits in the first wavefront
+    if (t < d) {
+        const double l = L.Ms[sys_index<d>(t, t)].re;
+        double f;
+        if (fn == 0) f = log(l);
+        else if (fn == 1) f = (fabs(l) > d * DBL_EPSILON * lmax) ? 1.0 / l : 0.0;
+        else f = sqrt(l > 0.0 ? l : 0.0);
+        L.lam[t] = f;
+    }
+    __syncthreads();
+    const Blk o = reconstruct_blk<d>(L.Vs, L.lam, t);
+    blk_store<d, d>(dst, t, o);
+    __syncthreads();
+}
+
+template <int NQ>
+__device__ __forceinline__ cplx matmul_big(const cplx* A, const cplx* Bm, int t) {
+    constexpr int d = 1 << NQ;
+    const int r = t / d, c = t % d;
+    cplx o; o.re = 0.0; o.im = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < d; ++k) {
+        const cplx a = A[r * d + k], b = Bm[k * d + c];
+        o.re += a.re * b.re - a.im * b.im;
+        o.im += a.re * b.im + a.im * b.re;
+    }
+    return o;
+}
+
+// iterative_mle_state_estimate, tomography.py:168-270: statement for statement the loop of mle_state_kernel
+template <int NQ>
+__global__ void __launch_bounds__(1 << (2 * NQ))
+mle_state_big_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
+                     double epsilon, double entropy_penalty, double beta, double tol, int maxiter,
+                     double* __restrict__ rho_out, int* __restrict__ iters_out, int* __restrict__ hit_out) {
+    constexpr int d = 1 << NQ, D = d * d, NT = D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StateBigLds<NQ> L; L.carve(smem);
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    const double* e = expect + item * des.m;
+    const int row = t / d, col = t % d;
+    double num_meas = 0.0;
+    for (int g = t; g < des.m; g += NT) num_meas += counts[item * des.m + g];
+    num_meas = big_sum<NQ>(num_meas, L);
+    cplx rho; rho.re = (row == col) ? 1.0 / d : 0.0; rho.im = 0.0;
+    L.rho[t] = rho;
+    __syncthreads();
+    int iteration = 1, hit = 0;
+    while (true) {
+        if (iteration >= maxiter) { hit = 1; break; }
+        cplx T = r_operator_big<NQ>(des, e, L, t);
+        if (row == col) T.re -= 1.0;
+        if (entropy_penalty > 0.0) {
+            herm_function_big<NQ>(L.rho, L.aux, 0, L, t);          // logm(rho)
+            cplx lg = L.aux[t];
+            const cplx rl = matmul_big<NQ>(L.rho, L.aux, t);
+            double tr_re = (row == col) ? rl.re : 0.0, tr_im = (row == col) ? rl.im : 0.0;
+            tr_re = big_sum<NQ>(tr_re, L); tr_im = big_sum<NQ>(tr_im, L);
+            if (row == col) { lg.re -= tr_re; lg.im -= tr_im; }
+            T.re -= entropy_penalty * lg.re; T.im -= entropy_penalty * lg.im;
+        }
+        if (beta > 0.0) {
+            T.re *= num_meas / 2; T.im *= num_meas / 2;
+            herm_function_big<NQ>(L.rho, L.aux, 1, L, t);          // pinv(rho)
+            cplx pi = L.aux[t];
+            if (row == col) pi.re -= d;
+            T.re += beta * pi.re / 2; T.im += beta * pi.im / 2;
+        }
+        cplx Um; Um.re = epsilon * T.re + ((row == col) ? 1.0 : 0.0); Um.im = epsilon * T.im;
+        __syncthreads();
+        L.U[t] = Um;
+        __syncthreads();
+        const cplx t1 = matmul_big<NQ>(L.rho, L.U, t);
+        L.tmp[t] = t1;
+        __syncthreads();
+        cplx nr = matmul_big<NQ>(L.U, L.tmp, t);
+        double tr_re = (row == col) ? nr.re : 0.0, tr_im = (row == col) ? nr.im : 0.0;
+        tr_re = big_sum<NQ>(tr_re, L); tr_im = big_sum<NQ>(tr_im, L);
+        {
+            const double den = tr_re * tr_re + tr_im * tr_im;
+            const double qr = (nr.re * tr_re + nr.im * tr_im) / den, qi = (nr.im * tr_re - nr.re * tr_im) / den;
+            nr.re = qr; nr.im = qi;
+        }
+        double diff = (nr.re - rho.re) * (nr.re - rho.re) + (nr.im - rho.im) * (nr.im - rho.im);
+        diff = big_sum<NQ>(diff, L);
+        rho = nr;
+        __syncthreads();
+        L.rho[t] = rho;
+        __syncthreads();
+        if (sqrt(diff) < tol) break;
+        ++iteration;
+    }
+    rho_out[(item * D + t) * 2] = rho.re; rho_out[(item * D + t) * 2 + 1] = rho.im;
+    if (t == 0) { if (iters_out) iters_out[item] = iteration; if (hit_out) hit_out[item] = hit; }
+}
+
+// op 0: R operator of a given state, 1: log-likelihood (log10) of a given state, 2: linear inversion
+template <int NQ>
+__global__ void __launch_bounds__(1 << (2 * NQ))
+state_big_kernel(int op, DesignDev des, long long B, const double* __restrict__ rho_in, const double* __restrict__ expect,
+                 const double* __restrict__ counts, double* __restrict__ out) {
+    constexpr int d = 1 << NQ, D = d * d, NT = D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StateBigLds<NQ> L; L.carve(smem);
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    const int m = des.m;
+    if (op == 2) {                                         // tomography.py:130-165, as linv_state_kernel
+        double* num = L.w; double* den = L.r;
+        num[t] = 0.0; den[t] = 0.0;
+        __syncthreads();
+        for (int g = t; g < m; g += NT) {
+            const int p = des.sp[g] & 0xffff;
+            const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+            atomicAdd(&num[p], cf * expect[item * m + des.order[g]]);
+            atomicAdd(&den[p], cf * cf);
+        }
+        __syncthreads();
+        const double wv = den[t] > 0.0 ? num[t] / (den[t] * d) : 0.0;
+        __syncthreads();
+        L.w[t] = wv;
+        __syncthreads();
+        const cplx v = pauli_synthesis<NQ>(L.w, 1.0 / d, t / d, t % d);
+        out[(item * D + t) * 2] = v.re; out[(item * D + t) * 2 + 1] = v.im;
+        return;
+    }
+    L.rho[t].re = rho_in[(item * D + t) * 2]; L.rho[t].im = rho_in[(item * D + t) * 2 + 1];
+    __syncthreads();
+    if (op == 0) {
+        const cplx R = r_operator_big<NQ>(des, expect + item * m, L, t);
+        out[(item * D + t) * 2] = R.re; out[(item * D + t) * 2 + 1] = R.im;
+        return;
+    }
+    pauli_expectations<NQ>(L.rho, L.r, t);
+    __syncthreads();
+    double ll = 0.0;
+    for (int g = t; g < m; g += NT) {
+        const int k = des.order[g], p = des.sp[g] & 0xffff;
+        const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+        const double n = counts[item * m + k], me = expect[item * m + k], pe = cf * L.r[p];
+        const double pp = (1.0 + pe) / 2, pm = (1.0 - pe) / 2;
+        if (pp > 0.0) ll += n * (1.0 + me) / 2 * log10(pp);
+        if (pm > 0.0) ll += n * (1.0 - me) / 2 * log10(pm);
+    }
+    ll = big_sum<NQ>(ll, L);
+    if (t == 0) out[item] = ll;
+}
+
+template <int NQ>
+static int launch_state_big(int op, const fbx_design* des, int64_t B, const double* rho, const double* e, const double* c, double* out) {
+    const size_t lds = StateBigLds<NQ>::bytes();
+    FBX_HIP(hipFuncSetAttribute((const void*)state_big_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(state_big_kernel<NQ>, dim3((unsigned)B), dim3(1 << (2 * NQ)), lds, stream(), op, des->dev, (long long)B, rho, e, c, out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+static int state_big(int op, const fbx_design* des, int64_t B, const double* rho, const double* e, const double* c, double* out) {
+    return des->dev.n == 4 ? launch_state_big<4>(op, des, B, rho, e, c, out) : launch_state_big<5>(op, des, B, rho, e, c, out);
+}
+template <int NQ>
+static int launch_mle_big(const fbx_design* des, int64_t B, const double* e, const double* c, double epsilon, double entropy_penalty,
+                          double beta, double tol, int maxiter, double* rho, int32_t* it, int32_t* hit) {
+    const size_t lds = StateBigLds<NQ>::bytes();
+    FBX_HIP(hipFuncSetAttribute((const void*)mle_state_big_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mle_state_big_kernel<NQ>, dim3((unsigned)B), dim3(1 << (2 * NQ)), lds, stream(), des->dev, (long long)B, e, c,
+                       epsilon, entropy_penalty, beta, tol, maxiter, rho, it, hit);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 namespace {
 struct HostIO {
     std::vector<DevBuf*> bufs;
@@ -988,6 +1233,7 @@ int fbx_linv_state_dev(const fbx_design* design, int64_t B, const double* d_expe
     FBX_REQUIRE(B >= 0 && (B == 0 || (d_expect && d_rho_out)), "fbx_linv_state: bad batch / NULL buffer");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
+    if (design->dev.n >= 4) return state_big(2, design, B, nullptr, d_expect, nullptr, d_rho_out);
     FBX_DISPATCH_NQ(design->dev.n, linv_state_kernel, 0, B, design->dev, (long long)B, d_expect, d_rho_out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;
@@ -1016,6 +1262,8 @@ int fbx_mle_state_dev(const fbx_design* design, int64_t B, const double* d_expec
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
+    if (n == 4) return launch_mle_big<4>(design, B, d_expect, d_counts, epsilon, entropy_penalty, beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
+    if (n == 5) return launch_mle_big<5>(design, B, d_expect, d_counts, epsilon, entropy_penalty, beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
     const size_t lds = state_lds(n, (int)m);
     if (lds > 64 * 1024) { set_error("fbx_mle_state: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
     const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !FBX_MLE_UNPACKED;
@@ -1057,6 +1305,7 @@ int fbx_r_operator_dev(const fbx_design* design, int64_t B, const double* d_rho,
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const int n = design->dev.n;
+    if (n >= 4) return state_big(0, design, B, d_rho, d_expect, nullptr, d_r_out);
     const size_t lds = state_lds(n, (int)design->dev.m);
     if (lds > 64 * 1024) { set_error("fbx_r_operator: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
     FBX_DISPATCH_NQ(n, r_operator_kernel, lds, B, design->dev, (long long)B, d_rho, d_expect, d_r_out);
@@ -1084,6 +1333,7 @@ int fbx_state_log_likelihood_dev(const fbx_design* design, int64_t B, const doub
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const int n = design->dev.n;
+    if (n >= 4) return state_big(1, design, B, d_rho, d_expect, d_counts, d_ll_out);
     FBX_DISPATCH_NQ(n, loglik_kernel, state_lds(n, 1), B, design->dev, (long long)B, d_rho, d_expect, d_counts, d_ll_out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;

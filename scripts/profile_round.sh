@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 evidence for one round, all three bench workloads (run ON the GPU box):
+# rocprofv3 evidence for one round, all four bench workloads (run ON the GPU box):
 #   bash scripts/profile_round.sh r02
-# Pass 1: --kernel-trace --stats of `python bench.py --workload <pgdb|sweep|pgdb3> --cpu-sample 0 --steps 5 --warmup 1`.
+# Pass 1: --kernel-trace --stats of `python bench.py --workload <pgdb|sweep|pgdb3|pgdb1> --cpu-sample 0 --steps 5 --warmup 1`.
 # Passes 2..: --pmc only (never combined with a trace domain), one counter group per pass:
 #   FETCH_SIZE | WRITE_SIZE | SQ group A | SQ group B.
 # Summaries land in gpurun_out/profile_<tag>/ (copy what should be judged into profiles/<tag>/).
@@ -17,12 +17,12 @@ BENCH="python $REPO/bench.py --cpu-sample 0"
 cd /tmp
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 # one trace run per workload, so that a kernel's average duration is over the bench launches only
-for wl in pgdb sweep pgdb3; do
+for wl in pgdb sweep pgdb3 pgdb1; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$wl" -o trace -- $BENCH --workload $wl --steps 5 --warmup 1 > "$OUT/bench_trace_$wl.log" 2>&1
 done
 pass() {   # name, counters...: one run per workload so that a kernel's mean is over identical launches
     local name=$1; shift
-    for wl in pgdb sweep pgdb3; do
+    for wl in pgdb sweep pgdb3 pgdb1; do
         rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_${name}_$wl" -o pmc -- $BENCH --workload $wl --steps 2 --warmup 1 > "$OUT/bench_pmc_${name}_$wl.log" 2>&1
     done
 }

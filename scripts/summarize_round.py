@@ -4,7 +4,8 @@ correction: FETCH_SIZE (KiB) x 1024 x 2 + WRITE_SIZE (KiB) x 1024."""
 import csv, glob, json, os, sys
 out, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
-KERNELS = {"pgdb_kernel": "pgdb", "pgdb3_kernel": "pgdb3", "sweep2q_pair_kernel": "sweep", "random_kraus_kernel": "random_kraus"}
+KERNELS = {"pgdb_kernel": "pgdb", "pgdb3_kernel": "pgdb3", "sweep2q_pair_kernel": "sweep", "random_kraus_kernel": "random_kraus",
+           "pgdb1_packed_kernel": "pgdb1"}
 
 
 def short(name):
@@ -15,7 +16,7 @@ def short(name):
 
 
 lines = []
-for wl in ("pgdb", "sweep", "pgdb3"):
+for wl in ("pgdb", "sweep", "pgdb3", "pgdb1"):
     for f in glob.glob(os.path.join(out, f"trace_{wl}", "**", "*kernel_stats.csv"), recursive=True):
         lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload {wl} --cpu-sample 0 --steps 5 --warmup 1")
         lines += [l.rstrip() for l in open(f)]
@@ -47,7 +48,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 continue
             pmc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 summary = {"tag": tag, "note": "means per kernel launch; separate --pmc passes (never combined with a trace domain); "
-                               "bench.py --workload <pgdb|sweep|pgdb3> --steps 2 --warmup 1 --cpu-sample 0, i.e. every launch of a kernel "
+                               "bench.py --workload <pgdb|sweep|pgdb3|pgdb1> --steps 2 --warmup 1 --cpu-sample 0, i.e. every launch of a kernel "
                                "in a pass is the bench launch (pgdb: B = 1024, fixed 100 iterations)",
            "kernels": {}}
 for k, cs in pmc.items():
@@ -65,7 +66,8 @@ for k, cs in pmc.items():
 json.dump(summary, open(os.path.join(dst, "pmc_counters.json"), "w"), indent=1)
 traffic = {"tag": tag, "note": "FETCH_SIZE(KiB) x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section) + "
                                 "WRITE_SIZE(KiB) x 1024; separate --pmc passes; per launch of the bench workload"}
-for k, key in (("pgdb", "pgdb_kernel_hbm_bytes_per_launch"), ("sweep", "sweep_kernel_hbm_bytes_per_launch"), ("pgdb3", "pgdb3_kernel_hbm_bytes_per_launch")):
+for k, key in (("pgdb", "pgdb_kernel_hbm_bytes_per_launch"), ("sweep", "sweep_kernel_hbm_bytes_per_launch"), ("pgdb3", "pgdb3_kernel_hbm_bytes_per_launch"),
+               ("pgdb1", "pgdb1_kernel_hbm_bytes_per_launch")):
     if k in summary["kernels"] and "hbm_bytes_per_launch" in summary["kernels"][k]:
         traffic[key] = summary["kernels"][k]["hbm_bytes_per_launch"]
         traffic[k + "_FETCH_SIZE_KiB"] = summary["kernels"][k]["FETCH_SIZE"]["mean"]

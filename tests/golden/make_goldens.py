@@ -76,7 +76,8 @@ def make_process_3q(batch=4):
     print("process 3 sic done")
 
 
-def make_state(n, batch):
+def make_state(n, batch, tol_maxiter=2000):
+    """(4 and 5 qubits: ``tol_maxiter`` 300 -- the reference takes ~0.1 s per iteration on 1023 settings)"""
     qubits = list(range(n))
     design, rhos, e, c = synthetic.state_batch(n, batch, mixed=0.1)
     settings = list(T._state_tomo_settings(qubits))
@@ -90,7 +91,7 @@ def make_state(n, batch):
             m100 = T.iterative_mle_state_estimate(res, qubits, maxiter=100)
             out["mle100"].append(m100)
             out["mle_tol"].append(T.iterative_mle_state_estimate(res, qubits, epsilon=0.5, tol=1e-6,
-                                                                 maxiter=2000))
+                                                                 maxiter=tol_maxiter))
             out["hedged"].append(T.iterative_mle_state_estimate(res, qubits, beta=0.5, epsilon=1e-4,
                                                                 maxiter=60))
             out["maxent"].append(T.iterative_mle_state_estimate(res, qubits, entropy_penalty=0.005,
@@ -433,6 +434,10 @@ if __name__ == "__main__":
         make_process_3q()
         make_superops(3, 1)
         sys.exit(0)
+    if "--state45" in sys.argv:
+        make_state(4, 3, tol_maxiter=300)
+        make_state(5, 2, tol_maxiter=300)
+        sys.exit(0)
     if "--2q" in sys.argv:
         make_process(2, "sic", 16, 2)
         make_process(2, "pauli", 16, 1)
@@ -443,6 +448,8 @@ if __name__ == "__main__":
     make_process(2, "pauli", 16, 1)
     make_state(1, 6)
     make_state(2, 4)
+    make_state(4, 3, tol_maxiter=300)
+    make_state(5, 2, tol_maxiter=300)
     make_superops(1, 6)
     make_superops(2, 6)
     make_extras()
