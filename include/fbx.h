@@ -153,7 +153,9 @@ int fbx_timer_end(double* elapsed_ms);
  * every item of a batch.  Replaces the per-call rebuilding of measurement operators in
  * tomography.py:159-160 (linear inversion), :326-327 (_R), :482-486, :494-539
  * (_extract_from_results).  in_labels / paulis are [m][n_qubits] codes (in_labels may be
- * NULL for FBX_KIND_STATE); coefs[m] are the observables' real coefficients (NULL = 1). */
+ * NULL for FBX_KIND_STATE); coefs[m] are the observables' real coefficients (NULL = 1).
+ * n_qubits: 1..3 for process designs (4^n x 4^n Choi matrices up to 64 x 64), 1..5 for state designs
+ * (density matrices up to 32 x 32, 1023 settings). */
 int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
                       const uint8_t* paulis, const double* coefs, fbx_design** out);
 int fbx_design_destroy(fbx_design* design);
@@ -207,7 +209,7 @@ int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect,
 int fbx_linv_process_dev(const fbx_design* design, int64_t B, const double* d_expect,
                          double* d_choi_out);
 
-/* ---------------------------------------------------------------- state estimators
+/* ---------------------------------------------------------------- state estimators (1..5 qubits)
  * linear_inv_state_estimate (tomography.py:130-165): rho_out[B][d][d], d = 2^n. */
 int fbx_linv_state(const fbx_design* design, int64_t B, const double* expect, double* rho_out);
 int fbx_linv_state_dev(const fbx_design* design, int64_t B, const double* d_expect,

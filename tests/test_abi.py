@@ -67,5 +67,7 @@ def test_argument_errors_map_to_value_error():
     rc = lib.fbx_mle_state(None, 1, None, None, 0.1, 0.0, 0.0, 1e-9, 10, None, None, None)
     assert rc == _lib.FBX_ERR_BAD_ARG
     h = ctypes.c_void_p()
-    rc = lib.fbx_design_create(4, 0, 1, None, None, None, ctypes.byref(h))
+    rc = lib.fbx_design_create(6, 0, 1, None, None, None, ctypes.byref(h))           # state designs: 1..5 qubits
+    assert rc == _lib.FBX_ERR_BAD_ARG and b"n_qubits" in lib.fbx_last_error()
+    rc = lib.fbx_design_create(4, 1, 1, None, None, None, ctypes.byref(h))           # process designs: 1..3
     assert rc == _lib.FBX_ERR_BAD_ARG and b"n_qubits" in lib.fbx_last_error()
