@@ -6,8 +6,8 @@ import numpy as np
 from fbx import synthetic, tomography, _lib
 _lib.set_device(0)
 warnings.simplefilter("ignore")
-for n, B in ((1, 16384), (2, 16384), (3, 4096)):
-    design, rhos, e, c = synthetic.state_batch(n, min(B, 1024), mixed=0.05)
+for n, B in ((1, 16384), (2, 16384), (3, 4096), (4, 1024), (5, 512)):
+    design, rhos, e, c = synthetic.state_batch(n, min(B, 1024 if n < 4 else 64), mixed=0.05)
     reps = B // e.shape[0]
     e = np.tile(e, (reps, 1)); c = np.tile(c, (reps, 1))
     for name, fn in (("linear_inv", lambda: tomography.linear_inv_state_estimate_batch(design, e)),
