@@ -580,6 +580,16 @@ def run_pgdb(args, comm, _lib, synthetic, rank_info):
     return line, batch
 
 
+def _pipeline_stages(n, chunk):
+    """Launches of the pipelined host-pointer call (csrc/fbx_pgdb.hip): a small first stage, the bulk in pieces of <= 65 536
+    items on a high-priority stream, a small last stage."""
+    if n <= chunk:
+        return 1
+    first = min(chunk, n // 2)
+    last = chunk if n - first > chunk else 0
+    return 1 + -(-(n - first - last) // 65536) + (1 if last else 0)
+
+
 def strong_anchor(args, comm, _lib, synthetic):
     """N = 1 only: BASELINE configs[4]'s whole batch (65 536 distinct items, the very items the ranks of an N-GPU run
     own between them) on ONE GPU, so that the driver's 1 -> 2 -> 4 -> 8 curve has a same-workload N = 1 point next to
@@ -625,11 +635,12 @@ def strong_anchor(args, comm, _lib, synthetic):
         th = float(np.median(ts[1:]))
         incl[str(nb)] = {"value": nb / th, "unit": "reconstructions/s", "ms_per_call": 1e3 * th, "resident_ms": res_ms,
                          "fraction_of_resident": res_ms / (1e3 * th), "calls": calls,
-                         "stages": -(-nb // int(_lib.get_option("pgdb_host_chunk")))}
+                         "stages": _pipeline_stages(nb, int(_lib.get_option("pgdb_host_chunk")))}
     out["pcie_inclusive"] = incl
-    out["pcie_inclusive_note"] = ("fbx_pgdb_process on page-locked host buffers: H2D of stage k + 1 and D2H of stage k - 1 under the "
-                                  "kernel of stage k (three streams, stages of fbx_set_option('pgdb_host_chunk') items); median of the "
-                                  "calls after one warm-up, against the HBM-resident launch of the same items")
+    out["pcie_inclusive_note"] = ("fbx_pgdb_process on page-locked host buffers: a small first stage (fbx_set_option('pgdb_host_chunk') "
+                                  "items) whose kernel covers the upload of the rest, the bulk in one launch on a high-priority stream, a "
+                                  "small last stage that is still computing while the bulk's results go down; median of the calls after "
+                                  "one warm-up, against the HBM-resident launch of the same items")
     del pe, pc_, pout
     batch.free()
     return out
@@ -675,7 +686,7 @@ def single_gpu_extras(args, comm, _lib, synthetic, batch, line):
                               "note": "fbx_pgdb_process on page-locked host buffers (fbx_host_alloc): H2D of 8.8 MB, kernel, D2H of "
                                       "4.2 MB, host call overhead; median of 10 calls after one warm-up.  `value` of this line "
                                       "is the HBM-resident rate (the bench contract); this is SURVEY 8d's transfer-inclusive "
-                                      "rate.  One stage at B = 1024 (nothing to overlap); see strong_65536.pcie_inclusive"}
+                                      "rate.  One launch at B = 1024 (nothing to overlap); see strong_65536.pcie_inclusive"}
     del pe, pc_, pout
     # ---- one experiment at a time through the reference signature (List[ExperimentResult], qubits)
     from fbx.observable_estimation import ExperimentResult

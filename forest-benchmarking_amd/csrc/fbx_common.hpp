@@ -46,7 +46,7 @@ struct PgdbExtras {
     int32_t* trace = nullptr;      // DEVICE [B][trace_iters][2]: Dykstra iterations and halvings of every outer iteration
     int trace_iters = 0;
     // set by the pipelined host-pointer entry point only: the stream a stage's kernels go to, and the stage's share of
-    // the per-item workspace (two stages are in flight, each with its own `ws_items` slots starting at `ws_offset`)
+    // the per-item workspace: `ws_items` slots in all, this stage's start at `ws_offset` (stages on different streams get disjoint ranges)
     hipStream_t launch_stream = nullptr;
     int64_t ws_items = 0, ws_offset = 0;
 };

@@ -16,6 +16,7 @@
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
 #include "fbx_choi.hpp"
 #include <cstdlib>
+#include <vector>
 #ifndef FBX_LEAN_CL_LDS
 #define FBX_LEAN_CL_LDS 0           // experiment: the lean kernel keeps its own LDS copy of the Bloch matrix (7 instead of 8 waves per CU)
 #endif
@@ -165,12 +166,15 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
             for (int j = 0; j < MAXJ; ++j) {
                 L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
             }
-        } else if (ncounts) {
-            // LEAN: the same table in the item's slice of an L2-resident workspace (lane-contiguous rows)
+        } else {
+            // LEAN: the same table in the item's slice of an L2-resident workspace (lane-contiguous rows: coalesced.  One run of
+            // 2 MAXJ doubles per lane -- a single address register instead of one per row -- measured 2.2 x slower: 64 cache lines per load)
+#ifndef FBX_LEAN_RECOUNT
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j) {
                 ncounts[(2 * j) * 64 + lane] = npl[j] / tot; ncounts[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
             }
+#endif
         }
     }
     FBX_WAVE_SYNC();
@@ -178,10 +182,10 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
     // program order is all the ordering needed), or recomputed from the inputs with the same expressions
     auto counts_of = [&](int j, double& np_, double& nm_) __attribute__((always_inline)) {
         if constexpr (LEAN) {
-            if (ncounts) {
-                np_ = ncounts[(2 * j) * 64 + lane]; nm_ = ncounts[(2 * j + 1) * 64 + lane];
-                return;
-            }
+#ifndef FBX_LEAN_RECOUNT
+            // (the launcher always provides the workspace: no second code path, whose operands the compiler would keep alive)
+            np_ = ncounts[(2 * j) * 64 + lane]; nm_ = ncounts[(2 * j + 1) * 64 + lane];
+#else       // experiment: recomputed from the inputs with the same expressions at every use
             const int g = lane + 64 * j;
             np_ = 0.0; nm_ = 0.0;
             if (g < m) {
@@ -190,6 +194,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
                 const double plus = (1.0 + e) / 2.0;
                 np_ = (c * plus) / tot; nm_ = (c * (1.0 - plus)) / tot;
             }
+#endif
         } else {
             np_ = L.Ln[(2 * j) * 64 + lane]; nm_ = L.Ln[(2 * j + 1) * 64 + lane];
         }
@@ -199,12 +204,19 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
     const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
 
     // per-setting design words stay in registers for the whole reconstruction
-    uint32_t spw[MAXJ];
+    uint32_t spw[LEAN ? 1 : MAXJ];
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int g = lane + 64 * j;
-        spw[j] = g < m ? des.sp[g] : 0u;
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = lane + 64 * j;
+            spw[j] = g < m ? des.sp[g] : 0u;
+        }
     }
+    // (LEAN: re-read from the design where they are used -- coalesced L2 hits -- instead of MAXJ registers)
+    auto design_word = [&](int j) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (LEAN) { const int g = lane + 64 * j; return g < m ? des.sp[g] : 0u; }
+        else return spw[j];
+    };
     const bool unit_coefs = des.unit_coefs != 0;      // wave-uniform: coefficients re-read only when needed
     // model probabilities of the current estimate (pe) and of the update direction (pu), per owned
     // setting and outcome: p(alpha) = pe + alpha * pu, so a line-search step touches no memory
@@ -219,7 +231,8 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
             const int g = lane + 64 * j;
             double a = missing, b = missing;
             if (g < m) {
-                const int s = spw[j] >> 16, p = spw[j] & 0xffff;
+                const uint32_t dw = design_word(j);
+                const int s = dw >> 16, p = dw & 0xffff;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
                 const double tr = T[s * D], ex = cf * T[s * D + p];
                 a = (tr + ex) * half_dd; b = (tr - ex) * half_dd;
@@ -318,7 +331,8 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
                 counts_of(j, np_, nm_);
                 const double ep = np_ / pp, em = nm_ / pm;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
-                const int st = spw[j] >> 16, p = spw[j] & 0xffff;
+                const uint32_t dw = design_word(j);
+                const int st = dw >> 16, p = dw & 0xffff;
                 atomicAdd(&Wt[st * D], 0.5 * (ep + em));
                 atomicAdd(&Wt[st * D + p], cf * 0.5 * (ep - em));
             }
@@ -714,8 +728,8 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     int64_t ws_items = ex.ws_items > 0 ? ex.ws_items : (B < CHUNK ? B : CHUNK);
     if (basis_item + counts_item) {
         for (;;) {
-            // the pipelined host entry point owns 2 x ws_items slots; everybody else min(B, CHUNK)
-            const size_t total = (basis_item + counts_item) * (size_t)(ex.ws_items > 0 ? 2 * ex.ws_items : ws_items);
+            // the pipelined host entry point says how many slots its stages need between them; everybody else min(B, CHUNK)
+            const size_t total = (basis_item + counts_item) * (size_t)ws_items;
             void* w = nullptr;
             const int rc = workspace(WS_PGDB_BASIS, total, &w);
             if (rc == FBX_OK) { wsp = (char*)w; break; }
@@ -724,7 +738,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
             ws_items /= 2; CHUNK = ws_items;
         }
     }
-    const int64_t n_slots = ex.ws_items > 0 ? 2 * ex.ws_items : ws_items;
+    const int64_t n_slots = ws_items;
     cplx* basis = basis_item ? (cplx*)wsp + (size_t)ex.ws_offset * D * D * BASIS_CAP : nullptr;
     double* ncounts = counts_item ? (double*)(wsp + basis_item * (size_t)n_slots) + (size_t)ex.ws_offset * 2 * MAXJ * 64 : nullptr;
 #ifdef FBX_LEAN_RECOUNT      // experiment: the lean kernel recomputes the counts from the inputs at every use
@@ -877,14 +891,32 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
         return rc;
     PgdbExtras ex; ex.eig_rel_tol = eig_rel_tol; ex.trace = trace_bytes ? dtr.as<int32_t>() : nullptr; ex.trace_iters = trace_bytes ? trace_iters : 0;
     if (ex.trace) FBX_HIP(hipMemsetAsync(ex.trace, 0, trace_bytes, stream()));
-    // Page-locked caller buffers and more than one stage of work: a three-stream pipeline -- H2D of stage k + 1 and D2H
-    // of stage k - 1 run under the kernel of stage k (SURVEY.md 8d prices the path including both transfers).  A stage
-    // is fbx_set_option("pgdb_host_chunk") items (default 4096: every SIMD keeps at least two reconstructions).
+    // Page-locked caller buffers and more than one stage of work: H2D, kernels and D2H overlap on separate streams (SURVEY.md
+    // 8d prices the path including both transfers).  What cannot be hidden is the H2D of the first stage and the D2H of the
+    // last, and every boundary between stages costs a launch tail (a stage's slowest items run while SIMDs idle): so the plan
+    // is a SMALL first stage (fbx_set_option("pgdb_host_chunk") items, default 2048 = one wavefront per slot of the chip; at
+    // most half the batch), a small last one, and everything in between in as few launches as the per-item workspace allows
+    // (65 536 items each) on a second, HIGH-PRIORITY compute stream: the first stage's kernel covers the upload of the rest,
+    // the bulk takes the SIMDs over as soon as it has arrived, and the last stage -- queued behind the first on the normal-
+    // priority stream -- only fills what the bulk's tail leaves idle and is still computing while the bulk's results go
+    // down.  (Round 3 first used equal stages: 8 boundaries for 65 536 items, 94-96 % of the resident rate.)
     const int64_t CH = option_pgdb_host_chunk();
     if (B > CH && host_pointer_is_pinned(expect) && host_pointer_is_pinned(counts) && host_pointer_is_pinned(choi_out)) {
         hipStream_t s_in, s_out, s_c2;
         if ((rc = copy_streams(&s_in, &s_out, &s_c2))) return rc;
-        const int nst = (int)((B + CH - 1) / CH);
+        struct Stage { int64_t b0, nb; bool second; int64_t ws_offset; };
+        std::vector<Stage> plan;
+        const int64_t MID = 65536;
+        const bool two_streams = design->dev.n <= 2;          // (the 3-qubit launcher has one workspace: one compute stream)
+        const int64_t first = CH < B / 2 ? CH : B / 2;
+        const int64_t last = (B - first > CH) ? CH : 0;
+        plan.push_back({0, first, false, 0});
+        for (int64_t b0 = first; b0 < B - last; b0 += MID)
+            plan.push_back({b0, (B - last - b0 < MID ? B - last - b0 : MID), two_streams, two_streams ? first : 0});
+        if (last) plan.push_back({B - last, last, false, 0});
+        const int64_t mid_slots = (B - last - first) < MID ? (B - last - first) : MID;
+        const int64_t ws_total = two_streams ? first + mid_slots : (first > mid_slots ? first : mid_slots);
+        const int nst = (int)plan.size();
         hipEvent_t* ev = nullptr;
         if ((rc = ordering_events(2 * nst + 1, &ev))) return rc;
         // (the staging buffers may still be in use by earlier work of this thread's stream)
@@ -892,24 +924,19 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
         FBX_HIP(hipStreamWaitEvent(s_in, ev[2 * nst], 0));
         FBX_HIP(hipStreamWaitEvent(s_out, ev[2 * nst], 0));
         FBX_HIP(hipStreamWaitEvent(s_c2, ev[2 * nst], 0));
-        auto h2d = [&](int k) -> int {
-            const int64_t b0 = (int64_t)k * CH, nb = B - b0 < CH ? B - b0 : CH;
+        for (int k = 0; k < nst; ++k) {                        // uploads in stage order, back to back
+            const int64_t b0 = plan[k].b0, nb = plan[k].nb;
             FBX_HIP(hipMemcpyAsync(de.as<double>() + b0 * m, expect + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
             FBX_HIP(hipMemcpyAsync(dc.as<double>() + b0 * m, counts + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
             FBX_HIP(hipEventRecord(ev[2 * k], s_in));
-            return FBX_OK;
-        };
-        if ((rc = h2d(0))) return rc;
+        }
         for (int k = 0; k < nst; ++k) {
-            const int64_t b0 = (int64_t)k * CH, nb = B - b0 < CH ? B - b0 : CH;
-            if (k + 1 < nst && (rc = h2d(k + 1))) break;
-            // even stages on the thread's stream, odd ones on a second compute stream, each with its own half of the
-            // per-item workspace: the tail of stage k (its slowest items) runs next to the head of stage k + 1
-            hipStream_t s_k = (k & 1) ? s_c2 : stream();
+            const int64_t b0 = plan[k].b0, nb = plan[k].nb;
+            hipStream_t s_k = plan[k].second ? s_c2 : stream();
             FBX_HIP(hipStreamWaitEvent(s_k, ev[2 * k], 0));
             PgdbExtras exk = ex;
             if (exk.trace) exk.trace += (size_t)b0 * exk.trace_iters * 2;
-            exk.launch_stream = s_k; exk.ws_items = CH; exk.ws_offset = (k & 1) ? CH : 0;
+            exk.launch_stream = s_k; exk.ws_items = ws_total; exk.ws_offset = plan[k].ws_offset;
             rc = pgdb_dispatch(design, nb, de.as<double>() + b0 * m, dc.as<double>() + b0 * m, trace_preserving, mode, max_iters,
                                dchoi.as<double>() + b0 * 2 * D * D, dit.as<int32_t>() + b0, ddy.as<int32_t>() + b0,
                                dbt.as<int32_t>() + b0, dcost.as<double>() + b0, dsw.as<int32_t>() + 4 * b0, exk);

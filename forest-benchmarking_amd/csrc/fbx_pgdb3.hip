@@ -787,7 +787,7 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(3);
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, stream(), dev, (long long)nb,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(1024), lds, ex.launch_stream ? ex.launch_stream : stream(), dev, (long long)nb,
                            e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * DD * 2, it ? it + b0 : nullptr,
                            dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, scratch,
                            FBX_PHASE_OUT3(b0), sw ? sw + 4 * b0 : nullptr, basis, BASIS_CAP,

@@ -98,7 +98,13 @@ int copy_streams(hipStream_t* in, hipStream_t* out, hipStream_t* compute2) {
     if (!c) { set_error("libfbx: no device context"); return FBX_ERR_HIP; }
     if (!c->copy_in) FBX_HIP(hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
     if (!c->copy_out) FBX_HIP(hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
-    if (!c->compute2) FBX_HIP(hipStreamCreateWithFlags(&c->compute2, hipStreamNonBlocking));
+    if (!c->compute2) {
+        // the second compute stream carries the BULK of a pipelined batch: highest priority, so that its workgroups are placed
+        // before those of the small first / last stages on the thread's own stream, which then only fill what it leaves idle
+        int lo = 0, hi = 0;
+        FBX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        FBX_HIP(hipStreamCreateWithPriority(&c->compute2, hipStreamNonBlocking, hi));
+    }
     *in = c->copy_in; *out = c->copy_out; *compute2 = c->compute2;
     return FBX_OK;
 }
@@ -191,7 +197,7 @@ namespace {
 std::atomic<double> g_eig_rel_tol2{FBX_JTOL_REL};     // 1- and 2-qubit PGDB (fbx_pgdb.hip)
 std::atomic<double> g_eig_rel_tol3{FBX3_JTOL_REL};     // 3-qubit PGDB (fbx_pgdb3.hip)
 std::atomic<int> g_eigh_coop{1};                      // large eigendecompositions may use a cooperative launch
-std::atomic<long long> g_host_chunk{8192};            // items per stage of the pipelined host-pointer PGDB entry point
+std::atomic<long long> g_host_chunk{2048};            // items of the first / last stage of the pipelined host-pointer PGDB entry point
 }
 long long option_pgdb_host_chunk() { return g_host_chunk.load(); }
 double option_pgdb_eig_rel_tol(int n_qubits) { return n_qubits >= 3 ? g_eig_rel_tol3.load() : g_eig_rel_tol2.load(); }

@@ -290,3 +290,38 @@ def test_pipelined_host_entry_point_equals_the_staged_one(gpu):
         tomography.pgdb_process_estimate_batch(design, pe, pc, out=np.empty((700, 16, 16), dtype=np.complex64))
     with pytest.raises(ValueError):
         gpu.set_option("pgdb_host_chunk", 3)
+
+
+def test_pipelined_host_entry_point_across_kernels(gpu):
+    """The stage plan of the pipelined call (small first stage, bulk on the high-priority stream, small last stage) where the
+    stages take DIFFERENT kernels and share the per-item workspace: 2 qubits (one-wave kernel for the edges, two-waves-per-SIMD
+    kernel for the bulk), 1 qubit on the lane-per-item kernel (one item counter per stream), 3 qubits (one compute stream)."""
+    from fbx import synthetic, tomography
+    old = gpu.get_option("pgdb_host_chunk")
+    try:
+        gpu.set_option("pgdb_host_chunk", 300)
+        # ---- 2 qubits: 300 | 2100 | 300
+        design, _, e0, c0 = synthetic.process_batch(2, "sic", 300)
+        e, c = np.tile(e0, (9, 1)), np.tile(c0, (9, 1))
+        edge, est = tomography.pgdb_process_estimate_batch(design, e0, c0, return_stats=True)
+        bulk, bst = tomography.pgdb_process_estimate_batch(design, e[300:2400], c[300:2400], return_stats=True)
+        out = gpu.pinned_empty((2700, 16, 16), np.complex128)
+        got, st = tomography.pgdb_process_estimate_batch(design, gpu.pinned_copy(e), gpu.pinned_copy(c), return_stats=True, out=out)
+        assert np.array_equal(got[:300], edge) and np.array_equal(got[2400:], edge) and np.array_equal(got[300:2400], bulk)
+        assert np.array_equal(st["dykstra"], np.concatenate([est["dykstra"], bst["dykstra"], est["dykstra"]]))
+        # ---- 1 qubit, lane-per-item kernel in every stage
+        design, _, e, c = synthetic.process_batch(1, "pauli", 1000)
+        with gpu.option("pgdb_packed_1q", 2.0):
+            want = tomography.pgdb_process_estimate_batch(design, e, c)
+            got = tomography.pgdb_process_estimate_batch(design, gpu.pinned_copy(e), gpu.pinned_copy(c),
+                                                         out=gpu.pinned_empty((1000, 4, 4), np.complex128))
+        assert np.array_equal(got, want)
+        # ---- 3 qubits: 150 | 150 on one compute stream
+        design, _, e0, c0 = synthetic.process_batch(3, "sic", 3)
+        e, c = np.tile(e0, (100, 1)), np.tile(c0, (100, 1))
+        want = tomography.pgdb_process_estimate_batch(design, e0, c0, mode="fixed", max_iters=2)
+        got = tomography.pgdb_process_estimate_batch(design, gpu.pinned_copy(e), gpu.pinned_copy(c), mode="fixed", max_iters=2,
+                                                     out=gpu.pinned_empty((300, 64, 64), np.complex128))
+        assert np.array_equal(got.reshape(100, 3, 64, 64), np.broadcast_to(want, (100, 3, 64, 64)))
+    finally:
+        gpu.set_option("pgdb_host_chunk", old)
