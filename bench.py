@@ -586,7 +586,7 @@ def _pipeline_stages(n, chunk):
     if n <= chunk:
         return 1
     first = min(chunk, n // 2)
-    last = chunk if n - first > chunk else 0
+    last = chunk if n >= 4 * chunk else 0
     return 1 + -(-(n - first - last) // 65536) + (1 if last else 0)
 
 

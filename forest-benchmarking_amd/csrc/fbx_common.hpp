@@ -49,6 +49,8 @@ struct PgdbExtras {
     // the per-item workspace: `ws_items` slots in all, this stage's start at `ws_offset` (stages on different streams get disjoint ranges)
     hipStream_t launch_stream = nullptr;
     int64_t ws_items = 0, ws_offset = 0;
+    int64_t total_batch = 0;       // size of the caller's whole batch when this launch is one stage of it: kernels are chosen by IT,
+                                   // so that a result never depends on how a batch was cut into stages
 };
 
 // Named grow-only device workspaces of the calling thread (kept between calls; released by

@@ -702,7 +702,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
                        int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
                        double* cost, int32_t* sw, const PgdbExtras& ex) {
     // batches that put several reconstructions on a SIMD take the lean two-waves-per-SIMD kernel (2 qubits)
-    const bool lean = NQ == 2 && B >= FBX_LEAN_MIN_BATCH;
+    const bool lean = NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH;
     size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
     if constexpr (NQ == 2) { if (lean) lds = PgdbLds<NQ, true>::bytes(des->dev.S, 64 * MAXJ); }
     if (lds > 160 * 1024) {
@@ -780,7 +780,7 @@ static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, cons
         // scripts/pgdb1_time.py); fbx_set_option("pgdb_packed_1q", 0 | 2) forces one or the other.
         {
             const int packed = option_pgdb_packed_1q();
-            if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && B >= FBX_PACKED_1Q_MIN_BATCH)))
+            if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_PACKED_1Q_MIN_BATCH)))
                 return pgdb1_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         }
         if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
@@ -909,7 +909,7 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
         const int64_t MID = 65536;
         const bool two_streams = design->dev.n <= 2;          // (the 3-qubit launcher has one workspace: one compute stream)
         const int64_t first = CH < B / 2 ? CH : B / 2;
-        const int64_t last = (B - first > CH) ? CH : 0;
+        const int64_t last = (B >= 4 * CH) ? CH : 0;           // queued BEHIND the first stage: only when the bulk outlasts both
         plan.push_back({0, first, false, 0});
         for (int64_t b0 = first; b0 < B - last; b0 += MID)
             plan.push_back({b0, (B - last - b0 < MID ? B - last - b0 : MID), two_streams, two_streams ? first : 0});
@@ -936,7 +936,7 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
             FBX_HIP(hipStreamWaitEvent(s_k, ev[2 * k], 0));
             PgdbExtras exk = ex;
             if (exk.trace) exk.trace += (size_t)b0 * exk.trace_iters * 2;
-            exk.launch_stream = s_k; exk.ws_items = ws_total; exk.ws_offset = plan[k].ws_offset;
+            exk.launch_stream = s_k; exk.ws_items = ws_total; exk.ws_offset = plan[k].ws_offset; exk.total_batch = B;
             rc = pgdb_dispatch(design, nb, de.as<double>() + b0 * m, dc.as<double>() + b0 * m, trace_preserving, mode, max_iters,
                                dchoi.as<double>() + b0 * 2 * D * D, dit.as<int32_t>() + b0, ddy.as<int32_t>() + b0,
                                dbt.as<int32_t>() + b0, dcost.as<double>() + b0, dsw.as<int32_t>() + 4 * b0, exk);
