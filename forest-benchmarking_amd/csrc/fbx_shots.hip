@@ -94,6 +94,62 @@ __device__ long long count_minus_generic(const uint8_t* __restrict__ bits, long 
     return cnt;
 }
 
+// Short records whose size is a multiple of 16 bytes (the usual 1000 shots x 2 qubits = 125 vectors): a wavefront per
+// setting with the NEXT setting's record requested before the current one is reduced.  A wavefront that loads, waits,
+// reduces and stores one 2 KB record at a time keeps 2 KB in flight; 32 wavefronts per CU then hold 16 MB on the chip --
+// just the 8 TB/s x 2 us the memory system needs -- and every reduction / store phase is a bubble (2.4-2.9 TB/s).
+// VPL = vectors per lane (record <= 1 / 2 / 4 / 8 KB).
+template <int NQB, int VPL>
+__device__ __forceinline__ void shots_wave_pipeline(long long first, long long stride, long long n_settings, long long n_shots,
+                                                    const uint8_t* __restrict__ bits, const uint8_t* __restrict__ obs_mask,
+                                                    const double* __restrict__ coefs, int beta_prior,
+                                                    double* __restrict__ mean_out, double* __restrict__ var_out, int lane) {
+    const long long nvec = n_shots * NQB / 16;
+    auto fetch = [&](long long s, ulonglong2 (&buf)[VPL], unsigned long long& pat) __attribute__((always_inline)) {
+        const ulonglong2* v = reinterpret_cast<const ulonglong2*>(bits + s * n_shots * NQB);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const long long i = lane + 64 * k;
+            buf[k] = i < nvec ? v[i] : ulonglong2{0ull, 0ull};
+        }
+        const uint8_t* mk = obs_mask + s * NQB;
+        pat = 0;
+#pragma unroll
+        for (int byte = 0; byte < 8; ++byte) pat |= (unsigned long long)(mk[byte % NQB] ? 1 : 0) << (8 * byte);
+    };
+    ulonglong2 cur[VPL], nxt[VPL];
+    unsigned long long pat = 0, pat_n = 0;
+    long long s = first;
+    if (s < n_settings) fetch(s, cur, pat);
+    while (s < n_settings) {
+        const long long sn = s + stride;
+        if (sn < n_settings) fetch(sn, nxt, pat_n);
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) cnt += odd_shots<NQB>(cur[k].x & pat) + odd_shots<NQB>(cur[k].y & pat);
+        const long long n_minus = (long long)wave_sum((double)cnt);
+        if (lane == 0) {
+            const long long n_plus = n_shots - n_minus;
+            const double coef = coefs ? coefs[s] : 1.0;
+            double mean, var;
+            if (pat == 0) { mean = coef; var = 0.0; }
+            else if (beta_prior) {
+                const double a = (double)n_plus + 1.0, bb = (double)n_minus + 1.0;
+                const double bm = a / (a + bb), bv = a * bb / ((a + bb) * (a + bb) * (a + bb + 1.0));
+                mean = coef * (2.0 * bm - 1.0); var = coef * coef * 4.0 * bv;
+            } else {
+                const double m = ((double)n_plus - (double)n_minus) / (double)n_shots;
+                mean = coef * m;
+                var = coef * coef * (1.0 - m * m) / (double)n_shots;
+            }
+            mean_out[s] = mean; var_out[s] = var;
+        }
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) cur[k] = nxt[k];
+        pat = pat_n; s = sn;
+    }
+}
+
 template <bool PER_WAVE>
 __global__ void __launch_bounds__(256)
 shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __restrict__ bits,
@@ -103,6 +159,19 @@ shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __re
     const int tid = PER_WAVE ? (threadIdx.x & 63) : threadIdx.x, nth = PER_WAVE ? 64 : 256;
     const long long first = PER_WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
     const long long stride = PER_WAVE ? (long long)gridDim.x * 4 : gridDim.x;
+    if constexpr (PER_WAVE) {
+        // records that are whole 16-byte vectors, at most eight per lane, from a 16-byte aligned base: the pipelined form
+        const long long bytes = n_shots * n;
+        if ((n == 1 || n == 2 || n == 4 || n == 8) && (bytes & 15) == 0 && bytes <= 8192 && ((uintptr_t)bits & 15) == 0) {
+            const int vpl = (int)((bytes / 16 + 63) / 64);
+#define FBX_SHOTS_PIPE(NQB, VPL) shots_wave_pipeline<NQB, VPL>(first, stride, n_settings, n_shots, bits, obs_mask, coefs, beta_prior, mean_out, var_out, tid)
+#define FBX_SHOTS_PIPE_N(NQB) do { if (vpl <= 1) FBX_SHOTS_PIPE(NQB, 1); else if (vpl == 2) FBX_SHOTS_PIPE(NQB, 2); else if (vpl <= 4) FBX_SHOTS_PIPE(NQB, 4); else FBX_SHOTS_PIPE(NQB, 8); } while (0)
+            if (n == 1) FBX_SHOTS_PIPE_N(1); else if (n == 2) FBX_SHOTS_PIPE_N(2); else if (n == 4) FBX_SHOTS_PIPE_N(4); else FBX_SHOTS_PIPE_N(8);
+#undef FBX_SHOTS_PIPE_N
+#undef FBX_SHOTS_PIPE
+            return;
+        }
+    }
     for (long long s = first; s < n_settings; s += stride) {
         const uint8_t* mk = obs_mask + s * n;
         const uint8_t* b = bits + s * n_shots * n;
