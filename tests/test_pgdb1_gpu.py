@@ -154,3 +154,30 @@ def test_reference_signature_single_experiment(gpu):
                                 std_err=0.0) for k, s in enumerate(settings)]
     got = tomography.pgdb_process_estimate(results, [0])
     assert np.abs(got - z["pgdb"][0]).max() < 1e-9
+
+
+def test_non_standard_designs(gpu):
+    """Signed observable coefficients, settings in another order with one input state dropped and two settings repeated, and a
+    design with more than 64 settings (which the lane-per-item kernel hands to the wavefront-per-item one)."""
+    from fbx import synthetic, tomography
+    from fbx.design import Design
+    full, us, e, c = synthetic.process_batch(1, "pauli", 40)
+    rs = np.random.RandomState(7)
+    keep = np.concatenate([rs.permutation(np.arange(15)), [3, 11]])            # states 0..4 only, two settings twice
+    coefs = np.where(rs.rand(len(keep)) < 0.5, -1.0, 1.0)
+    d = Design(1, "process", full.in_labels[keep], full.paulis[keep], coefs)
+    ek, ck = e[:, keep] * coefs, c[:, keep]
+    got, st = tomography.pgdb_process_estimate_batch(d, ek, ck, return_stats=True)
+    want, wst = _oracle(d, ek[:8], ck[:8])
+    assert np.abs(got[:8] - want).max() < 1e-9
+    for b in range(8):
+        assert (st["iterations"][b], st["dykstra"][b]) == (wst[b]["iterations"], wst[b]["dykstra"])
+    with _packed(False):
+        other, ost = tomography.pgdb_process_estimate_batch(d, ek, ck, return_stats=True, eig_rel_tol=0.0)
+    assert np.array_equal(st["iterations"], ost["iterations"]) and np.abs(got - other).max() < 1e-8
+    # 72 settings: every Pauli-basis setting four times
+    rep = np.tile(np.arange(18), 4)
+    d72 = Design(1, "process", full.in_labels[rep], full.paulis[rep])
+    got72 = tomography.pgdb_process_estimate_batch(d72, e[:6, rep], c[:6, rep])
+    want72, _ = _oracle(d72, e[:6, rep], c[:6, rep])
+    assert np.abs(got72 - want72).max() < 1e-9
