@@ -150,6 +150,15 @@ __device__ __forceinline__ void shots_wave_pipeline(long long first, long long s
     }
 }
 
+// one instantiation per record size class, so that the short records keep few registers and many wavefronts in flight
+template <int NQB, int VPL>
+__global__ void __launch_bounds__(256)
+shots_pipe_kernel(long long n_settings, long long n_shots, const uint8_t* __restrict__ bits, const uint8_t* __restrict__ obs_mask,
+                  const double* __restrict__ coefs, int beta_prior, double* __restrict__ mean_out, double* __restrict__ var_out) {
+    shots_wave_pipeline<NQB, VPL>((long long)blockIdx.x * 4 + (threadIdx.x >> 6), (long long)gridDim.x * 4, n_settings, n_shots, bits,
+                                  obs_mask, coefs, beta_prior, mean_out, var_out, threadIdx.x & 63);
+}
+
 template <bool PER_WAVE>
 __global__ void __launch_bounds__(256)
 shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __restrict__ bits,
@@ -159,19 +168,6 @@ shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __re
     const int tid = PER_WAVE ? (threadIdx.x & 63) : threadIdx.x, nth = PER_WAVE ? 64 : 256;
     const long long first = PER_WAVE ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
     const long long stride = PER_WAVE ? (long long)gridDim.x * 4 : gridDim.x;
-    if constexpr (PER_WAVE) {
-        // records that are whole 16-byte vectors, at most eight per lane, from a 16-byte aligned base: the pipelined form
-        const long long bytes = n_shots * n;
-        if ((n == 1 || n == 2 || n == 4 || n == 8) && (bytes & 15) == 0 && bytes <= 8192 && ((uintptr_t)bits & 15) == 0) {
-            const int vpl = (int)((bytes / 16 + 63) / 64);
-#define FBX_SHOTS_PIPE(NQB, VPL) shots_wave_pipeline<NQB, VPL>(first, stride, n_settings, n_shots, bits, obs_mask, coefs, beta_prior, mean_out, var_out, tid)
-#define FBX_SHOTS_PIPE_N(NQB) do { if (vpl <= 1) FBX_SHOTS_PIPE(NQB, 1); else if (vpl == 2) FBX_SHOTS_PIPE(NQB, 2); else if (vpl <= 4) FBX_SHOTS_PIPE(NQB, 4); else FBX_SHOTS_PIPE(NQB, 8); } while (0)
-            if (n == 1) FBX_SHOTS_PIPE_N(1); else if (n == 2) FBX_SHOTS_PIPE_N(2); else if (n == 4) FBX_SHOTS_PIPE_N(4); else FBX_SHOTS_PIPE_N(8);
-#undef FBX_SHOTS_PIPE_N
-#undef FBX_SHOTS_PIPE
-            return;
-        }
-    }
     for (long long s = first; s < n_settings; s += stride) {
         const uint8_t* mk = obs_mask + s * n;
         const uint8_t* b = bits + s * n_shots * n;
@@ -411,7 +407,21 @@ int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, 
     const bool per_wave = n_shots * n_qubits < 16384 && n_settings >= 4;
     const int64_t units = per_wave ? (n_settings + 3) / 4 : n_settings;
     const unsigned grid = (unsigned)(units < 256 * 16 ? units : 256 * 16);
-    if (per_wave)
+    // records that are whole 16-byte vectors, at most eight per lane, from a 16-byte aligned base: the pipelined form
+    const long long bytes = (long long)n_shots * n_qubits;
+    const bool pipe = per_wave && (n_qubits == 1 || n_qubits == 2 || n_qubits == 4 || n_qubits == 8) && (bytes & 15) == 0 &&
+                      bytes <= 8192 && (((uintptr_t)d_bits) & 15) == 0;
+    if (pipe) {
+        const int vpl = (int)((bytes / 16 + 63) / 64);
+#define FBX_SHOTS_LAUNCH(NQB, VPL) hipLaunchKernelGGL((shots_pipe_kernel<NQB, VPL>), dim3(grid), dim3(256), 0, stream(), (long long)n_settings, \
+                                                      (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out)
+#define FBX_SHOTS_LAUNCH_N(NQB) do { if (vpl <= 1) FBX_SHOTS_LAUNCH(NQB, 1); else if (vpl == 2) FBX_SHOTS_LAUNCH(NQB, 2); \
+                                     else if (vpl <= 4) FBX_SHOTS_LAUNCH(NQB, 4); else FBX_SHOTS_LAUNCH(NQB, 8); } while (0)
+        if (n_qubits == 1) FBX_SHOTS_LAUNCH_N(1); else if (n_qubits == 2) FBX_SHOTS_LAUNCH_N(2);
+        else if (n_qubits == 4) FBX_SHOTS_LAUNCH_N(4); else FBX_SHOTS_LAUNCH_N(8);
+#undef FBX_SHOTS_LAUNCH_N
+#undef FBX_SHOTS_LAUNCH
+    } else if (per_wave)
         hipLaunchKernelGGL(shots_kernel<true>, dim3(grid), dim3(256), 0, stream(), n_qubits, (long long)n_settings,
                            (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out);
     else
