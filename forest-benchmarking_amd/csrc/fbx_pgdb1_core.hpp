@@ -305,40 +305,31 @@ FBX_P1 Corr2 p1_tp_correction(const H4& x, bool trace_preserving) {
 // ---- Dykstra (project_superoperators.py:87-144), carried with two matrices: u = pre_CP and p = old_CP_change;
 // old_TP_change is the 2 x 2 correction of the last TP / TNI projection, last_CP_projection only enters through the
 // scalar <old_CP_change, last_CP_projection>, last_state = u + p (the form of proj_physical_blk_compact, fbx_choi.hpp)
-struct P1Dykstra { H4 u, p, state; Corr2 qold; double c0; };
-FBX_P1 void p1_dykstra_begin(const H4& x, P1Dykstra& d) {
-    d.u = x; d.p = h4_zero(); d.state = x;
-    d.qold.c00 = d.qold.c11 = d.qold.c01r = d.qold.c01i = 0.0;
-    d.c0 = 0.0;
-}
-// one iteration; returns true when the stopping rule fires (d.state is then the projection)
-FBX_P1 bool p1_dykstra_step(P1Dykstra& d, bool trace_preserving, int& iters, int& sweeps, int& terms, P1Basis& basis) {
-    ++iters;
-    const H4 cp = p1_proj_cp(d.u, sweeps, terms, basis);
-    const H4 new_cp = h4_sub(cp, d.u);
-    const double s1 = h4_norm2(h4_sub(new_cp, d.p));
-    const double pc = h4_dot(d.p, cp), nc = h4_dot(new_cp, cp);
-    const H4 last_state = h4_add(d.u, d.p);
-    const H4 old_tp = p1_tp_change(d.qold);
-    const H4 pre_tp = h4_sub(cp, old_tp);
-    const Corr2 q = p1_tp_correction(pre_tp, trace_preserving);
-    const H4 new_tp = p1_tp_change(q);
-    d.state = h4_add(pre_tp, new_tp);
-    const double s2 = h4_norm2(h4_sub(new_tp, old_tp));
-    const double i1 = h4_dot(old_tp, h4_sub(d.state, last_state));
-    const double i2 = pc - d.c0;
-    const double crit = s1 + s2 + 2.0 * fabs(i1) + 2.0 * fabs(i2);
-    if (!(crit >= 1e-4)) return true;                  // converged -- or not finite: never spin
-    d.c0 = nc; d.p = new_cp; d.qold = q;
-    d.u = h4_sub(d.state, new_cp);
-    return false;
-}
 FBX_P1 H4 p1_proj_physical(const H4& x, bool trace_preserving, int& iters, int& sweeps, int& terms, P1Basis& basis) {
-    P1Dykstra d;
-    p1_dykstra_begin(x, d);
-    for (int it = 0; it < P1_MAX_DYKSTRA; ++it)
-        if (p1_dykstra_step(d, trace_preserving, iters, sweeps, terms, basis)) break;
-    return d.state;
+    H4 u = x, p = h4_zero(), new_state = x;
+    Corr2 qold; qold.c00 = qold.c11 = qold.c01r = qold.c01i = 0.0;
+    double c0 = 0.0;
+    for (int it = 0; it < P1_MAX_DYKSTRA; ++it) {
+        ++iters;
+        const H4 cp = p1_proj_cp(u, sweeps, terms, basis);
+        const H4 new_cp = h4_sub(cp, u);
+        const double s1 = h4_norm2(h4_sub(new_cp, p));
+        const double pc = h4_dot(p, cp), nc = h4_dot(new_cp, cp);
+        const H4 last_state = h4_add(u, p);
+        const H4 old_tp = p1_tp_change(qold);
+        const H4 pre_tp = h4_sub(cp, old_tp);
+        const Corr2 q = p1_tp_correction(pre_tp, trace_preserving);
+        const H4 new_tp = p1_tp_change(q);
+        new_state = h4_add(pre_tp, new_tp);
+        const double s2 = h4_norm2(h4_sub(new_tp, old_tp));
+        const double i1 = h4_dot(old_tp, h4_sub(new_state, last_state));
+        const double i2 = pc - c0;
+        const double crit = s1 + s2 + 2.0 * fabs(i1) + 2.0 * fabs(i2);
+        if (!(crit >= 1e-4)) break;                   // converged -- or not finite: never spin
+        c0 = nc; p = new_cp; qold = q;
+        u = h4_sub(new_state, new_cp);
+    }
+    return new_state;
 }
 
 // ---- Choi <-> Pauli-Liouville coefficients, R_ij = (1/d) tr[(P_j^T (x) P_i) E]: radix-2 butterflies over the two tensor
@@ -561,24 +552,17 @@ FBX_P1 void p1_begin(const Des& des, const NT& nt, P1State& st) {
     st.new_cost = st.old_cost;
     st.ls_full = 1; st.ls_sums = 0;
 }
-// One outer iteration (tomography.py:570-592) in three phases, so that a driver may run them nested (p1_outer_iteration: the host
-// harness, small batches) or phase-synchronously over the lanes of a wavefront (fbx_pgdb1.hip):
-//   p1_iter_start   gradient, the point to project, Dykstra's starting state
-//   p1_dykstra_step one iteration of the projection (above), until it returns true
-//   p1_iter_finish  update direction, backtracking line search, the new estimate; returns true when the reconstruction is done
+// One outer iteration (tomography.py:570-592).  Returns true when the reconstruction is finished.
 template <class Des, class NT>
-FBX_P1 void p1_iter_start(const Des& des, const NT& nt, const P1State& st, H4& grad, P1Dykstra& d) {
+FBX_P1 bool p1_outer_iteration(const Des& des, const NT& nt, P1State& st, bool trace_preserving, int mode, int max_iters,
+                               int& dyk_this, int& bt_this) {
+    if (mode == 1 /* FBX_MODE_FIXED */ && st.iters >= max_iters) { dyk_this = 0; bt_this = 0; return true; }
+    const int dyk_before = st.dyk, bt_before = st.backtracks;
     double Re[16];
     p1_choi_to_pauli(st.est, Re);
-    grad = p1_gradient(des, nt, Re);
-    p1_dykstra_begin(h4_axpy(st.est, -(8.0 / 3.0), grad), d);       // est - gradient / mu, mu = 3 / (2 d^2)
-}
-template <class Des, class NT>
-FBX_P1 bool p1_iter_finish(const Des& des, const NT& nt, P1State& st, const H4& grad, const H4& proj, int mode, int max_iters,
-                           int& bt_this) {
-    const int bt_before = st.backtracks;
-    double Re[16];
-    p1_choi_to_pauli(st.est, Re);
+    const H4 grad = p1_gradient(des, nt, Re);
+    const H4 x = h4_axpy(st.est, -(8.0 / 3.0), grad);          // est - gradient / mu, mu = 3 / (2 d^2)
+    const H4 proj = p1_proj_physical(x, trace_preserving, st.dyk, st.sweeps, st.terms, st.basis);
     const H4 upd = h4_sub(proj, st.est);
     const double ipr = h4_dot(upd, grad);
     double Ru[16];
@@ -618,7 +602,7 @@ FBX_P1 bool p1_iter_finish(const Des& des, const NT& nt, P1State& st, const H4& 
     st.est = h4_axpy(st.est, alpha, upd);                     // tomography.py:588
     st.new_cost = new_cost;
     ++st.iters;
-    bt_this = st.backtracks - bt_before;
+    dyk_this = st.dyk - dyk_before; bt_this = st.backtracks - bt_before;
     bool done = false;
     if (mode == 0 /* FBX_MODE_CONVERGE */) {
         if (!(st.old_cost - new_cost >= P1_STOP)) done = true;        // tomography.py:589; a NaN cost also ends the loop
@@ -626,20 +610,6 @@ FBX_P1 bool p1_iter_finish(const Des& des, const NT& nt, P1State& st, const H4& 
     } else if (st.iters >= max_iters) done = true;
     st.old_cost = new_cost;
     return done;
-}
-// the nested form.  Returns true when the reconstruction is finished.
-template <class Des, class NT>
-FBX_P1 bool p1_outer_iteration(const Des& des, const NT& nt, P1State& st, bool trace_preserving, int mode, int max_iters,
-                               int& dyk_this, int& bt_this) {
-    if (mode == 1 /* FBX_MODE_FIXED */ && st.iters >= max_iters) { dyk_this = 0; bt_this = 0; return true; }
-    const int dyk_before = st.dyk;
-    H4 grad;
-    P1Dykstra d;
-    p1_iter_start(des, nt, st, grad, d);
-    for (int it = 0; it < P1_MAX_DYKSTRA; ++it)
-        if (p1_dykstra_step(d, trace_preserving, st.dyk, st.sweeps, st.terms, st.basis)) break;
-    dyk_this = st.dyk - dyk_before;
-    return p1_iter_finish(des, nt, st, grad, d.state, mode, max_iters, bt_this);
 }
 
 }  // namespace fbx
