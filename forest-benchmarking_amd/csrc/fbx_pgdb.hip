@@ -946,7 +946,14 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
             FBX_HIP(hipMemcpyAsync(choi_out + b0 * 2 * D * D, dchoi.as<double>() + b0 * 2 * D * D, sizeof(double) * 2 * nb * D * D,
                                    hipMemcpyDeviceToHost, s_out));
         }
-        if (rc) { (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(stream()); (void)hipStreamSynchronize(s_c2); (void)hipStreamSynchronize(s_out); return rc; }
+        if (rc) {
+            (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(stream()); (void)hipStreamSynchronize(s_c2); (void)hipStreamSynchronize(s_out);
+            // the pipeline wants workspace slots for the whole bulk at once; when the device cannot give that much the staged path
+            // below runs the batch in launches that fit (it halves them until the store does)
+            if (rc != FBX_ERR_NOMEM) return rc;
+            (void)hipGetLastError();
+            goto staged;
+        }
         FBX_HIP(hipEventRecord(ev[2 * nst], s_c2));            // the small outputs below follow BOTH compute streams
         FBX_HIP(hipStreamWaitEvent(stream(), ev[2 * nst], 0));
         if (iters_out) FBX_HIP(hipMemcpyAsync(iters_out, dit.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
@@ -960,6 +967,7 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
         FBX_HIP(hipStreamSynchronize(s_in));
         return FBX_OK;
     }
+staged:
     FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
     FBX_HIP(hipMemcpyAsync(dc.p, counts, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));
     rc = pgdb_dispatch(design, B, de.as<double>(), dc.as<double>(), trace_preserving, mode, max_iters,
