@@ -316,17 +316,18 @@ __device__ __forceinline__ void pauli_masks(int idx, int& x, int& z, int& ny) {
         x |= xb << t; z |= zb << t; ny += (code == 2);
     }
 }
-// inverse: masks -> Pauli index
+// inverse: masks -> Pauli index.  Digit t is (I, X, Y, Z) = (0, 1, 2, 3) for (x_t, z_t) = (0,0), (1,0), (1,1), (0,1): its high bit is
+// z_t and its low bit x_t ^ z_t, so the index is the bit-interleave of z and x ^ z (two Morton spreads instead of a loop over the qubits)
+__device__ __forceinline__ int spread_bits8(int v) {      // bit t -> bit 2 t, t < 8
+    v = (v | (v << 4)) & 0x0F0F;
+    v = (v | (v << 2)) & 0x3333;
+    v = (v | (v << 1)) & 0x5555;
+    return v;
+}
 template <int NQ>
 __device__ __forceinline__ int pauli_index(int x, int z) {
-    int idx = 0;
-#pragma unroll
-    for (int t = 0; t < NQ; ++t) {
-        int xb = (x >> t) & 1, zb = (z >> t) & 1;
-        int code = xb ? (zb ? 2 : 1) : (zb ? 3 : 0);
-        idx |= code << (2 * t);
-    }
-    return idx;
+    static_assert(NQ <= 8, "spread_bits8");
+    return (spread_bits8(z) << 1) | spread_bits8(x ^ z);
 }
 #endif
 
