@@ -159,6 +159,90 @@ shots_pipe_kernel(long long n_settings, long long n_shots, const uint8_t* __rest
                                   obs_mask, coefs, beta_prior, mean_out, var_out, threadIdx.x & 63);
 }
 
+// The same pipeline for the packed qubit counts 3 and 5 (6 and 7 measured no faster than shots_kernel: 110-180 registers): a lane's unit is a run of 16 shots = 2 NQ words; records of at
+// most RPL x 64 runs (RPL = runs per lane) plus a byte-wise tail of n_shots % 16 shots, 8-byte aligned.  Own kernels, like
+// shots_pipe_kernel: inside shots_kernel the two register buffers cost every path its occupancy.
+template <int NQ, int RPL>
+__global__ void __launch_bounds__(256)
+shots_pipe_packed_kernel(long long n_settings, long long n_shots, const uint8_t* __restrict__ bits, const uint8_t* __restrict__ obs_mask,
+                         const double* __restrict__ coefs, int beta_prior, double* __restrict__ mean_out, double* __restrict__ var_out) {
+    constexpr int W = 2 * NQ;
+    const int lane = threadIdx.x & 63;
+    const long long first = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), stride = (long long)gridDim.x * 4;
+    const long long runs = n_shots / 16, tail0 = runs * 16;
+    unsigned long long cur[RPL][W], nxt[RPL][W];
+    int tail_c = 0, tail_n = 0;
+    auto fetch = [&](long long s, unsigned long long (&x)[RPL][W], int& tail) __attribute__((always_inline)) {
+        const uint8_t* b = bits + s * n_shots * NQ;
+        const unsigned long long* v = reinterpret_cast<const unsigned long long*>(b);
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            const long long run = lane + 64 * k;
+#pragma unroll
+            for (int w = 0; w < W; ++w) x[k][w] = run < runs ? v[run * W + w] : 0ull;
+        }
+        tail = 0;                                              // the last n_shots % 16 shots: one per lane, masked later
+        const long long sh = tail0 + lane;
+        if (sh < n_shots) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tail |= (int)(b[sh * NQ + q] & 1) << q;
+        }
+    };
+    long long s = first;
+    if (s < n_settings) fetch(s, cur, tail_c);
+    while (s < n_settings) {
+        const long long sn = s + stride;
+        if (sn < n_settings) fetch(sn, nxt, tail_n);
+        const uint8_t* mk = obs_mask + s * NQ;
+        unsigned long long pat[W];
+        int mbits = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mbits |= (mk[q] ? 1 : 0) << q;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            unsigned long long m = 0;
+#pragma unroll
+            for (int byte = 0; byte < 8; ++byte) m |= (unsigned long long)((mbits >> ((8 * w + byte) % NQ)) & 1) << (8 * byte);
+            pat[w] = m;
+        }
+        int cnt = __popc(tail_c & mbits) & 1;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {                      // shot j of the run: bytes [j NQ, j NQ + NQ)
+                constexpr unsigned long long ALL = ~0ull;
+                const int lo = j * NQ, hi = lo + NQ - 1, w0 = lo >> 3, w1 = hi >> 3;
+                int pop;
+                if (w0 == w1) pop = __popcll(cur[k][w0] & pat[w0] & (ALL >> (8 * (7 - (hi & 7)))) & (ALL << (8 * (lo & 7))));
+                else pop = __popcll(cur[k][w0] & pat[w0] & (ALL << (8 * (lo & 7)))) + __popcll(cur[k][w1] & pat[w1] & (ALL >> (8 * (7 - (hi & 7)))));
+                cnt += pop & 1;
+            }
+        }
+        const long long n_minus = (long long)wave_sum((double)cnt);
+        if (lane == 0) {
+            const long long n_plus = n_shots - n_minus;
+            const double coef = coefs ? coefs[s] : 1.0;
+            double mean, var;
+            if (mbits == 0) { mean = coef; var = 0.0; }
+            else if (beta_prior) {
+                const double a = (double)n_plus + 1.0, bb = (double)n_minus + 1.0;
+                const double bm = a / (a + bb), bv = a * bb / ((a + bb) * (a + bb) * (a + bb + 1.0));
+                mean = coef * (2.0 * bm - 1.0); var = coef * coef * 4.0 * bv;
+            } else {
+                const double m = ((double)n_plus - (double)n_minus) / (double)n_shots;
+                mean = coef * m;
+                var = coef * coef * (1.0 - m * m) / (double)n_shots;
+            }
+            mean_out[s] = mean; var_out[s] = var;
+        }
+#pragma unroll
+        for (int k = 0; k < RPL; ++k)
+#pragma unroll
+            for (int w = 0; w < W; ++w) cur[k][w] = nxt[k][w];
+        tail_c = tail_n; s = sn;
+    }
+}
+
 template <bool PER_WAVE>
 __global__ void __launch_bounds__(256)
 shots_kernel(int n, long long n_settings, long long n_shots, const uint8_t* __restrict__ bits,
@@ -421,6 +505,15 @@ int fbx_shots_to_moments_dev(int n_qubits, int64_t n_settings, int64_t n_shots, 
         else if (n_qubits == 4) FBX_SHOTS_LAUNCH_N(4); else FBX_SHOTS_LAUNCH_N(8);
 #undef FBX_SHOTS_LAUNCH_N
 #undef FBX_SHOTS_LAUNCH
+    } else if (per_wave && (n_qubits == 3 || n_qubits == 5) && (bytes & 7) == 0 &&      // (6 and 7 qubits: measured no faster than shots_kernel)
+               (((uintptr_t)d_bits) & 7) == 0 && n_shots / 16 >= 1 && n_shots / 16 <= 128) {
+        const bool one = n_shots / 16 <= 64;
+#define FBX_SHOTS_PACKED(NQ) do { if (one) hipLaunchKernelGGL((shots_pipe_packed_kernel<NQ, 1>), dim3(grid), dim3(256), 0, stream(), (long long)n_settings, \
+                                                     (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out); \
+                                  else hipLaunchKernelGGL((shots_pipe_packed_kernel<NQ, 2>), dim3(grid), dim3(256), 0, stream(), (long long)n_settings, \
+                                                     (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out); } while (0)
+        if (n_qubits == 3) FBX_SHOTS_PACKED(3); else FBX_SHOTS_PACKED(5);
+#undef FBX_SHOTS_PACKED
     } else if (per_wave)
         hipLaunchKernelGGL(shots_kernel<true>, dim3(grid), dim3(256), 0, stream(), n_qubits, (long long)n_settings,
                            (long long)n_shots, d_bits, d_obs_mask, d_coefs, beta_prior, d_mean_out, d_var_out);
