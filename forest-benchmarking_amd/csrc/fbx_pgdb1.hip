@@ -105,13 +105,19 @@ int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const doub
     FBX_HIP(hipFuncSetAttribute((const void*)pgdb1_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // wavefronts in flight: what the chip holds at once (LDS- and register-limited), the rest of the batch through the
     // item counter.  Two waves per SIMD is the register limit (<= 256 VGPRs); 160 KiB of LDS per CU the other.
-    int dev = current_device();
-    hipDeviceProp_t prop;
-    FBX_HIP(hipGetDeviceProperties(&prop, dev < 0 ? 0 : dev));
-    int per_cu = 0;
-    FBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pgdb1_packed_kernel, 64, lds));
-    if (per_cu < 1) per_cu = 1;
-    const long long resident = (long long)per_cu * prop.multiProcessorCount;
+    // (queried once per device and LDS size: hipGetDeviceProperties costs ~100 us, this dispatch is also the B = 1 path)
+    static thread_local int cached_dev = -1, cached_epoch = -1, cached_cus = 0, cached_per_cu = 0;
+    static thread_local size_t cached_lds = 0;
+    const int dev = current_device();
+    if (cached_dev != dev || cached_epoch != device_epoch() || cached_lds != lds) {
+        hipDeviceProp_t prop;
+        FBX_HIP(hipGetDeviceProperties(&prop, dev < 0 ? 0 : dev));
+        int per_cu = 0;
+        FBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pgdb1_packed_kernel, 64, lds));
+        cached_cus = prop.multiProcessorCount; cached_per_cu = per_cu < 1 ? 1 : per_cu;
+        cached_dev = dev; cached_epoch = device_epoch(); cached_lds = lds;
+    }
+    const long long resident = (long long)cached_per_cu * cached_cus;
     const long long want = (B + 63) / 64;
     const long long grid = want < resident ? want : resident;
     void* w = nullptr;
