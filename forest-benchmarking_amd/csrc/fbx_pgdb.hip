@@ -20,6 +20,9 @@
 #ifndef FBX_LEAN_CL_LDS
 #define FBX_LEAN_CL_LDS 0           // experiment: the lean kernel keeps its own LDS copy of the Bloch matrix (7 instead of 8 waves per CU)
 #endif
+#ifndef FBX_LEAN_LN_LDS
+#define FBX_LEAN_LN_LDS 0           // experiment: the lean kernel keeps the normalised counts in LDS (25.7 KB per wavefront: 6 instead of 8 per CU)
+#endif
 #ifndef FBX_LEAN_MIN_BATCH
 #define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
 #endif
@@ -71,7 +74,7 @@ struct PgdbLds {
         constexpr int D = ChoiLds<NQ>::D;
         const size_t Su = S > D ? S : D;
         const size_t base = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
-        if (LEAN) return base + sizeof(double) * ((size_t)D * D + Su * D + (FBX_LEAN_CL_LDS ? (size_t)S * D : 0)) + 64;
+        if (LEAN) return base + sizeof(double) * ((size_t)D * D + Su * D + (FBX_LEAN_CL_LDS ? (size_t)S * D : 0) + (FBX_LEAN_LN_LDS ? 2 * (size_t)((m + 63) / 64) * 64 : 0)) + 64;
         return base + sizeof(double) * ((size_t)D * D + (Su + 2 * (size_t)S) * D + 2 * (size_t)((m + 63) / 64) * 64) + 64;
     }
     // every pointer is a plain offset from the start of the dynamic LDS segment (no conditional
@@ -86,7 +89,7 @@ struct PgdbLds {
         p += aligned;
         Rb = (double*)p; p += sizeof(double) * D * D;
         Tupd = (double*)p; p += sizeof(double) * (S > D ? S : D) * D;
-        if constexpr (LEAN) { Test = Tupd; Cl = FBX_LEAN_CL_LDS ? (double*)p : nullptr; Ln = nullptr; }
+        if constexpr (LEAN) { Test = Tupd; Cl = FBX_LEAN_CL_LDS ? (double*)p : nullptr; if (FBX_LEAN_CL_LDS) p += sizeof(double) * D * S; Ln = FBX_LEAN_LN_LDS ? (double*)p : nullptr; }
         else {
             Test = (double*)p; p += sizeof(double) * S * D;
             Cl = (double*)p; p += sizeof(double) * D * S;
@@ -161,7 +164,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
             }
         }
         tot = uniform(wave_sum(tot));
-        if constexpr (!LEAN) {
+        if constexpr (!LEAN || FBX_LEAN_LN_LDS) {
 #pragma unroll
             for (int j = 0; j < MAXJ; ++j) {
                 L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
@@ -181,7 +184,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
     // normalised counts of slot j: from LDS; LEAN: from the L2 workspace (written above by this very lane, so
     // program order is all the ordering needed), or recomputed from the inputs with the same expressions
     auto counts_of = [&](int j, double& np_, double& nm_) __attribute__((always_inline)) {
-        if constexpr (LEAN) {
+        if constexpr (LEAN && !FBX_LEAN_LN_LDS) {
 #ifndef FBX_LEAN_RECOUNT
             // (the launcher always provides the workspace: no second code path, whose operands the compiler would keep alive)
             np_ = ncounts[(2 * j) * 64 + lane]; nm_ = ncounts[(2 * j + 1) * 64 + lane];
