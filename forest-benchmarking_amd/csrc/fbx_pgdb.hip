@@ -20,6 +20,10 @@
 #ifndef FBX_LEAN_CL_LDS
 #define FBX_LEAN_CL_LDS 0           // experiment: the lean kernel keeps its own LDS copy of the Bloch matrix (7 instead of 8 waves per CU)
 #endif
+#ifndef FBX_LEAN_SHARED_TABLE
+#define FBX_LEAN_SHARED_TABLE 0     // experiment (fixed-iteration batches): four reconstructions per workgroup share an LDS copy of the
+                                    // Bloch matrix -- measured 6 % SLOWER at 8192 items than the one-wavefront workgroups
+#endif
 #ifndef FBX_LEAN_LN_LDS
 #define FBX_LEAN_LN_LDS 0           // experiment: the lean kernel keeps the normalised counts in LDS (25.7 KB per wavefront: 6 instead of 8 per CU)
 #endif
@@ -123,9 +127,9 @@ __device__ void predict_table(const double* Rb, const double* Ct, double* T, int
     }
 }
 
-template <int NQ, int MAXJ, bool LEAN>
+template <int NQ, int MAXJ, bool LEAN, bool SHARED_CT = false>
 __device__ __forceinline__ void
-pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restrict__ expect,
+pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev& des, long long B, const double* __restrict__ expect,
           const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
           double* __restrict__ choi_out, int* __restrict__ iters_out,
           int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
@@ -133,15 +137,16 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
           long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
           double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
-    const int lane = threadIdx.x;
-    const long long item = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long item = item_;
     const int m = des.m, S = des.S;
     PgdbLds<NQ, LEAN> L;
     L.carve(smem, S, 64 * MAXJ);
 
     // Bloch coefficients, one state per row: an LDS copy, or (LEAN) the design's own table through L2
     const double* Ct;
-    if constexpr (LEAN && !FBX_LEAN_CL_LDS) Ct = des.Ct;
+    if constexpr (LEAN && SHARED_CT) Ct = ct_shared;            // the workgroup's LDS copy (no run-time choice: the loads must stay ds_read, not flat)
+    else if constexpr (LEAN && !FBX_LEAN_CL_LDS) Ct = des.Ct;  // through L2
     else {
         for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
         Ct = L.Cl;
@@ -273,7 +278,7 @@ pgdb_body(char* smem, const DesignDev& des, long long B, const double* __restric
     int ls_full = 0, ls_sums = 0;          // work accounting: full cost evaluations / power-sum reductions
     // eigenvector bases of the previous outer iteration's Dykstra run (fbx_choi.hpp BasisStore)
     BasisStore basis;
-    basis.g = basis_scratch ? basis_scratch + (size_t)blockIdx.x * basis_cap * D * D : nullptr;
+    basis.g = basis_scratch ? basis_scratch + (size_t)item * basis_cap * D * D : nullptr;
     basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false; basis.write_all = false;
     int chain_start = 0;                           // value of `sweeps` at the last cold start of the stored bases
     double outer_step = 1.0;                       // alpha * ||update||_F of the previous outer iteration
@@ -660,7 +665,7 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     (void)ncounts;
-    pgdb_body<NQ, MAXJ, false>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+    pgdb_body<NQ, MAXJ, false>(smem, nullptr, blockIdx.x, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
                                dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, nullptr,
                                trace_out, trace_iters);
 }
@@ -669,19 +674,38 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 // SIMD, i.e. two dependent Jacobi chains interleaved on every SIMD -- for batches that put more than one
 // reconstruction on a SIMD anyway (BASELINE configs[4]: 8192 per GPU).  Results are bit-identical to
 // pgdb_kernel's (same arithmetic; only where operands are kept differs).
-template <int NQ, int MAXJ>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WAVES reconstructions (wavefronts) per workgroup.  WAVES = 1: the Bloch matrix is read through L2.  WAVES = 4: the wavefronts
+// share ONE LDS copy of Ct[S][D] at the start of the segment (4.6 KB for the 36-state design) -- the table every prediction /
+// gradient product walks -- at the price of a workgroup that holds its LDS until its slowest reconstruction has finished
+// (the fixed-iteration mode, whose reconstructions take similar times, uses it; a per-wavefront copy costs an eighth wavefront
+// per CU: 4.5 % slower).  The only workgroup barrier is the one that publishes the copy.
+template <int NQ, int MAXJ, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                  const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
                  double* __restrict__ choi_out, int* __restrict__ iters_out,
                  int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
                  double* __restrict__ cost_out, int* __restrict__ work_out,
                  long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-                 double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
+                 double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters, int wave_lds_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    pgdb_body<NQ, MAXJ, true>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
-                              dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
-                              ncounts ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters);
+    constexpr int D = 1 << (2 * NQ);
+    if constexpr (WAVES == 1) {
+        pgdb_body<NQ, MAXJ, true>(smem, nullptr, blockIdx.x, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+                                  dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
+                                  ncounts ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters);
+    } else {
+        double* ct = reinterpret_cast<double*>(smem);
+        for (int idx = threadIdx.x; idx < des.S * D; idx += 64 * WAVES) ct[idx] = des.Ct[idx];
+        __syncthreads();
+        const int wave = threadIdx.x >> 6;
+        const long long item = (long long)blockIdx.x * WAVES + wave;
+        if (item >= B) return;
+        const size_t ct_bytes = (sizeof(double) * (size_t)des.S * D + 15) & ~(size_t)15;
+        pgdb_body<NQ, MAXJ, true, true>(smem + ct_bytes + (size_t)wave * wave_lds_bytes, ct, item, des, B, expect, counts, trace_preserving, mode,
+                                  max_iters, choi_out, iters_out, dykstra_out, backtracks_out, cost_out, work_out, phase_out,
+                                  basis_scratch, basis_cap, ncounts ? ncounts + (size_t)item * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters);
+    }
 }
 
 #ifdef FBX_DIAGNOSTICS
@@ -707,14 +731,30 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     // batches that put several reconstructions on a SIMD take the lean two-waves-per-SIMD kernel (2 qubits)
     const bool lean = NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH;
     size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
-    if constexpr (NQ == 2) { if (lean) lds = PgdbLds<NQ, true>::bytes(des->dev.S, 64 * MAXJ); }
+    size_t wave_lds = 0;
+    constexpr int LW = 4;                  // wavefronts per workgroup of the shared-table form
+    bool lean4 = false;
+    if constexpr (NQ == 2) {
+        if (lean) {
+            wave_lds = (PgdbLds<NQ, true>::bytes(des->dev.S, 64 * MAXJ) + 15) & ~(size_t)15;
+            lds = wave_lds;
+            const size_t lds4 = ((sizeof(double) * (size_t)des->dev.S * (1 << (2 * NQ)) + 15) & ~(size_t)15) + LW * wave_lds;
+            lean4 = FBX_LEAN_SHARED_TABLE && mode == FBX_MODE_FIXED && 2 * lds4 <= 160 * 1024;
+            if (lean4) lds = lds4;
+        }
+    }
     if (lds > 160 * 1024) {
         set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
         return FBX_ERR_UNSUPPORTED;
     }
-    auto kern = pgdb_kernel<NQ, MAXJ>;
-    if constexpr (NQ == 2) { if (lean) kern = pgdb_lean_kernel<NQ, MAXJ>; }
-    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if constexpr (NQ == 2) {
+#if FBX_LEAN_SHARED_TABLE
+        if (lean && lean4) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<NQ, MAXJ, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else
+#endif
+        if (lean) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<NQ, MAXJ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (!lean) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_kernel<NQ, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each = 128 KiB per 2-qubit
     // item): a grow-only workspace of the calling thread (released by fbx_release_workspace).  A single
     // outer iteration has no previous iteration to take a basis from: no store then.
@@ -753,12 +793,21 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     hipStream_t st = ex.launch_stream ? ex.launch_stream : stream();
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64), lds, st, dev, (long long)nb,
-                           e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2,
-                           it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr,
-                           cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr,
-                           FBX_PHASE_OUT(b0), basis, BASIS_CAP, ncounts,
-                           ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr, ex.trace_iters);
+#define FBX_PGDB_ARGS dev, (long long)nb, e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2, \
+                      it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr, \
+                      FBX_PHASE_OUT(b0), basis, BASIS_CAP, ncounts, ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr, ex.trace_iters
+        if constexpr (NQ == 2) {
+            if (lean) {
+#if FBX_LEAN_SHARED_TABLE
+                if (lean4) hipLaunchKernelGGL((pgdb_lean_kernel<NQ, MAXJ, LW>), dim3((unsigned)((nb + LW - 1) / LW)), dim3(64 * LW), lds, st, FBX_PGDB_ARGS, (int)wave_lds);
+                else
+#endif
+                hipLaunchKernelGGL((pgdb_lean_kernel<NQ, MAXJ, 1>), dim3((unsigned)nb), dim3(64), lds, st, FBX_PGDB_ARGS, (int)wave_lds);
+                continue;
+            }
+        }
+        hipLaunchKernelGGL((pgdb_kernel<NQ, MAXJ>), dim3((unsigned)nb), dim3(64), lds, st, FBX_PGDB_ARGS);
+#undef FBX_PGDB_ARGS
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
