@@ -14,643 +14,9 @@
 //                           T[s][i] = sum_j R_ij c_j(s), R = Pauli-Liouville form of E)
 //   _cost / _grad_cost      tomography.py:597-633
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
-#include "fbx_choi.hpp"
-#include <cstdlib>
-#include <vector>
-#ifndef FBX_LEAN_CL_LDS
-#define FBX_LEAN_CL_LDS 0           // experiment: the lean kernel keeps its own LDS copy of the Bloch matrix (7 instead of 8 waves per CU)
-#endif
-#ifndef FBX_LEAN_SHARED_TABLE
-#define FBX_LEAN_SHARED_TABLE 0     // experiment (fixed-iteration batches): four reconstructions per workgroup share an LDS copy of the
-                                    // Bloch matrix -- measured 6 % SLOWER at 8192 items than the one-wavefront workgroups
-#endif
-#ifndef FBX_LEAN_LN_LDS
-#define FBX_LEAN_LN_LDS 0           // experiment: the lean kernel keeps the normalised counts in LDS (25.7 KB per wavefront: 6 instead of 8 per CU)
-#endif
-#ifndef FBX_LEAN_MIN_BATCH
-#define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
-#endif
-#ifndef FBX_PACKED_1Q_MIN_BATCH
-#define FBX_PACKED_1Q_MIN_BATCH 8192  // single-qubit batches from which the lane-per-item kernel is used (fbx_pgdb1.hip)
-#endif
-#ifndef FBX_BASIS_CHAIN_SWEEPS
-#define FBX_BASIS_CHAIN_SWEEPS 216  // Jacobi sweeps a chain of stored bases may accumulate (per slot, on average) before a cold restart
-#endif
-#ifndef FBX_BASIS_STEP
-#define FBX_BASIS_STEP 1e-3
-#endif
-#ifndef FBX_BASIS_WRITE_STEP
-#define FBX_BASIS_WRITE_STEP 3e-2     // outer step below which every Dykstra basis is written back (fbx_choi.hpp BasisStore)
-#endif
-#ifndef FBX_DBG_NOVALID
-#define FBX_DBG_NOVALID 0
-#endif
+#include "fbx_pgdb_body.hpp"
 
 namespace fbx {
-
-constexpr double PGDB_EPS = 1e-6;     // probability clip, tomography.py:597,613,631
-constexpr double PGDB_GAMMA = 0.3;    // tomography.py:567
-constexpr double PGDB_STOP = 1e-10;   // tomography.py:589
-constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
-#ifndef FBX_DBG_NOLADDER
-#define FBX_DBG_NOLADDER 0
-#endif
-#ifndef FBX_SMALL_STEP_LIMIT
-#define FBX_SMALL_STEP_LIMIT 0x1p-3      // alpha * max |pu / pe| below which the line search uses the power-sum series
-#endif
-
-// LEAN (2 waves per SIMD at large batches): 16.5 KB instead of 39 KB per reconstruction -- the Bloch matrix is
-// read from L2 (DesignDev::Ct), the normalised counts are recomputed from the inputs (L2) wherever they are
-// used, and ONE prediction table serves the estimate and the update direction in turn (the estimate's table
-// is rebuilt after the projection).
-template <int NQ, bool LEAN = false>
-struct PgdbLds {
-    ChoiLds<NQ, LEAN> choi;
-    double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time), TRANSPOSED: Rb[j * D + i] = R[i][j]
-    double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate           (LEAN: = Tupd)
-    double* Tupd;   // [S*D]  same for the update direction; reused as Wt[S][D] in the gradient
-    double* Cl;     // [S*D]  Bloch coefficients of the input states, one state per row: Cl[s * D + j] = C[j][s]   (LEAN: none)
-    double* Ln;     // [2*ceil(m/64)][64]  normalised counts n+ / n- of this lane's outcomes (row 2 j + sign): item
-                    // constants that are only read by the cost / gradient passes -- kept here, not in 36 registers (LEAN: none)
-    // Rb and Tupd are adjacent: both are dead while the projection runs, and together (>= 16 D^2 bytes,
-    // Tupd is sized for at least D states) they park the gradient block of every lane meanwhile
-    static size_t bytes(int S, int m) {
-        constexpr int D = ChoiLds<NQ>::D;
-        const size_t Su = S > D ? S : D;
-        const size_t base = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
-        if (LEAN) return base + sizeof(double) * ((size_t)D * D + Su * D + (FBX_LEAN_CL_LDS ? (size_t)S * D : 0) + (FBX_LEAN_LN_LDS ? 2 * (size_t)((m + 63) / 64) * 64 : 0)) + 64;
-        return base + sizeof(double) * ((size_t)D * D + (Su + 2 * (size_t)S) * D + 2 * (size_t)((m + 63) / 64) * 64) + 64;
-    }
-    // every pointer is a plain offset from the start of the dynamic LDS segment (no conditional
-    // layout), so the compiler keeps them in the LDS address space (ds_* instead of flat_*)
-    __device__ void carve(char* p, int S, int m) {
-        constexpr int D = ChoiLds<NQ>::D;
-        char* q = p;
-        choi.carve(q);
-        // (rounding the POINTER up through an integer cast would turn everything behind it into
-        // generic-address-space pointers: flat_load / flat_store instead of ds_read / ds_write)
-        constexpr size_t aligned = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
-        p += aligned;
-        Rb = (double*)p; p += sizeof(double) * D * D;
-        Tupd = (double*)p; p += sizeof(double) * (S > D ? S : D) * D;
-        if constexpr (LEAN) { Test = Tupd; Cl = FBX_LEAN_CL_LDS ? (double*)p : nullptr; if (FBX_LEAN_CL_LDS) p += sizeof(double) * D * S; Ln = FBX_LEAN_LN_LDS ? (double*)p : nullptr; }
-        else {
-            Test = (double*)p; p += sizeof(double) * S * D;
-            Cl = (double*)p; p += sizeof(double) * D * S;
-            Ln = (double*)p; p += sizeof(double) * 2 * ((m + 63) / 64) * 64;
-        }
-    }
-};
-
-// T[s][i] = sum_j R[i][j] * C[j][s].  Lane (i = lane % D, q = lane / D) keeps row i of R in registers
-// (Rb is transposed, so the D loads are conflict-free across i) and walks the states s = q, q + 64/D,
-// ...: per state D/2 broadcast 16-byte loads of the state's Bloch vector (Ct is [S][D]) and D FMAs, all
-// straight-line code -- the D x S loop over (s, i) pairs with two 8-byte loads per FMA it replaces
-// took 16k cycles per call for the 36-state design.
-template <int NQ>
-__device__ void predict_table(const double* Rb, const double* Ct, double* T, int S, int lane) {
-    constexpr int D = ChoiLds<NQ>::D, STEP = 64 / D;
-    const int i = lane % D, q = lane / D;
-    double r[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) r[j] = Rb[j * D + i];
-    for (int s = q; s < S; s += STEP) {
-        const double2* c2 = reinterpret_cast<const double2*>(Ct + (size_t)s * D);
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < D / 2; ++j) {
-            const double2 c = c2[j];
-            acc0 = fma(r[2 * j], c.x, acc0);
-            acc1 = fma(r[2 * j + 1], c.y, acc1);
-        }
-        T[s * D + i] = acc0 + acc1;
-    }
-}
-
-template <int NQ, int MAXJ, bool LEAN, bool SHARED_CT = false>
-__device__ __forceinline__ void
-pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev& des, long long B, const double* __restrict__ expect,
-          const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
-          double* __restrict__ choi_out, int* __restrict__ iters_out,
-          int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-          double* __restrict__ cost_out, int* __restrict__ work_out,
-          long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-          double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
-    constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
-    const int lane = threadIdx.x & 63;
-    const long long item = item_;
-    const int m = des.m, S = des.S;
-    PgdbLds<NQ, LEAN> L;
-    L.carve(smem, S, 64 * MAXJ);
-
-    // Bloch coefficients, one state per row: an LDS copy, or (LEAN) the design's own table through L2
-    const double* Ct;
-    if constexpr (LEAN && SHARED_CT) Ct = ct_shared;            // the workgroup's LDS copy (no run-time choice: the loads must stay ds_read, not flat)
-    else if constexpr (LEAN && !FBX_LEAN_CL_LDS) Ct = des.Ct;  // through L2
-    else {
-        for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
-        Ct = L.Cl;
-    }
-
-    // ---- data: n+-[k] = counts * (1 +- e)/2 / grand_total   (tomography.py:528-538)
-    double tot = 0.0;
-    {
-        double npl[MAXJ], nmi[MAXJ];
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = lane + 64 * j;
-            npl[j] = 0.0; nmi[j] = 0.0;
-            if (g < m) {
-                const int k = des.order[g];
-                const double e = expect[item * m + k], c = counts[item * m + k];
-                const double plus = (1.0 + e) / 2.0;
-                npl[j] = c * plus; nmi[j] = c * (1.0 - plus);
-                tot += c;
-            }
-        }
-        tot = uniform(wave_sum(tot));
-        if constexpr (!LEAN || FBX_LEAN_LN_LDS) {
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
-            }
-        } else {
-            // LEAN: the same table in the item's slice of an L2-resident workspace (lane-contiguous rows: coalesced.  One run of
-            // 2 MAXJ doubles per lane -- a single address register instead of one per row -- measured 2.2 x slower: 64 cache lines per load)
-#ifndef FBX_LEAN_RECOUNT
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                ncounts[(2 * j) * 64 + lane] = npl[j] / tot; ncounts[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
-            }
-#endif
-        }
-    }
-    FBX_WAVE_SYNC();
-    // normalised counts of slot j: from LDS; LEAN: from the L2 workspace (written above by this very lane, so
-    // program order is all the ordering needed), or recomputed from the inputs with the same expressions
-    auto counts_of = [&](int j, double& np_, double& nm_) __attribute__((always_inline)) {
-        if constexpr (LEAN && !FBX_LEAN_LN_LDS) {
-#ifndef FBX_LEAN_RECOUNT
-            // (the launcher always provides the workspace: no second code path, whose operands the compiler would keep alive)
-            np_ = ncounts[(2 * j) * 64 + lane]; nm_ = ncounts[(2 * j + 1) * 64 + lane];
-#else       // experiment: recomputed from the inputs with the same expressions at every use
-            const int g = lane + 64 * j;
-            np_ = 0.0; nm_ = 0.0;
-            if (g < m) {
-                const int k = des.order[g];
-                const double e = expect[item * m + k], c = counts[item * m + k];
-                const double plus = (1.0 + e) / 2.0;
-                np_ = (c * plus) / tot; nm_ = (c * (1.0 - plus)) / tot;
-            }
-#endif
-        } else {
-            np_ = L.Ln[(2 * j) * 64 + lane]; nm_ = L.Ln[(2 * j + 1) * 64 + lane];
-        }
-    };
-
-    const double half_dd = 0.5 / (double)(d * d);      // 1 / (2 d^2)
-    const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
-
-    // per-setting design words stay in registers for the whole reconstruction
-    uint32_t spw[LEAN ? 1 : MAXJ];
-    if constexpr (!LEAN) {
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = lane + 64 * j;
-            spw[j] = g < m ? des.sp[g] : 0u;
-        }
-    }
-    // (LEAN: re-read from the design where they are used -- coalesced L2 hits -- instead of MAXJ registers)
-    auto design_word = [&](int j) __attribute__((always_inline)) -> uint32_t {
-        if constexpr (LEAN) { const int g = lane + 64 * j; return g < m ? des.sp[g] : 0u; }
-        else return spw[j];
-    };
-    const bool unit_coefs = des.unit_coefs != 0;      // wave-uniform: coefficients re-read only when needed
-    // model probabilities of the current estimate (pe) and of the update direction (pu), per owned
-    // setting and outcome: p(alpha) = pe + alpha * pu, so a line-search step touches no memory
-    double pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
-    // (every slot is assigned -- `missing` for lanes without an outcome -- so that the arrays are dead
-    // between two calls and do not occupy registers across the projection)
-    auto load_probs = [&](const double* T, double (&pp)[MAXJ], double (&pm)[MAXJ], double missing) {
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = lane + 64 * j;
-            double a = missing, b = missing;
-            if (g < m) {
-                const uint32_t dw = design_word(j);
-                const int s = dw >> 16, p = dw & 0xffff;
-                const double cf = unit_coefs ? 1.0 : des.coef[g];
-                const double tr = T[s * D], ex = cf * T[s * D + p];
-                a = (tr + ex) * half_dd; b = (tr - ex) * half_dd;
-            }
-            pp[j] = a; pm[j] = b;
-        }
-    };
-    // negative log-likelihood at est + alpha * update (tomography.py:597-614)
-    auto cost_at = [&](double alpha) __attribute__((always_inline)) -> double {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = lane + 64 * j;
-            if (g < m) {
-                double pp = fma(alpha, pup[j], pep[j]), pm = fma(alpha, pum[j], pem[j]);
-                pp = pp < PGDB_EPS ? PGDB_EPS : pp;
-                pm = pm < PGDB_EPS ? PGDB_EPS : pm;
-                double np_, nm_;
-                counts_of(j, np_, nm_);
-                acc -= np_ * fast_log_pos(pp) + nm_ * fast_log_pos(pm);
-            }
-        }
-        return uniform(wave_sum(acc));
-    };
-
-    // ---- initial estimate I_D / d (tomography.py:564) in block layout
-    Blk est = blk_zero();
-    if (lane < NACT) {
-        const int I = lane / NB, J = lane % NB;
-        if (I == J) { est.re[0] = 1.0 / d; est.re[3] = 1.0 / d; }
-    }
-    FBX_WAVE_SYNC();
-
-    int iters = 0, dyk = 0, backtracks = 0, sweeps = 0;
-    int ls_full = 0, ls_sums = 0;          // work accounting: full cost evaluations / power-sum reductions
-    // eigenvector bases of the previous outer iteration's Dykstra run (fbx_choi.hpp BasisStore)
-    BasisStore basis;
-    basis.g = basis_scratch ? basis_scratch + (size_t)item * basis_cap * D * D : nullptr;
-    basis.cap = basis_cap; basis.nprev = 0; basis.use_prev = false; basis.write_all = false;
-    int chain_start = 0;                           // value of `sweeps` at the last cold start of the stored bases
-    double outer_step = 1.0;                       // alpha * ||update||_F of the previous outer iteration
-    PhaseClock pc; pc.reset(); L.choi.pc = &pc;
-    PH_START(pc);
-    double old_cost = 0.0, new_cost = 0.0;
-    bool have_cost = false;
-
-    while (true) {
-        if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
-        const int dyk_before = dyk, bt_before = backtracks;       // per-iteration trace (fbx_pgdb_process_ex)
-        // A stored basis is the product of all rotations applied to its chain since the last cold start, and every
-        // rotation costs ~1e-16 of unitarity: the chains are dropped once they have absorbed FBX_BASIS_CHAIN_SWEEPS
-        // sweeps per slot (216 sweeps x 120 rotations: < 3e-12 even if every rounding error had the same sign; the
-        // norm test of the warm start discards anything beyond 1e-9 anyway.  Round 1 dropped them every 16
-        // iterations whatever had happened, i.e. also in the stalled iterations, whose frozen decompositions apply
-        // no rotation at all, and a cold restart costs ~10 sweeps more than a warm projection).  The first basis of this iteration's
-        // projection is requested now, so that it arrives behind the gradient.
-#ifdef FBX_BASIS_RESET_MASK      // round-1 rule, for A/B builds: every (MASK + 1) iterations
-        if ((iters & FBX_BASIS_RESET_MASK) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
-        (void)chain_start;
-#else
-        if (iters == 0 || FBX_DBG_NOVALID ||
-            sweeps - chain_start >= FBX_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) {
-            basis.nprev = 0; chain_start = sweeps;
-        }
-#endif
-#ifndef FBX_NO_VFIRST
-        if (basis.g && basis.nprev > 0 && FBX_WARM_START) basis.template prefetch<D * D>(0, lane);
-#endif
-        // ---- prediction table of the current estimate
-        FBX_WAVE_SYNC();
-        blk_store<D, LD>(L.choi.Mw, lane, est);
-        FBX_WAVE_SYNC();
-        choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
-        FBX_WAVE_SYNC();
-        PH_STOP(pc, 3);
-        predict_table<NQ>(L.Rb, Ct, L.Test, S, lane);
-        FBX_WAVE_SYNC();
-        PH_STOP(pc, 7);
-        load_probs(L.Test, pep, pem, 1.0);
-        if (!have_cost) { old_cost = cost_at(0.0); have_cost = true; ++ls_full; }   // tomography.py:565
-
-        // ---- gradient (tomography.py:617-633): eta = n / clip(p); per input state s the weights of the
-        // Pauli components, Wt[s][0] = sum (eta+ + eta-)/2 and Wt[s][p] = coef (eta+ - eta-)/2, added
-        // straight from the registers of the lanes that own the settings (LDS fp64 atomics; one
-        // wavefront per item, so the order of the additions is the same in every run)
-        double* Wt = L.Tupd;                        // [S][D]
-        for (int idx = lane; idx < D * S; idx += 64) Wt[idx] = 0.0;
-        FBX_WAVE_SYNC();
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = lane + 64 * j;
-            if (g < m) {
-                const double pp = pep[j] < PGDB_EPS ? PGDB_EPS : pep[j];
-                const double pm = pem[j] < PGDB_EPS ? PGDB_EPS : pem[j];
-                double np_, nm_;
-                counts_of(j, np_, nm_);
-                const double ep = np_ / pp, em = nm_ / pm;
-                const double cf = unit_coefs ? 1.0 : des.coef[g];
-                const uint32_t dw = design_word(j);
-                const int st = dw >> 16, p = dw & 0xffff;
-                atomicAdd(&Wt[st * D], 0.5 * (ep + em));
-                atomicAdd(&Wt[st * D + p], cf * 0.5 * (ep - em));
-            }
-        }
-        FBX_WAVE_SYNC();
-        // R-coefficients of the gradient: Rg_ij = -(1/d^2) sum_s W[i][s] C[j][s].  Lane (i = lane % D,
-        // jq = lane / D) owns the outputs j = JB jq .. JB jq + JB - 1: per state one conflict-free load of
-        // Wt[s][i] and JB broadcast coefficients of the state's Bloch vector.
-        {
-            constexpr int JB = (D * D + 63) / 64;
-            const int i = lane % D, j0 = (lane / D) * JB;
-            if (j0 < D) {
-                double acc[JB];
-#pragma unroll
-                for (int r = 0; r < JB; ++r) acc[r] = 0.0;
-                for (int st = 0; st < S; ++st) {
-                    const double w = Wt[st * D + i];
-#pragma unroll
-                    for (int r = 0; r < JB; ++r) acc[r] = fma(w, Ct[st * D + j0 + r], acc[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < JB; ++r) L.Rb[(j0 + r) * D + i] = -acc[r] / (double)(d * d);
-            }
-        }
-        FBX_WAVE_SYNC();
-        Blk x;
-        {
-            const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, L.choi.Mw, lane);
-            PH_STOP(pc, 4);
-            // ---- projected step (tomography.py:572)
-            x = blk_axpy(est, -inv_mu, grad);
-            // the gradient is needed again after the projection (inner product with the update): parked in
-            // Rb + Tupd, not in 16 registers across the Dykstra loop
-            FBX_WAVE_SYNC();
-            if (lane < NACT) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { L.Rb[(2 * e) * NACT + lane] = grad.re[e]; L.Rb[(2 * e + 1) * NACT + lane] = grad.im[e]; }
-            }
-            FBX_WAVE_SYNC();
-        }
-        // below a step of 1e-3 the previous run's trajectory is closer to this one than consecutive
-        // Dykstra iterates are to each other (those stop at ~1e-2)
-        basis.use_prev = outer_step < FBX_BASIS_STEP;
-        // Inexact projections while the iteration is far from its fixed point: the eigensolver of the CP
-        // projections stops at an off-diagonal norm of des.eig_rel_tol (default FBX_JTOL_REL; fbx_set_option) x the previous outer step (relative to
-        // ||H||_F), never looser than that and never tighter than the 1e-13 it uses everywhere else.  What the
-        // reconstruction V diag(M)+ V^H drops is of the size of that off-diagonal part, i.e. 1e-8 of the
-        // distance the estimate still moves per iteration (-10 % time, parity survey unchanged).
-        { const double tr_ = des.eig_rel_tol * outer_step; L.choi.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }
-        basis.write_all = outer_step < FBX_BASIS_WRITE_STEP;
-        const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
-#ifdef FBX_NO_VFIRST
-                                               nullptr);
-#else
-                                               &basis);
-#endif
-        const Blk upd = blk_sub(proj, est);
-        Blk grad = blk_zero();
-        if (lane < NACT) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { grad.re[e] = L.Rb[(2 * e) * NACT + lane]; grad.im[e] = L.Rb[(2 * e + 1) * NACT + lane]; }
-        }
-        double ipr, ipi;
-        blk_dotc(upd, grad, ipr, ipi);
-        ipr = uniform(wave_sum(ipr));
-        PH_STOP(pc, 2);
-
-        // ---- prediction tables for the line search
-        if constexpr (LEAN) {
-            // one table buffer: the estimate's table was overwritten by the gradient weights -- rebuilt here
-            // (one more transform + table product per outer iteration, ~1 % of it) and read, before the
-            // update direction's takes its place
-            FBX_WAVE_SYNC();
-            blk_store<D, LD>(L.choi.Mw, lane, est);
-            FBX_WAVE_SYNC();
-            choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
-            FBX_WAVE_SYNC();
-            predict_table<NQ>(L.Rb, Ct, L.Test, S, lane);
-            FBX_WAVE_SYNC();
-            load_probs(L.Test, pep, pem, 1.0);
-        }
-        FBX_WAVE_SYNC();
-        blk_store<D, LD>(L.choi.Mw, lane, upd);
-        FBX_WAVE_SYNC();
-        choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
-        FBX_WAVE_SYNC();
-        predict_table<NQ>(L.Rb, Ct, L.Tupd, S, lane);
-        FBX_WAVE_SYNC();
-        if constexpr (!LEAN) load_probs(L.Test, pep, pem, 1.0);      // again: not kept in registers across the projection
-        load_probs(L.Tupd, pup, pum, 0.0);
-        PH_STOP(pc, 3);
-        // ---- backtracking line search (tomography.py:575-585)
-#ifndef FBX_NO_SMALL_STEP
-        // Small steps: cost(alpha) = cost(0) - sum n log1p(alpha pu / pe), and cost(0) is old_cost.
-        // Once alpha |pu / pe| < 2^-9 for every outcome (and nothing sits at the clip), log1p is a
-        // degree-6 polynomial to < 1e-17 relative -- 8 instructions per outcome instead of ~40.  The
-        // long halving runs of stalled iterations live here.
-        auto ratio = [](double pu, double pe) __attribute__((always_inline)) -> double {
-            double ip = __builtin_amdgcn_rcp(pe);
-            ip = fma(fma(-pe, ip, 1.0), ip, ip);
-            return (pe < 2.0 * PGDB_EPS || fabs(pu) > pe) ? 0.0 : pu * ip;
-        };
-        // outcomes evaluated exactly instead (compact list below): at the clip, or moving by more than
-        // their own size over a full step -- with those out, |pu / pe| <= 1 and the polynomial takes over
-        // from alpha = 2^-9 on whatever the design
-        auto exact = [](double pu, double pe) __attribute__((always_inline)) -> bool {
-            return pe < 2.0 * PGDB_EPS || fabs(pu) > pe;
-        };
-        double rmax = 0.0;                   // max |pu / pe| over the outcomes that are not listed
-        uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            rmax = fmax(rmax, fmax(fabs(ratio(pup[j], pep[j])), fabs(ratio(pum[j], pem[j]))));
-            if (__ballot(exact(pup[j], pep[j]))) near_clip |= 1u << (2 * j);
-            if (__ballot(exact(pum[j], pem[j]))) near_clip |= 2u << (2 * j);
-        }
-        rmax = uniform(wave_max(rmax));
-        const bool small_ok = rmax == rmax;
-        // The near-clip outcomes are few and scattered over lanes and slots: they are compacted into
-        // one entry per lane (through LDS -- the Jacobi work area is idle during the line search), so
-        // an evaluation costs one clipped log per lane instead of one per flagged slot and sign.
-        // the list lives in the Jacobi work area (Ms + Vs, idle during the line search): 4 rows of CL_MAX doubles
-        constexpr int CL_MAX = (2 * sizeof(cplx) * D * D) / (4 * sizeof(double)) < 64 ? (int)((2 * sizeof(cplx) * D * D) / (4 * sizeof(double))) : 64;
-        static_assert(4 * CL_MAX * sizeof(double) <= 2 * sizeof(cplx) * D * D, "compact list must fit into Ms + Vs");
-        double clip_pe = 1.0, clip_pu = 0.0, clip_n = 0.0;       // this lane's entry of the compact list
-        bool clip_listed = false;
-        double clip_base = 0.0;
-        int n_clip = 0;
-        if (near_clip) {
-            double* cl = (double*)L.choi.Ms;                     // [4][CL_MAX]: pe, pu, n, n log(clip(pe))
-            const unsigned long long below = (1ull << lane) - 1ull;
-            FBX_WAVE_SYNC();
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-#pragma unroll
-                for (int sg = 0; sg < 2; ++sg) {
-                    if (near_clip & ((1u + sg) << (2 * j))) {
-                        double np_, nm_;
-                        counts_of(j, np_, nm_);
-                        const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? nm_ : np_;
-                        const bool f = exact(pu, pe);
-                        const unsigned long long mk = __ballot(f);
-                        const int pos = n_clip + __popcll(mk & below);
-                        if (f && pos < CL_MAX) { cl[pos] = pe; cl[CL_MAX + pos] = pu; cl[2 * CL_MAX + pos] = nn; }
-                        n_clip += __popcll(mk);
-                    }
-                }
-            }
-            FBX_WAVE_SYNC();
-            clip_listed = n_clip <= CL_MAX;
-            if (clip_listed) {
-                if (lane < n_clip) { clip_pe = cl[lane]; clip_pu = cl[CL_MAX + lane]; clip_n = cl[2 * CL_MAX + lane]; }
-                clip_base = clip_n * fast_log_pos(clip_pe < PGDB_EPS ? PGDB_EPS : clip_pe);
-                if (lane < n_clip) cl[3 * CL_MAX + lane] = clip_base;       // for the one-pass ladder below
-            }                                                    // more than CL_MAX of them: full evaluations only
-            FBX_WAVE_SYNC();
-        }
-        auto clipped_log = [](double p) __attribute__((always_inline)) -> double { return fast_log_pos(p < PGDB_EPS ? PGDB_EPS : p); };
-        // sum_o n_o log1p(alpha r_o) = sum_k c_k alpha^k S_k with the power sums S_k = sum_o n_o r_o^k,
-        // c_k = (-1)^(k+1) / k, reduced ONCE per outer iteration (on the first small step): every further
-        // halving is a Horner evaluation (+ the clipped logs of the listed outcomes) instead of a pass
-        // over all outcomes.  Degree 16 below alpha rmax = 2^-3: remainder < 2^-51 / 17 per unit of n,
-        // below the rounding of the exact evaluation.
-        constexpr int NS = 16;
-        double Sk[NS];
-        bool have_sums = false;
-        auto small_regime = [&](double alpha) __attribute__((always_inline)) -> bool {
-            return small_ok && (near_clip == 0u || clip_listed) && alpha * rmax < FBX_SMALL_STEP_LIMIT;
-        };
-        auto series = [&](double alpha) __attribute__((always_inline)) -> double {      // alpha may differ per lane
-            double q = Sk[NS - 1];
-#pragma unroll
-            for (int k = NS - 2; k >= 0; --k) q = fma(alpha, q, Sk[k]);
-            return alpha * q;
-        };
-        // The acceptance test of tomography.py:578 is `new_cost > old_cost + change`.  In the small-step regime the
-        // cost DIFFERENCE is known exactly (the series), and the test is made on it: `new - old > change`.  The
-        // two forms differ only where |new - old| and |change| are below the rounding of the cost itself -- the
-        // stalled iterations past convergence, where the projection's inexactness makes the direction an
-        // ASCENT direction (new - old = alpha <update, gradient> > change > 0 for every alpha): there the
-        // reference's rounded test is decided by the noise of its cost sums (it ends up halving 47-50 times
-        // per iteration), the rounded test on an exact difference would accept as soon as both
-        // sides vanish against the cost (~11 halvings, a 3e-8 step along an ascent direction, every stalled
-        // iteration), and the exact test rejects down to alpha < 1e-15 like the reference's late iterations:
-        // the estimate then stays where the reference's stays, to rounding.  -DFBX_LS_ROUNDED restores the
-        // rounded form (round-1 behaviour).
-        bool ls_exact = false;
-        double ls_diff = 0.0;
-        auto cost_step = [&](double alpha) __attribute__((always_inline)) -> double {
-            ls_exact = false;
-            if (!small_regime(alpha)) { ++ls_full; return cost_at(alpha); }
-            if (!have_sums) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) Sk[k] = 0.0;
-#pragma unroll
-                for (int j = 0; j < MAXJ; ++j) {
-                    double np_, nm_;
-                    counts_of(j, np_, nm_);
-#pragma unroll
-                    for (int sg = 0; sg < 2; ++sg) {
-                        const double x = sg ? ratio(pum[j], pem[j]) : ratio(pup[j], pep[j]);   // recomputed: not kept live
-                        double t = (sg ? nm_ : np_) * x;
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) { Sk[k] += t; t *= x; }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NS; ++k) Sk[k] = uniform(wave_sum(Sk[k])) * ((k & 1) ? -1.0 : 1.0) / (double)(k + 1);
-                have_sums = true; ++ls_sums;
-            }
-            double acc = series(alpha);
-            if (near_clip)                   // the listed outcomes: exact difference of clipped logs
-                acc += uniform(wave_sum(clip_n * clipped_log(fma(alpha, clip_pu, clip_pe)) - clip_base));
-#ifndef FBX_LS_ROUNDED
-            ls_exact = true; ls_diff = -acc;
-#endif
-            return old_cost - acc;
-        };
-        auto rejected = [&](double change_) __attribute__((always_inline)) -> bool {
-            return ls_exact ? (ls_diff > change_) : (new_cost > old_cost + change_);
-        };
-#else
-        auto cost_step = [&](double alpha) -> double { ++ls_full; return cost_at(alpha); };
-        auto rejected = [&](double change_) -> bool { return new_cost > old_cost + change_; };
-#endif
-        double alpha = 1.0;
-        new_cost = cost_step(alpha);
-        double change = PGDB_GAMMA * alpha * ipr;
-#ifndef FBX_NO_SMALL_STEP
-        int small_fails = 0;
-#endif
-        while (rejected(change)) {
-#ifndef FBX_NO_SMALL_STEP
-            // Two series evaluations in a row have failed: this is one of the long halving runs of a
-            // stalled iteration.  The rest of the ladder alpha 2^-L, L = 1, 2, ... is evaluated in ONE pass,
-            // lane L taking its own alpha (same series; the listed outcomes, one per lane so far, are
-            // walked from their LDS list by every lane), and the first L that the sequential loop would
-            // have stopped at -- sufficient decrease, or alpha below the floor -- is taken.
-            if (small_fails >= 2 && !FBX_DBG_NOLADDER) {
-                const double a_l = __builtin_ldexp(alpha, -lane), c_l = __builtin_ldexp(change, -lane);
-                double acc = series(a_l);
-                if (near_clip) {
-                    const double* cl = (const double*)L.choi.Ms;
-                    for (int e = 0; e < n_clip; ++e) {
-                        const double pe = cl[e], pu = cl[CL_MAX + e], nn = cl[2 * CL_MAX + e];
-                        acc += nn * clipped_log(fma(a_l, pu, pe)) - cl[3 * CL_MAX + e];
-                    }
-                }
-                const double val = old_cost - acc;
-#ifndef FBX_LS_ROUNDED
-                const bool rej_l = -acc > c_l;
-#else
-                const bool rej_l = val > old_cost + c_l;
-#endif
-                const unsigned long long stop = __ballot(lane >= 1 && (a_l < PGDB_ALPHA_MIN || !rej_l));
-                const int Ls = __builtin_ctzll(stop);          // alpha <= 1: lane 50 is below the floor at the latest
-                alpha = __builtin_ldexp(alpha, -Ls); change = __builtin_ldexp(change, -Ls);
-                new_cost = uniform(__shfl(val, Ls));
-                backtracks += Ls;
-                break;
-            }
-#endif
-            alpha *= 0.5;
-            change *= 0.5;
-#ifndef FBX_NO_SMALL_STEP
-            if (small_regime(alpha)) ++small_fails;
-#endif
-            new_cost = cost_step(alpha);
-            ++backtracks;
-            if (alpha < PGDB_ALPHA_MIN) break;
-        }
-        PH_STOP(pc, 5);
-        est = blk_axpy(est, alpha, upd);            // tomography.py:588
-        outer_step = alpha * sqrt(uniform(wave_sum(blk_norm2(upd))));
-        if (trace_out && iters < trace_iters && lane == 0) {     // Dykstra iterations and halvings of THIS outer iteration
-            int* tr = trace_out + ((size_t)item * trace_iters + iters) * 2;
-            tr[0] = dyk - dyk_before; tr[1] = backtracks - bt_before;
-        }
-        ++iters;
-        if (mode == FBX_MODE_CONVERGE) {
-            if (!(old_cost - new_cost >= PGDB_STOP)) break;      // tomography.py:589; a NaN cost also ends the loop
-            if (max_iters > 0 && iters >= max_iters) break;
-        }
-        old_cost = new_cost;
-    }
-
-    // ---- write back
-    if (lane < NACT) {
-        const int I = lane / NB, J = lane % NB;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
-            double* o = choi_out + ((item * D + row) * D + col) * 2;
-            o[0] = est.re[e]; o[1] = est.im[e];
-        }
-    }
-    if (lane == 0) {
-        if (iters_out) iters_out[item] = iters;
-        if (dykstra_out) dykstra_out[item] = dyk;
-        if (backtracks_out) backtracks_out[item] = backtracks;
-        if (cost_out) cost_out[item] = have_cost ? new_cost : 0.0;
-        if (work_out) {     // Jacobi sweeps, eigenvalue terms rebuilt, full cost evaluations, power-sum reductions
-            work_out[4 * item] = sweeps; work_out[4 * item + 1] = L.choi.terms;
-            work_out[4 * item + 2] = ls_full; work_out[4 * item + 3] = ls_sums;
-        }
-    }
-#ifdef FBX_PHASE_TIMERS
-    if (lane == 0 && phase_out) for (int i = 0; i < FBX_NPHASE; ++i) phase_out[item * FBX_NPHASE + i] = pc.acc[i];
-#endif
-}
 
 // The product kernel: one wavefront per SIMD (up to 512 registers, 39 KB of LDS) -- the fastest form while
 // there are no more reconstructions in flight than SIMDs (B <= 1024 on 256 CUs).
@@ -668,44 +34,6 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
     pgdb_body<NQ, MAXJ, false>(smem, nullptr, blockIdx.x, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
                                dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, nullptr,
                                trace_out, trace_iters);
-}
-
-// The same reconstruction with the lean LDS layout (16.5 KB) and at most 256 registers: TWO wavefronts per
-// SIMD, i.e. two dependent Jacobi chains interleaved on every SIMD -- for batches that put more than one
-// reconstruction on a SIMD anyway (BASELINE configs[4]: 8192 per GPU).  Results are bit-identical to
-// pgdb_kernel's (same arithmetic; only where operands are kept differs).
-// WAVES reconstructions (wavefronts) per workgroup.  WAVES = 1: the Bloch matrix is read through L2.  WAVES = 4: the wavefronts
-// share ONE LDS copy of Ct[S][D] at the start of the segment (4.6 KB for the 36-state design) -- the table every prediction /
-// gradient product walks -- at the price of a workgroup that holds its LDS until its slowest reconstruction has finished
-// (the fixed-iteration mode, whose reconstructions take similar times, uses it; a per-wavefront copy costs an eighth wavefront
-// per CU: 4.5 % slower).  The only workgroup barrier is the one that publishes the copy.
-template <int NQ, int MAXJ, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
-pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
-                 const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
-                 double* __restrict__ choi_out, int* __restrict__ iters_out,
-                 int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
-                 double* __restrict__ cost_out, int* __restrict__ work_out,
-                 long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-                 double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters, int wave_lds_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = 1 << (2 * NQ);
-    if constexpr (WAVES == 1) {
-        pgdb_body<NQ, MAXJ, true>(smem, nullptr, blockIdx.x, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
-                                  dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
-                                  ncounts ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters);
-    } else {
-        double* ct = reinterpret_cast<double*>(smem);
-        for (int idx = threadIdx.x; idx < des.S * D; idx += 64 * WAVES) ct[idx] = des.Ct[idx];
-        __syncthreads();
-        const int wave = threadIdx.x >> 6;
-        const long long item = (long long)blockIdx.x * WAVES + wave;
-        if (item >= B) return;
-        const size_t ct_bytes = (sizeof(double) * (size_t)des.S * D + 15) & ~(size_t)15;
-        pgdb_body<NQ, MAXJ, true, true>(smem + ct_bytes + (size_t)wave * wave_lds_bytes, ct, item, des, B, expect, counts, trace_preserving, mode,
-                                  max_iters, choi_out, iters_out, dykstra_out, backtracks_out, cost_out, work_out, phase_out,
-                                  basis_scratch, basis_cap, ncounts ? ncounts + (size_t)item * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters);
-    }
 }
 
 #ifdef FBX_DIAGNOSTICS
@@ -732,13 +60,11 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     const bool lean = NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH;
     size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
     size_t wave_lds = 0;
-    constexpr int LW = 4;                  // wavefronts per workgroup of the shared-table form
-    bool lean4 = false;
+    bool lean4 = false;                    // the shared-table experiment of fbx_pgdb_lean.hip (fixed-iteration batches)
     if constexpr (NQ == 2) {
         if (lean) {
-            wave_lds = (PgdbLds<NQ, true>::bytes(des->dev.S, 64 * MAXJ) + 15) & ~(size_t)15;
-            lds = wave_lds;
-            const size_t lds4 = ((sizeof(double) * (size_t)des->dev.S * (1 << (2 * NQ)) + 15) & ~(size_t)15) + LW * wave_lds;
+            lds = pgdb_lean_lds(MAXJ, des->dev.S, false, &wave_lds);
+            const size_t lds4 = pgdb_lean_lds(MAXJ, des->dev.S, true, &wave_lds);
             lean4 = FBX_LEAN_SHARED_TABLE && mode == FBX_MODE_FIXED && 2 * lds4 <= 160 * 1024;
             if (lean4) lds = lds4;
         }
@@ -746,13 +72,6 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     if (lds > 160 * 1024) {
         set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
         return FBX_ERR_UNSUPPORTED;
-    }
-    if constexpr (NQ == 2) {
-#if FBX_LEAN_SHARED_TABLE
-        if (lean && lean4) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<NQ, MAXJ, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else
-#endif
-        if (lean) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<NQ, MAXJ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (!lean) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_kernel<NQ, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each = 128 KiB per 2-qubit
@@ -793,21 +112,21 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     hipStream_t st = ex.launch_stream ? ex.launch_stream : stream();
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
-#define FBX_PGDB_ARGS dev, (long long)nb, e + b0 * m, c + b0 * m, tp, mode, max_iters, choi + b0 * D * D * 2, \
-                      it ? it + b0 : nullptr, dy ? dy + b0 : nullptr, bt ? bt + b0 : nullptr, cost ? cost + b0 : nullptr, sw ? sw + 4 * b0 : nullptr, \
-                      FBX_PHASE_OUT(b0), basis, BASIS_CAP, ncounts, ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr, ex.trace_iters
+        PgdbLaunch a;
+        a.dev = dev; a.nb = nb; a.e = e + b0 * m; a.c = c + b0 * m; a.tp = tp; a.mode = mode; a.max_iters = max_iters;
+        a.choi = choi + b0 * D * D * 2; a.it = it ? it + b0 : nullptr; a.dy = dy ? dy + b0 : nullptr; a.bt = bt ? bt + b0 : nullptr;
+        a.cost = cost ? cost + b0 : nullptr; a.sw = sw ? sw + 4 * b0 : nullptr; a.phase = FBX_PHASE_OUT(b0); a.basis = basis;
+        a.basis_cap = BASIS_CAP; a.ncounts = ncounts; a.trace = ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr;
+        a.trace_iters = ex.trace_iters;
         if constexpr (NQ == 2) {
             if (lean) {
-#if FBX_LEAN_SHARED_TABLE
-                if (lean4) hipLaunchKernelGGL((pgdb_lean_kernel<NQ, MAXJ, LW>), dim3((unsigned)((nb + LW - 1) / LW)), dim3(64 * LW), lds, st, FBX_PGDB_ARGS, (int)wave_lds);
-                else
-#endif
-                hipLaunchKernelGGL((pgdb_lean_kernel<NQ, MAXJ, 1>), dim3((unsigned)nb), dim3(64), lds, st, FBX_PGDB_ARGS, (int)wave_lds);
+                const int rc = pgdb_lean_launch(MAXJ, lds, wave_lds, lean4, st, a);
+                if (rc) return rc;
                 continue;
             }
         }
-        hipLaunchKernelGGL((pgdb_kernel<NQ, MAXJ>), dim3((unsigned)nb), dim3(64), lds, st, FBX_PGDB_ARGS);
-#undef FBX_PGDB_ARGS
+        hipLaunchKernelGGL((pgdb_kernel<NQ, MAXJ>), dim3((unsigned)nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
+                           a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
