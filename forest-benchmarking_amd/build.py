@@ -10,10 +10,15 @@ OUT = os.path.join(HERE, "libfbx.so")
 MAP = os.path.join(CSRC, "libfbx.map")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"] + os.environ.get("FBX_EXTRA_FLAGS", "").split()
-# Per-file flags.  fbx_pgdb.hip holds the one-wavefront-per-SIMD PGDB kernels: a lone wavefront has nobody to hide its latencies
-# behind, and the scheduler's max-ILP strategy is worth 3 % there (B = 1024: 12.95 -> 12.58 ms on the same box); the
-# register-starved two-wavefronts-per-SIMD kernel of fbx_pgdb_lean.hip runs at HALF its speed with it, hence the two units.
-FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", "-mllvm -amdgpu-sched-strategy=max-ilp").split()}
+# Per-file flags: the instruction scheduler's max-ILP strategy (same-box A/Bs, scripts/ab_time*.py; results are bit-identical).
+#   fbx_pgdb.hip       one-wavefront-per-SIMD PGDB kernels: a lone wavefront has nobody to hide its latencies behind: B = 1024
+#                      12.85 -> 12.6 ms.  The register-starved two-wavefronts-per-SIMD kernel of fbx_pgdb_lean.hip runs at HALF
+#                      its speed with it -- hence the two translation units.
+#   fbx_pgdb3.hip      3-qubit kernel (1024-thread workgroups, 128 registers): 360.6 -> 335.0 ms per 256 reconstructions (-7 %).
+#   fbx_pgdb1.hip      lane-per-item single-qubit kernel: no difference (66.4 vs 66.8 ms), default kept.
+_MAX_ILP = "-mllvm -amdgpu-sched-strategy=max-ilp"
+FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", _MAX_ILP).split(),
+              "fbx_pgdb3.hip": os.environ.get("FBX_PGDB3_FLAGS", _MAX_ILP).split()}
 
 
 def file_flags(src):
