@@ -18,7 +18,8 @@
 #define FBX_LEAN_LN_LDS 0           // experiment: the lean kernel keeps the normalised counts in LDS (25.7 KB per wavefront: 6 instead of 8 per CU)
 #endif
 #ifndef FBX_LEAN_MIN_BATCH
-#define FBX_LEAN_MIN_BATCH 2048     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits)
+#define FBX_LEAN_MIN_BATCH 1280     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits): measured crossover with the
+                                    // one-wave kernel between 1100 and 1280 reconstructions in both modes (1280: 18.8 against 20.4 ms)
 #endif
 #ifndef FBX_PACKED_1Q_MIN_BATCH
 #define FBX_PACKED_1Q_MIN_BATCH 8192  // single-qubit batches from which the lane-per-item kernel is used (fbx_pgdb1.hip)

@@ -9,7 +9,7 @@ import numpy as np
 from fbx import synthetic, _lib
 _lib.set_device(0)
 B = int(sys.argv[2]); mode = _lib.MODE_FIXED if sys.argv[3] == "fixed" else _lib.MODE_CONVERGE
-design, _, e, c = synthetic.process_batch(2, "pauli", min(B, 2048))
+design, _, e, c = synthetic.process_batch(2, "pauli", min(B, 2048))  # (distinct items up to 2048, tiled beyond)
 if B > 2048:
     e = np.tile(e, (B // 2048, 1)); c = np.tile(c, (B // 2048, 1))
 d_e, d_c = _lib.DeviceBuffer.from_array(e), _lib.DeviceBuffer.from_array(c)

@@ -222,7 +222,7 @@ def test_config5_shard_size_properties(gpu):
 
 @pytest.mark.parametrize("basis", ["pauli", "sic"])
 def test_lean_two_waves_per_simd_kernel_agrees_with_the_one_wave_kernel(gpu, basis):
-    """Batches of >= 2048 two-qubit reconstructions run pgdb_lean_kernel (16.5 KB of LDS, <= 256 registers, two
+    """Batches of >= 1280 two-qubit reconstructions (2048 here) run pgdb_lean_kernel (16.5 KB of LDS, <= 256 registers, two
     wavefronts per SIMD).  Since round 3 it carries Dykstra's state as two matrices + an 8-number
     summary instead of four matrices (fbx_choi.hpp proj_physical_blk_compact: same projections and stopping rule, the
     stopping functional assembled from algebraically equal terms), so its trajectory equals the one-wave kernel's to
