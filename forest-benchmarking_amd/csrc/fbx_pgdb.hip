@@ -146,12 +146,16 @@ static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, cons
     const int n = des->dev.n, m = des->dev.m;
     if (n == 1) {
         // Large batches: 64 reconstructions per wavefront, one per lane (fbx_pgdb1.hip; the eigensolver at its full tolerance --
-        // eig_rel_tol does not apply).  A lane is ~3x slower on one reconstruction than a wavefront, so the wave-per-item kernel
-        // below keeps the batches that do not fill the lanes of the chip (measured crossover between 4096 and 16 384 items,
-        // scripts/pgdb1_time.py); fbx_set_option("pgdb_packed_1q", 0 | 2) forces one or the other.
+        // eig_rel_tol does not apply).  A lane is ~3x slower on one reconstruction than a wavefront and a launch lasts as long as
+        // its slowest reconstruction (12-14 ms for the Pauli design, 5 ms for SIC, whatever the batch up to 65 536), while the
+        // wave-per-item kernel below scales with the batch (1.0 / 0.76 us per reconstruction): the measured crossover
+        // (scripts/pgdb1_crossover.py) is ~7000 experiments for the 12-setting SIC design and ~16 000 for the 18-setting Pauli
+        // design.  fbx_set_option("pgdb_packed_1q", 0 | 2) forces one or the other.
         {
             const int packed = option_pgdb_packed_1q();
-            if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_PACKED_1Q_MIN_BATCH)))
+            const int64_t total = ex.total_batch > B ? ex.total_batch : B;
+            const int64_t from = m <= 12 ? FBX_PACKED_1Q_MIN_BATCH : 2 * FBX_PACKED_1Q_MIN_BATCH;
+            if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && total >= from)))
                 return pgdb1_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         }
         if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);

@@ -95,7 +95,7 @@ int         fbx_release_workspace(void);            /* free the calling thread's
  *   fbx_pgdb_process (see fbx_host_alloc); the bulk in between goes in one launch per 65 536 items.
  *   "eigh_cooperative" (default 1): fbx_eigh of a few matrices with N >= 128 spreads each matrix over the whole chip with a
  *   cooperative launch; 0 keeps one workgroup per matrix.
- *   "pgdb_packed_1q" (default 1): single-qubit fbx_pgdb_process* with at most 64 settings and at least 8192 experiments runs
+ *   "pgdb_packed_1q" (default 1): single-qubit fbx_pgdb_process* with at most 64 settings and at least 8192 experiments (16 384 for designs of more than 12 settings) runs
  *   64 reconstructions per wavefront, one per lane (csrc/fbx_pgdb1.hip; same line-search rule as the other kernels, the
  *   eigensolver always at full tolerance -- eig_rel_tol does not apply); 2 = for every batch size, 0 = never (the
  *   wavefront-per-reconstruction kernel, which smaller batches and larger designs use). */
