@@ -24,6 +24,15 @@ extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
 #else
 #define FBX_PHASE_OUT3(b0) ((long long*)nullptr)
 #endif
+#ifndef FBX3_BASIS_STEP
+#define FBX3_BASIS_STEP 3e-2           // outer step below which Dykstra iteration j starts from the previous call's basis j.  The 2-qubit kernel's
+                                       // 1e-3 (FBX_BASIS_STEP) is too timid here: same-box A/B (scripts/ab_time3.py, 256 items) 331.6 ms at
+                                       // 1e-3 / 3e-2, 324.4 at 1e-2 / 1e-1, 317.2 at 3e-2 / 3e-1, 317.1 at 1e-1 / 1 -- a starting basis only
+                                       // changes how many sweeps a decomposition needs, never the tolerance it runs to
+#endif
+#ifndef FBX3_BASIS_WRITE_STEP
+#define FBX3_BASIS_WRITE_STEP 3e-1     // outer step below which every basis is written back (10 x the threshold above, as in the 2-qubit kernel)
+#endif
 #ifndef FBX3_BASIS_CHAIN_SWEEPS
 #define FBX3_BASIS_CHAIN_SWEEPS 216   // as FBX_BASIS_CHAIN_SWEEPS of the 2-qubit kernel (fbx_pgdb.hip)
 #endif
@@ -668,8 +677,8 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         // bounds the accumulated loss of unitarity of the chained bases: a cold restart once the chains have
         // absorbed 54 sweeps per slot (what 16 converging iterations apply; see fbx_pgdb.hip)
         if (iters == 0 || sweeps - chain_start >= FBX3_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) { basis.nprev = 0; chain_start = sweeps; }
-        basis.use_prev = outer_step < 1e-3;
-        basis.write_all = outer_step < 3e-2;
+        basis.use_prev = outer_step < FBX3_BASIS_STEP;
+        basis.write_all = outer_step < FBX3_BASIS_WRITE_STEP;
         { const double tr_ = des.eig_rel_tol * outer_step; L.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }   // as in fbx_pgdb.hip
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch,
