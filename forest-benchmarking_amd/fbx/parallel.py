@@ -40,8 +40,9 @@ class FileRendezvous:
     MASTER_PORT; FBX_RDZV_DIR may be reused), so nothing in it is trusted by name alone: rank 0 opens a
     GENERATION -- it removes whatever the directory held and publishes a fresh random nonce under the one
     fixed name ``gen`` -- and every other file name carries that nonce.  A rank that still sees the
-    previous attempt's ``gen`` joins a generation nobody else is in; it times out on the first exchange
-    (``join_timeout``) and re-reads ``gen``.  ``close`` is acknowledged: files go only after every rank
+    previous attempt's ``gen`` joins a generation nobody else is in; every ``join_timeout`` without an ack it
+    re-reads ``gen`` and joins again once the nonce has changed (a late ack alone is not a reason to leave: rank 0
+    acknowledges only after the LAST rank has joined).  ``close`` is acknowledged: files go only after every rank
     has said it will read no more."""
 
     def __init__(self, rank: int, world: int, directory: Optional[str] = None, timeout: float = 300.0,
@@ -85,21 +86,40 @@ class FileRendezvous:
             tokens = self._collect("join", self.timeout)
             self._publish(b",".join(tokens), "ack")
             return self.gen
-        tried = set()
+        # A late ack is NOT a stale generation: rank 0 acks only once EVERY rank has joined, so with three or more ranks
+        # an early rank may wait for a straggler far longer than ``join_timeout``.  The join file and its token stay in
+        # place while ``gen`` is unchanged; the rank re-joins only when ``gen`` has changed (rank 0 of a new attempt
+        # purged the directory), when its files were purged under it, or when the ack of this generation does not echo
+        # its token (a complete-looking dead attempt).  Only such a generation is skipped from then on.
+        dead = set()
         while True:
-            self.gen = self._read(gen_path, deadline, skip=tried)
+            self.gen = self._read(gen_path, deadline, skip=dead)
             token = os.urandom(8).hex().encode()
+            self._mine = []
             try:
                 self._publish(token, "join")
-                ack = self._collect("ack", join_timeout, ranks=(0,))[0].split(b",")
-                if len(ack) == self.world and ack[self.rank] == token:
-                    return self.gen
-            except (TimeoutError, OSError):                    # (OSError: rank 0 purged the directory under us)
-                pass
-            tried.add(self.gen)                                # a stale generation: wait for rank 0's new one
-            self._mine = []
-            if time.monotonic() > deadline:
-                raise TimeoutError(f"rendezvous: no live generation appeared in {self.dir}")
+            except OSError:                                    # rank 0 purged the directory under us: read ``gen`` again
+                continue
+            while True:
+                try:
+                    ack = self._collect("ack", join_timeout, ranks=(0,))[0].split(b",")
+                    if len(ack) == self.world and ack[self.rank] == token:
+                        return self.gen
+                    dead.add(self.gen)                         # an ack that cannot be about this join: a dead attempt
+                    break
+                except TimeoutError:
+                    pass
+                except OSError:
+                    break
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"rendezvous: rank 0 never acknowledged generation {self.gen} in {self.dir}")
+                try:
+                    with open(gen_path, "r") as f:
+                        current = f.read()
+                except OSError:
+                    current = ""                               # mid-purge: the new ``gen`` is about to appear
+                if current != self.gen or not os.path.exists(self._mine[-1]):
+                    break                                      # a new generation (or our join file is gone): join again
 
     def _read(self, path: str, deadline: float, skip=()) -> str:
         delay = 1e-4
