@@ -139,6 +139,19 @@ def _profiled(key):
         return None
 
 
+def _measured_flop(kernel, items):
+    """fp64 operations of one launch of `kernel` COUNTED by the hardware (profiles/pmc_flops.json, written by
+    scripts/profile_flops.py from a `rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64
+    SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64` pass over this very command): wave-instructions x 64 lanes (fma = 2;
+    lanes masked off by EXEC are counted as if active -- an upper bound on useful work) + MFMA operations.  Returns flop per
+    item of a launch of `items` items, or None when no such pass is on file."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_flops.json")))[f"{kernel}@{items}"]
+        return float(rec["flop_per_launch"]) / float(rec["items_per_launch"])
+    except Exception:
+        return None
+
+
 # ================================================================================== flop accounting
 def pgdb2q_executed_flop(m, S, iters, dyk, backtracks, work):
     """Floating-point operations the 2-qubit kernel EXECUTES for one reconstruction (mean over the
@@ -169,7 +182,7 @@ def pgdb3q_executed_flop(m, S, iters, dyk, work):
     it, dy = float(np.mean(iters)), float(np.mean(dyk))
     f = {}
     f["jacobi_sweeps"] = sweeps * 63 * 1024 * 162
-    f["basis_change"] = dy * 2 * 64 ** 3 * 8                       # V^H H V as two dense complex 64^3 products (VALU)
+    f["basis_change_mfma"] = dy * 2 * 64 ** 3 * 8                  # V^H H V as two dense complex 64^3 products on the fp64 matrix cores
     f["reconstruct"] = terms * 1024 * 28
     f["dykstra_rest"] = dy * 1024 * 240
     f["tables_mfma"] = it * 3 * 2 * S * 64 * 64                    # T = C^T R^T (x2) and R^G = -W C^T / d^2 on the fp64 matrix cores
@@ -229,6 +242,40 @@ def cpu_baseline_and_parity(design, us, e, c, n_items, iters, gpu_fixed, gpu_con
                                    "sample": f"first {n_faith} items to convergence with the design matrix "
                                              f"rebuilt per call as tomography.py:494-539 does, {dt_faith:.1f} s"}}
     return base, [par_fixed, par_conv]
+
+
+def fixture_parity(batch, gpu_fixed, gpu_conv, iters):
+    """The timed launch against the COMMITTED REFERENCE FIXTURES: tests/golden/process_2q_pauli_fixed100.npz holds, for the
+    first 64 items of this very batch, what the reference itself (tests/golden/make_goldens.py --fixed2q, run in the build
+    container) produced -- the estimate after exactly 100 iterations, the estimate and iteration count at its own stopping point,
+    per-iteration Dykstra counts.  Returns the deviation histogram of both modes (share of items <= 1e-9 / <= 1e-8, the
+    maximum, the largest process-fidelity difference), or None when the fixture does not describe this batch."""
+    fn = os.path.join(ROOT, "tests", "golden", f"process_2q_{batch.design.in_basis if hasattr(batch.design, 'in_basis') else 'pauli'}_fixed100.npz")
+    if iters != 100 or not os.path.exists(fn):
+        return None
+    g = np.load(fn)
+    n = int(g["expectations"].shape[0])
+    if n > batch.B or not (np.array_equal(g["expectations"], batch.e[:n]) and np.array_equal(g["counts"], batch.c[:n])):
+        return None
+    _, _, so, om = _oracle()
+
+    def fid(choi, b):
+        return om.process_fidelity(so.kraus2pauli_liouville([g["unitaries"][b]]), so.choi2pauli_liouville(choi))
+
+    out = []
+    for label, (choi_g, st_g), want, last in (
+            (f"fixed {iters} iterations (the timed launch)", gpu_fixed, g["pgdb_fixed"], np.full(n, iters)),
+            ("converge (reference semantics, tomography.py:589)", gpu_conv, g["pgdb_conv"], g["conv_iter"])):
+        dev = np.abs(choi_g[:n] - want).reshape(n, -1).max(axis=1)
+        fdev = np.array([abs(fid(choi_g[b], b) - fid(want[b], b)) for b in range(n)])
+        dyk_ref = np.array([int(g["dykstra"][b][:int(last[b])].sum()) for b in range(n)])
+        out.append({"mode": label, "items": n, "against": "reference-generated fixtures " + os.path.relpath(fn, ROOT),
+                    "share_le_1e-9": float((dev <= 1e-9).mean()), "share_le_1e-8": float((dev <= 1e-8).mean()),
+                    "max_abs_choi_diff": float(dev.max()), "median_abs_choi_diff": float(np.median(dev)),
+                    "max_process_fidelity_diff": float(fdev.max()),
+                    "outer_iteration_mismatches": int((np.asarray(st_g["iterations"][:n]) != last).sum()),
+                    "dykstra_total_mismatches": int((np.asarray(st_g["dykstra"][:n]) != dyk_ref).sum())})
+    return out
 
 
 _POOL_WORKER = r"""
@@ -374,6 +421,7 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
     flop = args.iters * 3 * (2 * m) * 4096 * 8 + float(dyk.mean()) * (25 * 64 ** 3 + 2 * 64 ** 3 * 8)
     tflops = B * flop / ksec / 1e12
     ex, parts = pgdb3q_executed_flop(m, design.n_states, its, dyk, work)
+    meas = _measured_flop("pgdb3_kernel<4>" if basis == "sic" else "pgdb3_kernel<14>", B)
     line = {"metric": "process-tomography MLE reconstructions/sec (3-qubit, 64x64 Choi, 100 iters)",
             "value": comm.world * B * steps / elapsed, "unit": "reconstructions/s", "n_gpus": comm.world,
             "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": 1e3 * elapsed / steps,
@@ -386,14 +434,18 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
                        "iters": args.iters, "parallelism": f"shard{comm.world}",
                        "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean()),
                        "max_over_mean_jacobi_sweeps": float(work[:, 0].max() / work[:, 0].mean())},
-            "roofline": {"bound": "mfma", "pipe": "fp64 VALU + LDS", "achieved": B * ex / ksec / 1e12, "peak": FP64_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU + fp64 MFMA (basis changes, table products) + LDS",
+                         "achieved": B * ex / ksec / 1e12, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
+                         "executed_flop_measured": meas,
+                         "measured_frac": (B * meas / ksec / 1e12 / FP64_PEAK_TFLOPS) if meas else None,
                          "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch") if basis == "sic" else None,
                          "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
                          "executed_flop": ex, "executed_breakdown": {k: round(v) for k, v in parts.items()},
-                         "dense_formulation_tflops": tflops,
+                         "dense_accounting_tflops": tflops, "dense_accounting_frac": tflops / FP64_PEAK_TFLOPS,
                          "note": "achieved / frac = flops the Kronecker-form kernel really performs per reconstruction, from its "
-                                 "work counters (DESIGN.md 2.2), x batch / HIP-event kernel time.  dense_formulation_tflops = the "
+                                 "work counters (DESIGN.md 2.2), x batch / HIP-event kernel time; executed_flop_measured = the "
+                                 "hardware's count of the same launch (profiles/pmc_flops.json).  dense_accounting_tflops = the "
                                  "same launch priced in the reference's dense formulation (3 x 2m x 4096 complex MACs per outer "
                                  "iteration + ~25 N^3 per 64 x 64 eigendecomposition): an accounting figure that exceeds the fp64 "
                                  "peak for the Pauli in-basis, because the dense A products it counts are never executed"}}
@@ -443,6 +495,7 @@ def run_pgdb1(args, comm, _lib, synthetic, with_cpu):
             "roofline": {"bound": "mfma", "pipe": "fp64 VALU (one reconstruction per lane)", "achieved": B * ex / ksec / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
                          "traffic": None, "kernel": "pgdb1_packed_kernel", "kernel_ms": 1e3 * ksec, "executed_flop": ex,
+                         "executed_flop_measured": _measured_flop("pgdb1_packed_kernel", B),
                          "note": "flops executed per reconstruction (work counters x per-unit counts from the source) x batch / "
                                  "HIP-event kernel time; lanes idle through divergence (a wavefront runs the longest Dykstra / "
                                  "line-search trip count of its 64 lanes) are not counted as work"}}
@@ -505,25 +558,35 @@ class PgdbBatch:
 
 
 def pgdb_roofline(batch, st, kernel_s, iters):
+    """`achieved` / `frac`: the flops the kernel EXECUTES (per-item work counters x per-unit counts from the source; next to
+    it the hardware's own count of the same launch when a PMC pass is on file) / HIP-event kernel time, against the fp64 peak.
+    The reference's dense-A pricing of SURVEY.md 8d is kept as `dense_accounting_*`: it counts A-products the Kronecker-form
+    kernel never performs and exceeds the peak at large batches, so it is not a utilisation figure."""
     B, m, S = batch.B, batch.design.m, batch.design.n_states
-    achieved = B * ALGO_FLOP_PER_RECON * (iters / 100.0) / kernel_s / 1e12
+    dense = B * ALGO_FLOP_PER_RECON * (iters / 100.0) / kernel_s / 1e12
     ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"])
     algo_bytes = 2 * m * 8 + 4096
-    return {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-            "traffic": _profiled("pgdb_kernel_hbm_bytes_per_launch") if B == 1024 else None,
-            "kernel": ("pgdb_lean_kernel" if B >= 2048 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>"),
-            "kernel_ms": 1e3 * kernel_s,
-            "executed_flop": ex, "executed_tflops": B * ex / kernel_s / 1e12,
-            "executed_frac": B * ex / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
-            "executed_breakdown": {k: round(v) for k, v in parts.items()},
-            "note": "PGDB is fp64-compute / latency bound (SURVEY.md 8d).  achieved = the agreed numerator, 0.77 GFLOP "
-                    "per reconstruction in the reference's dense-A formulation, x batch / HIP-event kernel time: an "
-                    "ACCOUNTING figure (86 % of it is dense A-GEMV work the Kronecker-form kernel never performs).  "
-                    "executed_* = flops the kernel really executes per reconstruction, from its per-item work "
-                    "counters (Jacobi sweeps, eigenvalue terms, cost evaluations): the utilisation figure.",
-            "hbm": {"achieved": B * algo_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": B * algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": B * algo_bytes}}
+    kernel = ("pgdb_lean_kernel" if B >= 1280 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
+    measured = _measured_flop(kernel, B)
+    out = {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": B * ex / kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,
+           "unit": "TFLOP/s", "frac": B * ex / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
+           "traffic": _profiled({1024: "pgdb_kernel_hbm_bytes_per_launch", 8192: "pgdb_lean8192_hbm_bytes_per_launch",
+                                 65536: "pgdb_lean65536_hbm_bytes_per_launch"}.get(B, "-")),
+           "kernel": kernel, "kernel_ms": 1e3 * kernel_s,
+           "executed_flop": ex, "executed_breakdown": {k: round(v) for k, v in parts.items()},
+           "executed_flop_measured": measured,
+           "measured_frac": (B * measured / kernel_s / 1e12 / FP64_PEAK_TFLOPS) if measured else None,
+           "dense_accounting_tflops": dense, "dense_accounting_frac": dense / FP64_PEAK_TFLOPS,
+           "note": "PGDB is fp64-compute / latency bound (SURVEY.md 8d).  achieved / frac = flops the kernel really executes "
+                   "per reconstruction (work counters: Jacobi sweeps, eigenvalue terms, cost evaluations; x per-unit counts "
+                   "from the source, fma = 2) x batch / HIP-event kernel time / 78.6 TFLOP/s.  executed_flop_measured = the "
+                   "same launch counted by SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes + SQ_INSTS_VALU_MFMA_MOPS_F64 "
+                   "(profiles/pmc_flops.json; EXEC-masked lanes included, so an upper bound).  dense_accounting_* = SURVEY "
+                   "8d's agreed 0.77 GFLOP per reconstruction in the reference's dense-A formulation: an accounting "
+                   "figure (86 % of it is A-GEMV work the Kronecker-form kernel never performs; it exceeds 1 at 65 536 items)",
+           "hbm": {"achieved": B * algo_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": B * algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": B * algo_bytes}}
+    return out
 
 
 def run_pgdb(args, comm, _lib, synthetic, rank_info):
@@ -609,6 +672,7 @@ def strong_anchor(args, comm, _lib, synthetic):
            "kernel": "pgdb_lean_kernel<2,9>" if batch.design.m > 256 else "pgdb_lean_kernel<2,4>",
            "mean_outer_iters": float(st["iterations"].mean()), "mean_dykstra_iters": float(st["dykstra"].mean()),
            "mean_jacobi_sweeps": float(st["work"][:, 0].mean()), "host_input_generation_s": t_gen,
+           "roofline": pgdb_roofline(batch, st, kms / 1e3 / steps, args.iters),
            "note": "compare bench.py --gpus N (value = the same 65 536 items block-partitioned over N ranks) with THIS "
                    "figure, not with the 1024-item headline"}
     # ---- the same with the transfers inside (SURVEY 8d's metric): page-locked host buffers, pipelined in stages
@@ -652,11 +716,12 @@ def single_gpu_extras(args, comm, _lib, synthetic, batch, line):
     from fbx import tomography
     B, iters = batch.B, args.iters
     n_cpu = min(args.cpu_sample, B)
-    gpu_fixed = (batch.choi(n_cpu), batch.stats()) if n_cpu else None
+    n_fix = min(64, B)
+    gpu_fixed = (batch.choi(n_fix), batch.stats())
     # ---- converge mode: the reference's own semantics (stop at delta cost < 1e-10)
     el, km = timed_steps(lambda: batch.launch(_lib.MODE_CONVERGE, 0), args.steps, 1, comm, _lib)
     stc = batch.stats()
-    gpu_conv = (batch.choi(n_cpu), stc) if n_cpu else None
+    gpu_conv = (batch.choi(n_fix), stc)
     line["converge_mode"] = {"value": B * args.steps / el, "unit": "reconstructions/s",
                              "ms_per_step": 1e3 * el / args.steps, "kernel_ms": km / args.steps,
                              "mean_outer_iters": float(stc["iterations"].mean()),
@@ -705,6 +770,9 @@ def single_gpu_extras(args, comm, _lib, synthetic, batch, line):
         base, parity = cpu_baseline_and_parity(batch.design, batch.us, batch.e, batch.c, n_cpu, iters, gpu_fixed, gpu_conv)
         line["cpu_baseline"] = base
         line["parity_self_check"] = parity
+    fx = fixture_parity(batch, gpu_fixed, gpu_conv, iters)
+    if fx is not None:
+        line["parity_vs_reference_fixtures"] = fx
         line["cpu_baseline_multicore"] = cpu_baseline_pool(batch.design, batch.e, batch.c, iters)
 
 

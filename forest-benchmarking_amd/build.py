@@ -16,12 +16,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #                      its speed with it -- hence the two translation units.
 #   fbx_pgdb3.hip      3-qubit kernel (1024-thread workgroups, 128 registers): 360.6 -> 335.0 ms per 256 reconstructions (-7 %).
 #   fbx_pgdb1.hip      lane-per-item single-qubit kernel: no difference (66.4 vs 66.8 ms), default kept.
-#   fbx_pgdb_lean.hip  two-wavefronts-per-SIMD kernel (256 registers, spilling): -Os instead of -O3 -- 560 instead of 664 B of scratch,
-#                      8192 items 73.2 -> 71.2 ms (-Oz: 76 ms; -Os on the other two PGDB units: 5 % slower).
+#   fbx_pgdb_lean.hip  two-wavefronts-per-SIMD kernel (256 registers): -Os instead of -O3 (round 3: 560 instead of 664 B of scratch,
+#                      8192 items 73.2 -> 71.2 ms; round 4, after the kernel's re-layout: 66.3 against 71.5 ms -- the -O3 code of the
+#                      540-setting instantiation is larger than the 64 KB instruction cache eight wavefronts share) and no machine
+#                      LICM: loop-invariant per-lane addresses and masks hoisted out of the outer loop were what still spilled
+#                      (70 -> 38 spilled registers, 62.0 -> 61.5 ms per 8192 reconstructions).
 _MAX_ILP = "-mllvm -amdgpu-sched-strategy=max-ilp"
 FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", _MAX_ILP).split(),
               "fbx_pgdb3.hip": os.environ.get("FBX_PGDB3_FLAGS", _MAX_ILP).split(),
-              "fbx_pgdb_lean.hip": os.environ.get("FBX_PGDB_LEAN_FLAGS", "-Os").split()}
+              "fbx_pgdb_lean.hip": os.environ.get("FBX_PGDB_LEAN_FLAGS", "-Os -mllvm -disable-machine-licm").split()}
 
 
 def file_flags(src):

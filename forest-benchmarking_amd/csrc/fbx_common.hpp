@@ -256,6 +256,26 @@ __device__ __forceinline__ double uniform(double v) {
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Raw buffer access (buffer_load / buffer_store with an SGPR resource, ONE 32-bit VGPR byte offset and an SGPR / immediate row
+// offset) for per-lane rows of a wave-private slice: no 64-bit per-lane address arithmetic, which the compiler otherwise hoists
+// out of the outer loop (one VGPR pair per 4 KB of rows) and then spills.  Reads beyond `bytes` return zero.
+typedef unsigned fbx_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned fbx_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const fbx_v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)w.y, (int)w.x);
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    fbx_v2u w; w.x = (unsigned)__double2loint(v); w.y = (unsigned)__double2hiint(v);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+}
+__device__ __forceinline__ unsigned buf_load_u32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+
 // 1/sqrt(x) for normal positive x to ~1 ulp: hardware estimate (v_rsq_f64, ~2^-26) refined by
 // one cubically convergent step  y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2.
 // Avoids the IEEE sqrt / divide expansions in the Jacobi rotation's dependent chain.

@@ -28,10 +28,9 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
             int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
             double* __restrict__ cost_out, int* __restrict__ work_out,
             long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-            double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
+            int* __restrict__ trace_out, int trace_iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    (void)ncounts;
-    pgdb_body<NQ, MAXJ, false>(smem, nullptr, blockIdx.x, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+    pgdb_body<NQ, MAXJ, false>(smem, blockIdx.x, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
                                dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, nullptr,
                                trace_out, trace_iters);
 }
@@ -57,17 +56,11 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
                        int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
                        double* cost, int32_t* sw, const PgdbExtras& ex) {
     // batches that put several reconstructions on a SIMD take the lean two-waves-per-SIMD kernel (2 qubits)
-    const bool lean = NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH;
+    bool lean = NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH;
     size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
-    size_t wave_lds = 0;
-    bool lean4 = false;                    // the shared-table experiment of fbx_pgdb_lean.hip (fixed-iteration batches)
     if constexpr (NQ == 2) {
-        if (lean) {
-            lds = pgdb_lean_lds(MAXJ, des->dev.S, false, &wave_lds);
-            const size_t lds4 = pgdb_lean_lds(MAXJ, des->dev.S, true, &wave_lds);
-            lean4 = FBX_LEAN_SHARED_TABLE && mode == FBX_MODE_FIXED && 2 * lds4 <= 160 * 1024;
-            if (lean4) lds = lds4;
-        }
+        lean = lean && pgdb_lean_eligible(des->dev.S);
+        if (lean) lds = pgdb_lean_lds(MAXJ, des->dev.S);
     }
     if (lds > 160 * 1024) {
         set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
@@ -84,7 +77,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     // When the device cannot give that much, the launch size is halved until the store fits.
     const bool want_basis = !(mode == FBX_MODE_FIXED && max_iters <= 1) && !(mode == FBX_MODE_CONVERGE && max_iters == 1);
     const size_t basis_item = want_basis ? sizeof(cplx) * D * D * BASIS_CAP : 0;
-    const size_t counts_item = lean ? sizeof(double) * 2 * MAXJ * 64 : 0;
+    const size_t counts_item = lean ? sizeof(double) * 2 * MAXJ * 64 : 0;      // normalised counts of the lean kernel (fbx_pgdb_body.hpp)
     int64_t CHUNK = 65536;
     char* wsp = nullptr;
     int64_t ws_items = ex.ws_items > 0 ? ex.ws_items : (B < CHUNK ? B : CHUNK);
@@ -103,9 +96,6 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     const int64_t n_slots = ws_items;
     cplx* basis = basis_item ? (cplx*)wsp + (size_t)ex.ws_offset * D * D * BASIS_CAP : nullptr;
     double* ncounts = counts_item ? (double*)(wsp + basis_item * (size_t)n_slots) + (size_t)ex.ws_offset * 2 * MAXJ * 64 : nullptr;
-#ifdef FBX_LEAN_RECOUNT      // experiment: the lean kernel recomputes the counts from the inputs at every use
-    ncounts = nullptr;
-#endif
     const size_t m = des->dev.m;
     DesignDev dev = des->dev;
     dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(NQ);     // per call, else the process default
@@ -120,13 +110,13 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
         a.trace_iters = ex.trace_iters;
         if constexpr (NQ == 2) {
             if (lean) {
-                const int rc = pgdb_lean_launch(MAXJ, lds, wave_lds, lean4, st, a);
+                const int rc = pgdb_lean_launch(MAXJ, lds, st, a);
                 if (rc) return rc;
                 continue;
             }
         }
         hipLaunchKernelGGL((pgdb_kernel<NQ, MAXJ>), dim3((unsigned)nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
-                           a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters);
+                           a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.trace, a.trace_iters);
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;

@@ -7,16 +7,6 @@
 #include "fbx_choi.hpp"
 #include <cstdlib>
 #include <vector>
-#ifndef FBX_LEAN_CL_LDS
-#define FBX_LEAN_CL_LDS 0           // experiment: the lean kernel keeps its own LDS copy of the Bloch matrix (7 instead of 8 waves per CU)
-#endif
-#ifndef FBX_LEAN_SHARED_TABLE
-#define FBX_LEAN_SHARED_TABLE 0     // experiment (fixed-iteration batches): four reconstructions per workgroup share an LDS copy of the
-                                    // Bloch matrix -- measured 6 % SLOWER at 8192 items than the one-wavefront workgroups
-#endif
-#ifndef FBX_LEAN_LN_LDS
-#define FBX_LEAN_LN_LDS 0           // experiment: the lean kernel keeps the normalised counts in LDS (25.7 KB per wavefront: 6 instead of 8 per CU)
-#endif
 #ifndef FBX_LEAN_MIN_BATCH
 #define FBX_LEAN_MIN_BATCH 1280     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits): measured crossover with the
                                     // one-wave kernel between 1100 and 1280 reconstructions in both modes (1280: 18.8 against 20.4 ms)
@@ -50,45 +40,55 @@ constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
 #define FBX_SMALL_STEP_LIMIT 0x1p-3      // alpha * max |pu / pe| below which the line search uses the power-sum series
 #endif
 
-// LEAN (2 waves per SIMD at large batches): 16.5 KB instead of 39 KB per reconstruction -- the Bloch matrix is
-// read from L2 (DesignDev::Ct), the normalised counts are recomputed from the inputs (L2) wherever they are
-// used, and ONE prediction table serves the estimate and the update direction in turn (the estimate's table
-// is rebuilt after the projection).
+// LEAN (2 waves per SIMD at large batches): 19.4 KB instead of 39 KB per reconstruction, so that eight wavefronts share a CU's
+// 160 KB.  The Bloch matrix is read through L2 (DesignDev::Ct); the normalised counts n+- live in REGISTERS (2 MAXJ doubles per
+// lane) and the model probabilities of an outcome are recomputed from the two prediction tables wherever they are used (four
+// ds_read_b64 and four flops per setting -- the one-wave kernel keeps them in 8 MAXJ registers); the Pauli-coefficient matrix Rb
+// aliases the tail of Vs, which is dead whenever Rb is live (outside a projection; the transforms stage through the front of
+// Ms + Vs), and the gradient is parked in Tupd alone while the projection runs.  Round 3's form kept ONE table and the counts in
+// an L2 workspace: 72 + registers of per-outcome probabilities, 216 spilled registers and ~9 KB of L2 reads per cost evaluation.
 template <int NQ, bool LEAN = false>
 struct PgdbLds {
     ChoiLds<NQ, LEAN> choi;
-    double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time), TRANSPOSED: Rb[j * D + i] = R[i][j]
-    double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate           (LEAN: = Tupd)
+    double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time), TRANSPOSED: Rb[j * D + i] = R[i][j]   (LEAN: inside Vs)
+    double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
     double* Tupd;   // [S*D]  same for the update direction; reused as Wt[S][D] in the gradient
     double* Cl;     // [S*D]  Bloch coefficients of the input states, one state per row: Cl[s * D + j] = C[j][s]   (LEAN: none)
     double* Ln;     // [2*ceil(m/64)][64]  normalised counts n+ / n- of this lane's outcomes (row 2 j + sign): item
-                    // constants that are only read by the cost / gradient passes -- kept here, not in 36 registers (LEAN: none)
-    // Rb and Tupd are adjacent: both are dead while the projection runs, and together (>= 16 D^2 bytes,
-    // Tupd is sized for at least D states) they park the gradient block of every lane meanwhile
+                    // constants that are only read by the cost / gradient passes -- kept here, not in 36 registers (LEAN: registers)
+    double* park;   // [2*D*D] the gradient block of every lane while the projection runs: Rb + Tupd (adjacent, both dead
+                    // meanwhile; Tupd is sized for at least D states); LEAN: Tupd alone (sized for at least 2 D states)
+    static constexpr int D = ChoiLds<NQ>::D;
+    static constexpr size_t tupd_rows(int S) { return LEAN ? (S > 2 * D ? S : 2 * D) : (S > D ? S : D); }
     static size_t bytes(int S, int m) {
-        constexpr int D = ChoiLds<NQ>::D;
-        const size_t Su = S > D ? S : D;
+        const size_t Su = tupd_rows(S);
         const size_t base = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
-        if (LEAN) return base + sizeof(double) * ((size_t)D * D + Su * D + (FBX_LEAN_CL_LDS ? (size_t)S * D : 0) + (FBX_LEAN_LN_LDS ? 2 * (size_t)((m + 63) / 64) * 64 : 0)) + 64;
+        if (LEAN) return base + sizeof(double) * ((Su + (size_t)S) * D) + 64;
         return base + sizeof(double) * ((size_t)D * D + (Su + 2 * (size_t)S) * D + 2 * (size_t)((m + 63) / 64) * 64) + 64;
     }
     // every pointer is a plain offset from the start of the dynamic LDS segment (no conditional
     // layout), so the compiler keeps them in the LDS address space (ds_* instead of flat_*)
     __device__ void carve(char* p, int S, int m) {
-        constexpr int D = ChoiLds<NQ>::D;
         char* q = p;
         choi.carve(q);
         // (rounding the POINTER up through an integer cast would turn everything behind it into
         // generic-address-space pointers: flat_load / flat_store instead of ds_read / ds_write)
         constexpr size_t aligned = (ChoiLds<NQ, LEAN>::bytes() + 15) & ~(size_t)15;
         p += aligned;
-        Rb = (double*)p; p += sizeof(double) * D * D;
-        Tupd = (double*)p; p += sizeof(double) * (S > D ? S : D) * D;
-        if constexpr (LEAN) { Test = Tupd; Cl = FBX_LEAN_CL_LDS ? (double*)p : nullptr; if (FBX_LEAN_CL_LDS) p += sizeof(double) * D * S; Ln = FBX_LEAN_LN_LDS ? (double*)p : nullptr; }
-        else {
+        if constexpr (LEAN) {
+            static_assert(sizeof(cplx) * D * (D + 1) + sizeof(double) * D * D <= 2 * sizeof(cplx) * sys_elems<D>(),
+                          "the transforms' staging matrix and Rb must both fit into Ms + Vs");
+            Rb = (double*)(choi.Vs + sys_elems<D>()) - D * D;
+            Tupd = (double*)p; p += sizeof(double) * tupd_rows(S) * D;
+            Test = (double*)p; p += sizeof(double) * S * D;
+            Cl = nullptr; Ln = nullptr; park = Tupd;
+        } else {
+            Rb = (double*)p; p += sizeof(double) * D * D;
+            Tupd = (double*)p; p += sizeof(double) * tupd_rows(S) * D;
             Test = (double*)p; p += sizeof(double) * S * D;
             Cl = (double*)p; p += sizeof(double) * D * S;
             Ln = (double*)p; p += sizeof(double) * 2 * ((m + 63) / 64) * 64;
+            park = Rb;
         }
     }
 };
@@ -118,9 +118,9 @@ __device__ void predict_table(const double* Rb, const double* Ct, double* T, int
     }
 }
 
-template <int NQ, int MAXJ, bool LEAN, bool SHARED_CT = false>
+template <int NQ, int MAXJ, bool LEAN>
 __device__ __forceinline__ void
-pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev& des, long long B, const double* __restrict__ expect,
+pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const double* __restrict__ expect,
           const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
           double* __restrict__ choi_out, int* __restrict__ iters_out,
           int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
@@ -128,23 +128,50 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
           long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
           double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
+    // The passes over a lane's MAXJ outcome slots (cost, gradient weights, clip detection, power sums) are straight-line code in
+    // the one-wave kernel and LOOPS in the lean one (the slot index is wave-uniform: register arrays are indexed through
+    // s_set_gpr_idx): unrolled they are 6.4 KB of code per slot -- 58 of the 91 KB of the 540-setting instantiation, against a
+    // 64 KB instruction cache that eight wavefronts in eight different phases share.
+#ifndef FBX_FAT_SLOT_UNROLL
+#define FBX_FAT_SLOT_UNROLL MAXJ     // (experiment: 1 = the one-wave kernel loops over its slots too)
+#endif
+    constexpr int SLOT_UNROLL = LEAN ? 1 : FBX_FAT_SLOT_UNROLL;
     const int lane = threadIdx.x & 63;
     const long long item = item_;
     const int m = des.m, S = des.S;
     PgdbLds<NQ, LEAN> L;
     L.carve(smem, S, 64 * MAXJ);
 
-    // Bloch coefficients, one state per row: an LDS copy, or (LEAN) the design's own table through L2
+    // Bloch coefficients, one state per row.  One-wave kernel: an LDS copy for the whole reconstruction.  LEAN: a TRANSIENT copy at
+    // the front of Ms + Vs (where the transforms stage: dead as soon as Rb holds the coefficients), re-read from the design's
+    // [S][D] table (4.6 KB, shared by the batch: L1 / L2 hits, five 16-byte loads per lane) in front of each table product --
+    // the products then run from LDS like the one-wave kernel's (through L2 they were latency-bound loops: round 3's lean kernel
+    // spent 3.7 x the one-wave kernel's cycles in the transform / table phases, profiles/r04/phase_*.txt).  pgdb_lean_eligible()
+    // keeps designs whose table does not fit beside Rb (more than 50 states) on the one-wave kernel.
     const double* Ct;
-    if constexpr (LEAN && SHARED_CT) Ct = ct_shared;            // the workgroup's LDS copy (no run-time choice: the loads must stay ds_read, not flat)
-    else if constexpr (LEAN && !FBX_LEAN_CL_LDS) Ct = des.Ct;  // through L2
+    if constexpr (LEAN) Ct = (const double*)L.choi.Ms;
     else {
         for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
         Ct = L.Cl;
     }
+    auto stage_ct = [&]() __attribute__((always_inline)) {       // LEAN: des.Ct -> front of Ms + Vs (both sides 16-byte aligned)
+        if constexpr (LEAN) {
+            typedef __attribute__((address_space(1))) const fbx_v2d* gptr;
+            const gptr src = (gptr)des.Ct;
+            fbx_v2d* dst = (fbx_v2d*)L.choi.Ms;
+            for (int idx = lane; idx < (D / 2) * S; idx += 64) dst[idx] = src[idx];
+        }
+    };
 
     // ---- data: n+-[k] = counts * (1 +- e)/2 / grand_total   (tomography.py:528-538)
     double tot = 0.0;
+    // LEAN: the normalised counts and the design words of this lane's MAXJ slots are REGISTER copies that live from the
+    // gradient to the projection and from the projection to the end of the line search -- not across the projection, where the
+    // Dykstra state and the eigensolver need the registers: load_slots() re-reads them (coalesced rows of the item's slice of
+    // an L2-resident workspace; the design's own table) in front of the gradient pass and in front of the line search.
+    double nreg_p[LEAN ? MAXJ : 1], nreg_m[LEAN ? MAXJ : 1];
+    const __amdgpu_buffer_rsrc_t nc_rsrc = buf_rsrc(ncounts, LEAN ? 2 * MAXJ * 64 * 8 : 0);      // (raw buffer rows: fbx_common.hpp)
+    const __amdgpu_buffer_rsrc_t sp_rsrc = buf_rsrc(des.sp, 4u * (unsigned)m);                   // settings beyond m read as 0
     {
         double npl[MAXJ], nmi[MAXJ];
 #pragma unroll
@@ -160,93 +187,89 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
             }
         }
         tot = uniform(wave_sum(tot));
-        if constexpr (!LEAN || FBX_LEAN_LN_LDS) {
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
-            }
-        } else {
-            // LEAN: the same table in the item's slice of an L2-resident workspace (lane-contiguous rows: coalesced.  One run of
-            // 2 MAXJ doubles per lane -- a single address register instead of one per row -- measured 2.2 x slower: 64 cache lines per load)
-#ifndef FBX_LEAN_RECOUNT
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                ncounts[(2 * j) * 64 + lane] = npl[j] / tot; ncounts[(2 * j + 1) * 64 + lane] = nmi[j] / tot;
-            }
-#endif
+        for (int j = 0; j < MAXJ; ++j) {
+            if constexpr (LEAN) {
+                buf_store_f64(nc_rsrc, 8u * lane, 512u * (2 * j), npl[j] / tot); buf_store_f64(nc_rsrc, 8u * lane, 512u * (2 * j + 1), nmi[j] / tot);
+            } else { L.Ln[(2 * j) * 64 + lane] = npl[j] / tot; L.Ln[(2 * j + 1) * 64 + lane] = nmi[j] / tot; }
         }
     }
+    if constexpr (LEAN) {        // the update direction's table is read (times alpha = 0) by the very first cost evaluation
+        for (int idx = lane; idx < S * D; idx += 64) L.Tupd[idx] = 0.0;
+    }
     FBX_WAVE_SYNC();
-    // normalised counts of slot j: from LDS; LEAN: from the L2 workspace (written above by this very lane, so
-    // program order is all the ordering needed), or recomputed from the inputs with the same expressions
+    // normalised counts of slot j
     auto counts_of = [&](int j, double& np_, double& nm_) __attribute__((always_inline)) {
-        if constexpr (LEAN && !FBX_LEAN_LN_LDS) {
-#ifndef FBX_LEAN_RECOUNT
-            // (the launcher always provides the workspace: no second code path, whose operands the compiler would keep alive)
-            np_ = ncounts[(2 * j) * 64 + lane]; nm_ = ncounts[(2 * j + 1) * 64 + lane];
-#else       // experiment: recomputed from the inputs with the same expressions at every use
-            const int g = lane + 64 * j;
-            np_ = 0.0; nm_ = 0.0;
-            if (g < m) {
-                const int k = des.order[g];
-                const double e = expect[item * m + k], c = counts[item * m + k];
-                const double plus = (1.0 + e) / 2.0;
-                np_ = (c * plus) / tot; nm_ = (c * (1.0 - plus)) / tot;
-            }
-#endif
-        } else {
-            np_ = L.Ln[(2 * j) * 64 + lane]; nm_ = L.Ln[(2 * j + 1) * 64 + lane];
-        }
+        if constexpr (LEAN) { np_ = nreg_p[j]; nm_ = nreg_m[j]; }
+        else { np_ = L.Ln[(2 * j) * 64 + lane]; nm_ = L.Ln[(2 * j + 1) * 64 + lane]; }
     };
 
     const double half_dd = 0.5 / (double)(d * d);      // 1 / (2 d^2)
     const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
 
-    // per-setting design words stay in registers for the whole reconstruction
-    uint32_t spw[LEAN ? 1 : MAXJ];
-    if constexpr (!LEAN) {
+    // per-setting design words: in registers for the whole reconstruction (LEAN: see load_slots)
+    uint32_t spw[MAXJ];
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = lane + 64 * j;
-            spw[j] = g < m ? des.sp[g] : 0u;
-        }
+    for (int j = 0; j < MAXJ; ++j) {
+        const int g = lane + 64 * j;
+        spw[j] = g < m ? des.sp[g] : 0u;
     }
-    // (LEAN: re-read from the design where they are used -- coalesced L2 hits -- instead of MAXJ registers)
-    auto design_word = [&](int j) __attribute__((always_inline)) -> uint32_t {
-        if constexpr (LEAN) { const int g = lane + 64 * j; return g < m ? des.sp[g] : 0u; }
-        else return spw[j];
+    auto load_slots = [&]() __attribute__((always_inline)) {
+        if constexpr (LEAN) {
+            // (the compiler must neither keep the previous copies alive across the projection nor hoist these loads above it)
+            __asm__ volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                nreg_p[j] = buf_load_f64(nc_rsrc, 8u * lane, 512u * (2 * j)); nreg_m[j] = buf_load_f64(nc_rsrc, 8u * lane, 512u * (2 * j + 1));
+                spw[j] = buf_load_u32(sp_rsrc, 4u * lane, 256u * j);
+            }
+        }
     };
     const bool unit_coefs = des.unit_coefs != 0;      // wave-uniform: coefficients re-read only when needed
+    // model probabilities of an owned setting's two outcomes from a prediction table (`missing` for lanes without one)
+    auto table_probs = [&](const double* T, int j, double missing, double& a, double& b) __attribute__((always_inline)) {
+        const int g = lane + 64 * j;
+        a = missing; b = missing;
+        if (g < m) {
+            const uint32_t dw = spw[j];
+            const int s = dw >> 16, p = dw & 0xffff;
+            const double cf = unit_coefs ? 1.0 : des.coef[g];
+            const double tr = T[s * D], ex = cf * T[s * D + p];
+            a = (tr + ex) * half_dd; b = (tr - ex) * half_dd;
+        }
+    };
     // model probabilities of the current estimate (pe) and of the update direction (pu), per owned
-    // setting and outcome: p(alpha) = pe + alpha * pu, so a line-search step touches no memory
-    double pep[MAXJ], pem[MAXJ], pup[MAXJ], pum[MAXJ];
+    // setting and outcome: p(alpha) = pe + alpha * pu.  One-wave kernel: register arrays, so a line-search step
+    // touches no memory.  LEAN: recomputed from the two tables at every use (same expressions, same bits).
+    double pep[LEAN ? 1 : MAXJ], pem[LEAN ? 1 : MAXJ], pup[LEAN ? 1 : MAXJ], pum[LEAN ? 1 : MAXJ];
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
+        for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
+    }
     // (every slot is assigned -- `missing` for lanes without an outcome -- so that the arrays are dead
     // between two calls and do not occupy registers across the projection)
-    auto load_probs = [&](const double* T, double (&pp)[MAXJ], double (&pm)[MAXJ], double missing) {
+    auto load_probs = [&](const double* T, double* pp, double* pm, double missing) __attribute__((always_inline)) {
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int g = lane + 64 * j;
-            double a = missing, b = missing;
-            if (g < m) {
-                const uint32_t dw = design_word(j);
-                const int s = dw >> 16, p = dw & 0xffff;
-                const double cf = unit_coefs ? 1.0 : des.coef[g];
-                const double tr = T[s * D], ex = cf * T[s * D + p];
-                a = (tr + ex) * half_dd; b = (tr - ex) * half_dd;
-            }
-            pp[j] = a; pm[j] = b;
+            for (int j = 0; j < MAXJ; ++j) table_probs(T, j, missing, pp[j], pm[j]);
         }
+    };
+    auto pe_of = [&](int j, double& a, double& b) __attribute__((always_inline)) {
+        if constexpr (LEAN) table_probs(L.Test, j, 1.0, a, b); else { a = pep[j]; b = pem[j]; }
+    };
+    auto pu_of = [&](int j, double& a, double& b) __attribute__((always_inline)) {
+        if constexpr (LEAN) table_probs(L.Tupd, j, 0.0, a, b); else { a = pup[j]; b = pum[j]; }
     };
     // negative log-likelihood at est + alpha * update (tomography.py:597-614)
     auto cost_at = [&](double alpha) __attribute__((always_inline)) -> double {
         double acc = 0.0;
-#pragma unroll
+#pragma unroll SLOT_UNROLL
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
             if (g < m) {
-                double pp = fma(alpha, pup[j], pep[j]), pm = fma(alpha, pum[j], pem[j]);
+                double ep_, em_, up_, um_;
+                pe_of(j, ep_, em_); pu_of(j, up_, um_);
+                double pp = fma(alpha, up_, ep_), pm = fma(alpha, um_, em_);
                 pp = pp < PGDB_EPS ? PGDB_EPS : pp;
                 pm = pm < PGDB_EPS ? PGDB_EPS : pm;
                 double np_, nm_;
@@ -306,8 +329,11 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
         FBX_WAVE_SYNC();
         choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
         FBX_WAVE_SYNC();
+        stage_ct();                                 // (LEAN) stays in place for the gradient product below
+        FBX_WAVE_SYNC();
         PH_STOP(pc, 3);
         predict_table<NQ>(L.Rb, Ct, L.Test, S, lane);
+        load_slots();
         FBX_WAVE_SYNC();
         PH_STOP(pc, 7);
         load_probs(L.Test, pep, pem, 1.0);
@@ -320,17 +346,19 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
         double* Wt = L.Tupd;                        // [S][D]
         for (int idx = lane; idx < D * S; idx += 64) Wt[idx] = 0.0;
         FBX_WAVE_SYNC();
-#pragma unroll
+#pragma unroll SLOT_UNROLL
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
             if (g < m) {
-                const double pp = pep[j] < PGDB_EPS ? PGDB_EPS : pep[j];
-                const double pm = pem[j] < PGDB_EPS ? PGDB_EPS : pem[j];
+                double ep_, em_;
+                pe_of(j, ep_, em_);
+                const double pp = ep_ < PGDB_EPS ? PGDB_EPS : ep_;
+                const double pm = em_ < PGDB_EPS ? PGDB_EPS : em_;
                 double np_, nm_;
                 counts_of(j, np_, nm_);
                 const double ep = np_ / pp, em = nm_ / pm;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
-                const uint32_t dw = design_word(j);
+                const uint32_t dw = spw[j];
                 const int st = dw >> 16, p = dw & 0xffff;
                 atomicAdd(&Wt[st * D], 0.5 * (ep + em));
                 atomicAdd(&Wt[st * D + p], cf * 0.5 * (ep - em));
@@ -364,11 +392,11 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
             // ---- projected step (tomography.py:572)
             x = blk_axpy(est, -inv_mu, grad);
             // the gradient is needed again after the projection (inner product with the update): parked in
-            // Rb + Tupd, not in 16 registers across the Dykstra loop
+            // Rb + Tupd (LEAN: Tupd), not in 16 registers across the Dykstra loop
             FBX_WAVE_SYNC();
             if (lane < NACT) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { L.Rb[(2 * e) * NACT + lane] = grad.re[e]; L.Rb[(2 * e + 1) * NACT + lane] = grad.im[e]; }
+                for (int e = 0; e < 4; ++e) { L.park[(2 * e) * NACT + lane] = grad.re[e]; L.park[(2 * e + 1) * NACT + lane] = grad.im[e]; }
             }
             FBX_WAVE_SYNC();
         }
@@ -392,7 +420,7 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
         Blk grad = blk_zero();
         if (lane < NACT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { grad.re[e] = L.Rb[(2 * e) * NACT + lane]; grad.im[e] = L.Rb[(2 * e + 1) * NACT + lane]; }
+            for (int e = 0; e < 4; ++e) { grad.re[e] = L.park[(2 * e) * NACT + lane]; grad.im[e] = L.park[(2 * e + 1) * NACT + lane]; }
         }
         double ipr, ipi;
         blk_dotc(upd, grad, ipr, ipi);
@@ -400,27 +428,17 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
         PH_STOP(pc, 2);
 
         // ---- prediction tables for the line search
-        if constexpr (LEAN) {
-            // one table buffer: the estimate's table was overwritten by the gradient weights -- rebuilt here
-            // (one more transform + table product per outer iteration, ~1 % of it) and read, before the
-            // update direction's takes its place
-            FBX_WAVE_SYNC();
-            blk_store<D, LD>(L.choi.Mw, lane, est);
-            FBX_WAVE_SYNC();
-            choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
-            FBX_WAVE_SYNC();
-            predict_table<NQ>(L.Rb, Ct, L.Test, S, lane);
-            FBX_WAVE_SYNC();
-            load_probs(L.Test, pep, pem, 1.0);
-        }
         FBX_WAVE_SYNC();
         blk_store<D, LD>(L.choi.Mw, lane, upd);
         FBX_WAVE_SYNC();
         choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
         FBX_WAVE_SYNC();
-        predict_table<NQ>(L.Rb, Ct, L.Tupd, S, lane);
+        stage_ct();
         FBX_WAVE_SYNC();
-        if constexpr (!LEAN) load_probs(L.Test, pep, pem, 1.0);      // again: not kept in registers across the projection
+        predict_table<NQ>(L.Rb, Ct, L.Tupd, S, lane);
+        load_slots();
+        FBX_WAVE_SYNC();
+        load_probs(L.Test, pep, pem, 1.0);      // again: not kept in registers across the projection
         load_probs(L.Tupd, pup, pum, 0.0);
         PH_STOP(pc, 3);
         // ---- backtracking line search (tomography.py:575-585)
@@ -442,11 +460,13 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
         };
         double rmax = 0.0;                   // max |pu / pe| over the outcomes that are not listed
         uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
-#pragma unroll
+#pragma unroll SLOT_UNROLL
         for (int j = 0; j < MAXJ; ++j) {
-            rmax = fmax(rmax, fmax(fabs(ratio(pup[j], pep[j])), fabs(ratio(pum[j], pem[j]))));
-            if (__ballot(exact(pup[j], pep[j]))) near_clip |= 1u << (2 * j);
-            if (__ballot(exact(pum[j], pem[j]))) near_clip |= 2u << (2 * j);
+            double ep_, em_, up_, um_;
+            pe_of(j, ep_, em_); pu_of(j, up_, um_);
+            rmax = fmax(rmax, fmax(fabs(ratio(up_, ep_)), fabs(ratio(um_, em_))));
+            if (__ballot(exact(up_, ep_))) near_clip |= 1u << (2 * j);
+            if (__ballot(exact(um_, em_))) near_clip |= 2u << (2 * j);
         }
         rmax = uniform(wave_max(rmax));
         const bool small_ok = rmax == rmax;
@@ -464,14 +484,15 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
             double* cl = (double*)L.choi.Ms;                     // [4][CL_MAX]: pe, pu, n, n log(clip(pe))
             const unsigned long long below = (1ull << lane) - 1ull;
             FBX_WAVE_SYNC();
-#pragma unroll
+#pragma unroll SLOT_UNROLL
             for (int j = 0; j < MAXJ; ++j) {
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
                     if (near_clip & ((1u + sg) << (2 * j))) {
-                        double np_, nm_;
+                        double np_, nm_, ep_, em_, up_, um_;
                         counts_of(j, np_, nm_);
-                        const double pe = sg ? pem[j] : pep[j], pu = sg ? pum[j] : pup[j], nn = sg ? nm_ : np_;
+                        pe_of(j, ep_, em_); pu_of(j, up_, um_);
+                        const double pe = sg ? em_ : ep_, pu = sg ? um_ : up_, nn = sg ? nm_ : np_;
                         const bool f = exact(pu, pe);
                         const unsigned long long mk = __ballot(f);
                         const int pos = n_clip + __popcll(mk & below);
@@ -526,13 +547,14 @@ pgdb_body(char* smem, const double* ct_shared, long long item_, const DesignDev&
             if (!have_sums) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) Sk[k] = 0.0;
-#pragma unroll
+#pragma unroll SLOT_UNROLL
                 for (int j = 0; j < MAXJ; ++j) {
-                    double np_, nm_;
+                    double np_, nm_, ep_, em_, up_, um_;
                     counts_of(j, np_, nm_);
+                    pe_of(j, ep_, em_); pu_of(j, up_, um_);
 #pragma unroll
                     for (int sg = 0; sg < 2; ++sg) {
-                        const double x = sg ? ratio(pum[j], pem[j]) : ratio(pup[j], pep[j]);   // recomputed: not kept live
+                        const double x = sg ? ratio(um_, em_) : ratio(up_, ep_);   // recomputed: not kept live
                         double t = (sg ? nm_ : np_) * x;
 #pragma unroll
                         for (int k = 0; k < NS; ++k) { Sk[k] += t; t *= x; }
@@ -649,7 +671,8 @@ struct PgdbLaunch {
     int *it, *dy, *bt; double* cost; int* sw; long long* phase; cplx* basis; int basis_cap; double* ncounts; int* trace; int trace_iters;
 };
 // fbx_pgdb_lean.hip: the two-wavefronts-per-SIMD kernel for 2 qubits, MAXJ in {4, 9, 16}
-size_t pgdb_lean_lds(int maxj, int S, bool shared_table, size_t* wave_lds);
-int pgdb_lean_launch(int maxj, size_t lds, size_t wave_lds, bool shared_table, hipStream_t st, const PgdbLaunch& a);
+size_t pgdb_lean_lds(int maxj, int S);
+bool pgdb_lean_eligible(int S);      // the design's Bloch table fits beside Rb in the Jacobi work area
+int pgdb_lean_launch(int maxj, size_t lds, hipStream_t st, const PgdbLaunch& a);
 
 }  // namespace fbx

@@ -422,7 +422,12 @@ if __name__ == "__main__":
         make_process_fixed(2, "sic", 16, workers=6)
         sys.exit(0)
     if "--fixed3q" in sys.argv:           # 3 qubits: 16 items, ~1.5 GB and a few minutes each
-        make_process_fixed(3, "sic", 16, workers=4)
+        if "--basis" in sys.argv and sys.argv[sys.argv.index("--basis") + 1] == "pauli":
+            # round 4: the Pauli in-basis instantiation (13 608 settings: the reference's dense A is 27 216 x 4096
+            # complex = 1.8 GB, ~5 GB per worker while it is assembled); 4 bench items, converge + fixed-100 snapshots
+            make_process_fixed(3, "pauli", 4, workers=2, n_direct=1)
+        else:
+            make_process_fixed(3, "sic", 16, workers=4)
         sys.exit(0)
     if "--round2" in sys.argv:
         make_round2()
