@@ -103,6 +103,24 @@ def build_guard_test(verbose=True):
     return out
 
 
+def build_barrier_test(verbose=True):
+    """libfbx_fullbar.so: the product sources with every workgroup barrier of fbx_pgdb3.hip a full __syncthreads() instead of the
+    LDS-only form (-DFBX_FULL_BARRIERS) -- only loaded by tests/test_barriers_gpu.py, which requires bit-identical results."""
+    out = os.path.join(HERE, "libfbx_fullbar.so")
+    lib = build(verbose=verbose)
+    src = os.path.join(CSRC, "fbx_pgdb3.hip")
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(lib):
+        return out
+    obj = os.path.join(HERE, "build", "fbx_pgdb3.hip.fullbar.o")
+    cmd = [HIPCC] + FLAGS + file_flags(src) + ["-DFBX_FULL_BARRIERS", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs = [obj] + [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if s != src]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + MAP, "-ldl"] + objs + ["-o", out])
+    return out
+
+
 def build_variant(name, extra_flags, verbose=True):
     """Experiment builds: libfbx_<name>.so = the product objects with fbx_pgdb.hip and fbx_pgdb_lean.hip recompiled with extra
     -D flags (e.g. `python build.py --variant nosmall -DFBX_NO_SMALL_STEP`).  Not shipped, not loaded by tests."""
@@ -131,5 +149,6 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--guard-test" in sys.argv:
         build_guard_test()
+        build_barrier_test()
     else:
         build(force="--force" in sys.argv, profile="--profile" in sys.argv)

@@ -256,6 +256,12 @@ __device__ __forceinline__ double uniform(double v) {
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// The same value, but opaque to the optimiser: index arithmetic derived from it is recomputed where it is used (a few integer
+// instructions) instead of being hoisted out of every enclosing loop as a "loop-invariant" per-thread constant -- dozens of
+// them in the 1024-thread kernels, which have 128 registers: hoisted, they are spilled at kernel entry and re-read from
+// scratch (HBM latency, one wait each) in front of every phase.
+__device__ __forceinline__ int opaque(int v) { __asm__ volatile("" : "+v"(v)); return v; }
+
 // Raw buffer access (buffer_load / buffer_store with an SGPR resource, ONE 32-bit VGPR byte offset and an SGPR / immediate row
 // offset) for per-lane rows of a wave-private slice: no 64-bit per-lane address arithmetic, which the compiler otherwise hoists
 // out of the outer loop (one VGPR pair per 4 KB of rows) and then spills.  Reads beyond `bytes` return zero.

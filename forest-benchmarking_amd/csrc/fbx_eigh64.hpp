@@ -1,0 +1,250 @@
+// fbx_eigh64.hpp -- the 64 x 64 Hermitian eigensolver of the 3-qubit kernels (1024 threads, one 2 x 2 block per thread on a
+// 32 x 32 grid), round 4: the same cyclic two-sided Jacobi in the Brent-Luk systolic form as jacobi_eigh_simple<64, 1024>
+// (fbx_eigh.hpp) with the two things that bounded its round removed (LDS WRITES, 78 B/clk/CU, and two
+// workgroup barriers per round):
+//
+//   * the eigenvector block never touches LDS.  A wavefront owns two block rows (lanes 0-31 = row 2w, 32-63 = row 2w + 1),
+//     and the tournament permutation only moves eigenvector COLUMNS -- the top column of pair J goes to pair J + 1, the bottom
+//     one to pair J - 1, with the three exceptions at the ends of the ring -- i.e. between neighbouring lanes of the same
+//     wavefront: two full-wave DPP shifts (wave_shr:1 / wave_shl:1) and three selects per 32-bit register instead of four
+//     ds_write_b128 + four ds_read_b128 per thread and round;
+//   * the work matrix is double buffered in Ms / Vs (Vs is free now): a round reads buffer `cur` and writes the permuted blocks
+//     to the other one, so nothing separates its reads from its writes and ONE barrier per round is left.
+//
+// Interface as jacobi_eigh_simple: on entry Ms holds the Hermitian matrix (element-major layout, sys_pos<64>), Vs the starting
+// basis unless init_identity; on exit Ms is diagonal, Vs holds the eigenvectors.  Replaces scipy.linalg.eigh at
+// operator_tools/project_superoperators.py:30 for D = 64.  Parity is on V f(Lambda) V^H, never on eigenvectors.
+#pragma once
+#include "fbx_eigh.hpp"
+
+namespace fbx {
+
+// value of the previous / next lane of the wavefront (lane 0 / 63 keep their own)
+__device__ __forceinline__ double dpp_prev_lane(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_next_lane(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);      // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// one component (re or im of one row) of the eigenvector block's two columns through the tournament permutation:
+//   new top[J] = old top[J - 1] (J >= 2), old bottom[0] (J = 1), old top[0] (J = 0)
+//   new bottom[J] = old bottom[J + 1] (J <= 30), old top[31] (J = 31)
+// (Measured and dropped: the shift and the end-of-ring select fused into one v_cndmask_b32_dpp per register through inline
+// assembly -- 48 instead of 80 instructions per round for the two blocks, and 6 % SLOWER: the assembly blocks pin the order of
+// 16 instructions and need their own s_nop for the DPP read hazard, which the scheduler otherwise hides.)
+__device__ __forceinline__ void seat_shift(double& top, double& bot, bool first, bool last) {
+    const double send = first ? bot : top;             // pair 0 hands its BOTTOM column to pair 1 and keeps its top one
+    const double from_prev = dpp_prev_lane(send);
+    const double from_next = dpp_next_lane(bot);
+    const double t_old = top;
+    top = first ? t_old : from_prev;
+    bot = last ? t_old : from_next;
+}
+
+// Where the entry (slot r, slot c), r != c, of the Hermitian work matrix is STORED: only the upper block triangle is kept
+// (block row <= block column) and, inside a diagonal block, the entry (even slot, odd slot).  Returns the offset in the
+// element-major layout; `conj` says that the stored value is the conjugate of M[r][c].
+__device__ __forceinline__ int herm_store_pos(int r, int c, bool& conj) {
+    constexpr int N = 64, PS = sys_plane<N>();
+    const int R = r >> 1, C = c >> 1;
+    conj = R > C || (R == C && (r & 1));
+    const int rr = conj ? c : r, cc = conj ? r : c;
+    const int pl = (rr & 1) * 2 + (cc & 1);
+    return pl * PS + sys_pos<N>(rr >> 1, cc >> 1, pl);
+}
+
+// jacobi_eigh64: roles.  The Hermitian symmetry halves the matrix work and the eigenvector work has none to offer, so the two
+// are given to different wavefronts (two of each per SIMD):
+//   * wavefronts 0-7, MATRIX role: 496 threads own one strictly-upper block (Iu, Ju) each.  Both
+//     rotations of the block are computed locally from the two pivot blocks (two independent reciprocal-square-root chains:
+//     no exchange between lanes, no second barrier); every entry is written once, to the seat the tournament permutation
+//     assigns it or to the mirrored seat (conjugated), whichever lies in the stored triangle.
+//   * wavefronts 8-15, EIGENVECTOR role: thread (I, J), I < 16, owns the eigenvector blocks (I, J) and (I + 16, J) -- same
+//     column pair, one rotation for both -- in registers, exchanged with the neighbouring lanes as above.  The thread whose
+//     row pair equals its column pair (I == J or I + 16 == J) also places the pair's rotated diagonal and the annihilated entry.
+// Two sets of LDS addresses (one per buffer) alternate between consecutive rounds, so a round contains no address arithmetic.
+// The two roles are two separate loop nests behind a SCALAR branch (the wavefront index is wave-uniform), with the same sequence
+// of workgroup barriers -- two per convergence test, one per round: their registers overlap instead of adding up (as one loop
+// body with both roles the solver needed all 128 registers of a 1024-thread workgroup and, behind its call boundary in the
+// 3-qubit kernels, saved 49 callee-saved registers to scratch per decomposition).
+namespace eigh64 {
+constexpr int N = 64, NB = 32, PS = sys_plane<N>(), NUP = NB * (NB - 1) / 2, NT = 1024;
+
+// the loop nest both roles run: `test(o2, n2)` adds the role's share of the off-diagonal / total norm, `round(rd, wr)` is one
+// round reading the buffer described by the first address set and writing the one described by the second (barrier NOT included)
+template <int NR, int NW, class Test, class Round>
+__device__ __forceinline__ int sweeps(int (&ra)[NR], int (&wa)[NW], int delta, double* red, double tol2, Test test, Round round) {
+    int rb[NR], wb[NW];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rb[k] = ra[k] + delta;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) wb[k] = wa[k] + delta;
+    int sweep = 0;
+    for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
+        double o2 = 0.0, n2 = 0.0;
+        test(ra, o2, n2);
+        block_sum2<NT>(o2, n2, red);
+        o2 = uniform(o2); n2 = uniform(n2);
+        if (!(o2 > tol2 * n2)) break;
+        for (int r = 0; r < (N - 2) / 2; ++r) {
+            round(ra, wb); FBX_BLOCK_SYNC();
+            round(rb, wa); FBX_BLOCK_SYNC();
+        }
+        round(ra, wb); FBX_BLOCK_SYNC();
+        // 63 rounds: the matrix is in the other buffer now -- the two address sets change places
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { const int x = ra[k]; ra[k] = rb[k]; rb[k] = x; }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { const int x = wa[k]; wa[k] = wb[k]; wb[k] = x; }
+    }
+    return sweep;
+}
+
+__device__ __forceinline__ double flip_sign(double x, unsigned mask) {
+    return __hiloint2double(__double2hiint(x) ^ (int)mask, __double2loint(x));
+}
+
+__device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* red, double tol2) {
+    // rows i and 30 - i have 32 strictly-upper blocks between them: half-wavefront r = t / 32 takes those two rows (r < 15),
+    // the last one the 16 blocks of row 15 -- runs of consecutive column pairs, as the conflict-free layout wants them
+    const int r = t / NB, c = t % NB;
+    const bool mrole = r < 15 || c < 16;
+    const bool lower_row = c >= NB - 1 - r;                // the second row of the pair (r < 15 only)
+    const int Iu = mrole ? (lower_row ? 30 - r : r) : 0;
+    const int Ju = mrole ? (lower_row ? Iu + 1 + (c - (NB - 1 - r)) : r + 1 + c) : 1;
+    static_assert(NUP == 15 * NB + 16, "496 strictly-upper blocks");
+    // own block (planes b = 0 / 1), pivot block of the row pair, pivot block of the column pair; the four seats
+    int ra[6], wa[4];
+    unsigned sgm[4];                                        // sign bit to flip on the imaginary part of an entry stored mirrored
+    ra[0] = sys_pos<N>(Iu, Ju, 0); ra[1] = sys_pos<N>(Iu, Ju, 1);
+    ra[2] = sys_pos<N>(Iu, Iu, 0); ra[3] = sys_pos<N>(Iu, Iu, 1);
+    ra[4] = sys_pos<N>(Ju, Ju, 0); ra[5] = sys_pos<N>(Ju, Ju, 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        bool cj;
+        wa[e] = herm_store_pos(jacobi_seat<N>(2 * Iu + (e >> 1)), jacobi_seat<N>(2 * Ju + (e & 1)), cj);
+        sgm[e] = cj ? 0x80000000u : 0u;
+    }
+    auto test = [&](const int (&rd)[6], double& o2, double& n2) __attribute__((always_inline)) {
+        if (mrole) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const cplx v = Ms[e * PS + rd[e & 1]];
+                o2 += 2.0 * (v.re * v.re + v.im * v.im);
+            }
+            n2 = o2;
+        }
+    };
+    auto round = [&](const int (&rd)[6], const int (&wr)[4]) __attribute__((always_inline)) {
+        if (mrole) {
+            const double aI = Ms[0 * PS + rd[2]].re, dI_ = Ms[3 * PS + rd[3]].re; const cplx bI = Ms[1 * PS + rd[3]];
+            const double aJ = Ms[0 * PS + rd[4]].re, dJ_ = Ms[3 * PS + rd[5]].re; const cplx bJ = Ms[1 * PS + rd[5]];
+            cplx m00 = Ms[0 * PS + rd[0]], m01 = Ms[1 * PS + rd[1]];
+            cplx m10 = Ms[2 * PS + rd[0]], m11 = Ms[3 * PS + rd[1]];
+            const JRot rI = jacobi_rotation(aI, dI_, bI.re, bI.im);
+            const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
+            jacobi_apply_m(rI.c, rI.sr, rI.si, rJ.c, rJ.sr, rJ.si, m00, m01, m10, m11);
+            m00.im = flip_sign(m00.im, sgm[0]); m01.im = flip_sign(m01.im, sgm[1]);
+            m10.im = flip_sign(m10.im, sgm[2]); m11.im = flip_sign(m11.im, sgm[3]);
+            Ms[wr[0]] = m00; Ms[wr[1]] = m01; Ms[wr[2]] = m10; Ms[wr[3]] = m11;
+        }
+    };
+    return sweeps<6, 4>(ra, wa, delta, red, tol2, test, round);
+}
+
+__device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv, bool init_identity, double* red, double tol2) {
+    const int I = tv / NB, J = tv % NB;
+    const bool first = J == 0, last = J == NB - 1;
+    const bool diag = I == (J & 15);                       // row pair I (J < 16) or I + 16 (J >= 16) is the column pair
+    // pivot block of the column pair; seats of the rotated diagonal and of the annihilated entry
+    int ra[2], wa[3];
+    {
+        const int sa = jacobi_seat<N>(2 * J), sd = jacobi_seat<N>(2 * J + 1);
+        bool cj;
+        ra[0] = sys_pos<N>(J, J, 0); ra[1] = sys_pos<N>(J, J, 1);
+        wa[0] = 3 * (sa & 1) * PS + sys_pos<N>(sa >> 1, sa >> 1, sa & 1);
+        wa[1] = 3 * (sd & 1) * PS + sys_pos<N>(sd >> 1, sd >> 1, sd & 1);
+        wa[2] = herm_store_pos(sa, sd, cj);
+    }
+    // eigenvector blocks in registers: rows 2I, 2I + 1 (block 0) and 2I + 32, 2I + 33 (block 1); columns = slots 2J (p), 2J + 1 (q)
+    cplx v0p[2], v0q[2], v1p[2], v1q[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int Ik = I + 16 * k;
+        if (init_identity) {
+            v0p[k].re = (Ik == J) ? 1.0 : 0.0; v0p[k].im = 0.0; v1q[k] = v0p[k];
+            v0q[k].re = 0.0; v0q[k].im = 0.0; v1p[k] = v0q[k];
+        } else {
+            v0p[k] = Vs[0 * PS + sys_pos<N>(Ik, J, 0)]; v0q[k] = Vs[1 * PS + sys_pos<N>(Ik, J, 1)];
+            v1p[k] = Vs[2 * PS + sys_pos<N>(Ik, J, 0)]; v1q[k] = Vs[3 * PS + sys_pos<N>(Ik, J, 1)];
+        }
+    }
+    FBX_BLOCK_SYNC();                                       // Vs is the second matrix buffer from here on
+    double ev_a = 0.0, ev_d = 0.0;                          // (diag threads) the pair's diagonal at the last convergence test
+    auto test = [&](const int (&rd)[2], double& o2, double& n2) __attribute__((always_inline)) {
+        if (diag) {
+            ev_a = Ms[0 * PS + rd[0]].re; ev_d = Ms[3 * PS + rd[1]].re;
+            const cplx b = Ms[1 * PS + rd[1]];
+            o2 = 2.0 * (b.re * b.re + b.im * b.im);
+            n2 = o2 + ev_a * ev_a + ev_d * ev_d;
+        }
+    };
+    auto round = [&](const int (&rd)[2], const int (&wr)[3]) __attribute__((always_inline)) {
+        const double aV = Ms[0 * PS + rd[0]].re, dV = Ms[3 * PS + rd[1]].re;
+        const cplx bV = Ms[1 * PS + rd[1]];
+        const JRot rV = jacobi_rotation(aV, dV, bV.re, bV.im);
+        if (diag) {
+            cplx a; a.re = rV.an; a.im = 0.0; cplx d; d.re = rV.dn; d.im = 0.0; cplx z; z.re = 0.0; z.im = 0.0;
+            Ms[wr[0]] = a; Ms[wr[1]] = d; Ms[wr[2]] = z;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            jacobi_apply_v(rV.c, rV.sr, rV.si, v0p[k], v0q[k], v1p[k], v1q[k]);
+            seat_shift(v0p[k].re, v0q[k].re, first, last); seat_shift(v0p[k].im, v0q[k].im, first, last);
+            seat_shift(v1p[k].re, v1q[k].re, first, last); seat_shift(v1p[k].im, v1q[k].im, first, last);
+        }
+    };
+    const int sweep = sweeps<2, 3>(ra, wa, delta, red, tol2, test, round);
+    if (sweep == FBX_JACOBI_MAX_SWEEPS && diag) { ev_a = Ms[0 * PS + ra[0]].re; ev_d = Ms[3 * PS + ra[1]].re; }
+    FBX_BLOCK_SYNC();
+    // results where the callers expect them: the eigenvalues on the diagonal of Ms, the eigenvectors in Vs (both buffers are
+    // free: every thread's last read lies behind a barrier)
+    if (diag) {
+        cplx a; a.re = ev_a; a.im = 0.0; cplx d; d.re = ev_d; d.im = 0.0;
+        Ms[0 * PS + sys_pos<N>(J, J, 0)] = a; Ms[3 * PS + sys_pos<N>(J, J, 1)] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int Ik = I + 16 * k;
+        Vs[0 * PS + sys_pos<N>(Ik, J, 0)] = v0p[k]; Vs[1 * PS + sys_pos<N>(Ik, J, 1)] = v0q[k];
+        Vs[2 * PS + sys_pos<N>(Ik, J, 0)] = v1p[k]; Vs[3 * PS + sys_pos<N>(Ik, J, 1)] = v1q[k];
+    }
+    return sweep;
+}
+}  // namespace eigh64
+
+template <int NT = 1024>
+__device__ int jacobi_eigh64(cplx* Ms, cplx* Vs, int t, bool init_identity, double* red, double tol2 = FBX_JACOBI_TOL2) {
+    static_assert(NT == 1024, "sixteen wavefronts");
+    const int delta = (int)(Vs - Ms);
+    int sweep;
+    // (a scalar branch: both sides execute the same sequence of workgroup barriers)
+    if (__builtin_amdgcn_readfirstlane(t) < 512) {
+        FBX_BLOCK_SYNC();                                   // (the eigenvector role's barrier behind its read of Vs)
+        sweep = eigh64::matrix_role(Ms, delta, t, red, tol2);
+        FBX_BLOCK_SYNC();                                   // (its barrier in front of the results)
+    } else {
+        sweep = eigh64::vector_role(Ms, Vs, delta, t - 512, init_identity, red, tol2);
+    }
+    FBX_BLOCK_SYNC();
+    return sweep;
+}
+
+}  // namespace fbx

@@ -12,8 +12,11 @@
 // Reference: tomography.py:542-633, operator_tools/project_superoperators.py:19-144.
 // no thread of these kernels reads global memory another thread of the same launch wrote (basis store and parked state
 // are per thread, tables go through LDS): barriers order LDS only and leave global traffic in flight (fbx_common.hpp)
-#define FBX_LDS_ONLY_BARRIERS
+#ifndef FBX_FULL_BARRIERS          // (-DFBX_FULL_BARRIERS: every barrier a full __syncthreads() -- libfbx_fullbar.so, the reference build of
+#define FBX_LDS_ONLY_BARRIERS      //  tests/test_barriers_gpu.py, which must reproduce this one bit for bit)
+#endif
 #include "fbx_choi.hpp"
+#include "fbx_eigh64.hpp"
 #include <cstdlib>
 
 namespace fbx {
@@ -37,6 +40,15 @@ extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
 #define FBX3_BASIS_CHAIN_SWEEPS 216   // as FBX_BASIS_CHAIN_SWEEPS of the 2-qubit kernel (fbx_pgdb.hip)
 #endif
 
+#ifndef FBX3_PARK_DYKSTRA
+#define FBX3_PARK_DYKSTRA 1
+#endif
+#ifndef FBX3_OPAQUE
+#define FBX3_OPAQUE 1
+#endif
+#if !FBX3_OPAQUE
+#define opaque(x) (x)
+#endif
 namespace p3 {
 constexpr int NQ = 3, d = 8, D = 64, NB = 32, NT = 1024, LD = 64, LDs = d + 1;
 constexpr double EPS = 1e-6, GAMMA = 0.3, STOP = 1e-10, ALPHA_MIN = 1e-15;
@@ -143,6 +155,7 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
 #ifndef FBX3_ROTATE_VALU
 __device__ void rotate_into_basis_mfma(Lds& L, int t) {
     typedef double v4d __attribute__((ext_vector_type(4)));
+    t = opaque(t);
     const int w = t >> 6, l = t & 63, tm = w >> 2, tn = w & 3, g = l >> 4, c = l & 15;
     const int colA = 16 * tm + c, colB = 16 * tn + c;
     v4d tre = {0.0, 0.0, 0.0, 0.0}, tim = {0.0, 0.0, 0.0, 0.0};
@@ -189,13 +202,28 @@ __device__ void rotate_into_basis_mfma(Lds& L, int t) {
 // constants and those of every other phase are hoisted out of the Dykstra loop together and spilled -- with scratch
 // reloads inside the Jacobi round loop.  Behind a call boundary the solver is allocated on its own (80 registers, no
 // scratch, as in eigh_kernel<64, 1024>) and the caller's live values are saved around the call, once per decomposition.
-__device__ __attribute__((noinline)) int jacobi64(cplx* Ms, cplx* Vs, int t, bool init_identity, double* red, double tol2) {
+#ifndef FBX3_JACOBI_CALL
+#define FBX3_JACOBI_CALL 0      // 1: behind a call boundary (noinline), 0: inlined into the kernels (round 4: 296 -> 274 ms per 256 reconstructions;
+                                // the role-split solver needs more than the 80 caller-saved registers and saved 49 more to scratch per call)
+#endif
+#if FBX3_JACOBI_CALL
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+int jacobi64(cplx* Ms, cplx* Vs, int t, bool init_identity, double* red, double tol2) {
+    t = opaque(t);
+#ifdef FBX3_JACOBI_ROUND3          // the one-block-per-thread form of rounds 1-3 (A/B builds)
     return jacobi_eigh_simple<D, NT>(Ms, Vs, t, init_identity, red, tol2);
+#else
+    return jacobi_eigh64<NT>(Ms, Vs, t, init_identity, red, tol2);     // fbx_eigh64.hpp
+#endif
 }
 
 // ---- CP projection (project_superoperators.py:19-34)
 // Hermitised copy of x into Ms (element-major layout); returns ||h||_F^2's per-thread part when asked
 __device__ __forceinline__ double hermitise_into_ms(const Blk& x, Lds& L, int t, bool want_norm) {
+    t = opaque(t);
     FBX_BLOCK_SYNC();
     sys_store<D>(L.Ms, t, x);
     FBX_BLOCK_SYNC();
@@ -208,8 +236,12 @@ __device__ __forceinline__ double hermitise_into_ms(const Blk& x, Lds& L, int t,
     FBX_BLOCK_SYNC();
     return want_norm ? blk_norm2(h) : 0.0;
 }
-__device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = false, cplx* Tg = nullptr,
-                       bool check_basis = false) {
+__device__ __forceinline__ Blk unpark_blk(const cplx* g, int t);
+// (`upark`: the caller's two matrices are read back from their parking slab behind the eigensolver, see proj_physical)
+__device__ __forceinline__ Blk proj_cp(const Blk& x_, Lds& L, int t_, int& sweeps, bool warm = false, cplx* Tg = nullptr,
+                       bool check_basis = false, const cplx* upark = nullptr, Blk* u_back = nullptr, Blk* p_back = nullptr) {
+    const Blk x = x_;
+    int t = t_;
     // (the Hermitised matrix lives in LDS only: a register copy kept for the rare rejected basis would stay live
     // across the eigensolver -- 16 of 128 registers; the rejection path rebuilds it from x instead)
     double n2[2] = {0.0, 0.0};
@@ -235,7 +267,13 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
         }
     }
     PH_STOP(*L.pc, 6);
+    if (upark) __asm__ volatile("" ::: "memory");       // nothing of the caller's parked matrices stays in registers across the solver
     sweeps += jacobi64(L.Ms, L.Vs, t, !warm, L.red, L.jtol2);
+    t = opaque(t);
+    if (upark) {                                        // requested here, consumed behind the reconstruction below
+        __asm__ volatile("" ::: "memory");
+        *u_back = unpark_blk(upark, t); *p_back = unpark_blk(upark + 4 * NT, t);
+    }
     PH_STOP(*L.pc, 0);
     if (t < D) {
         const double l = L.Ms[sys_index<D>(t, t)].re;
@@ -254,6 +292,7 @@ __device__ Blk proj_cp(const Blk& x, Lds& L, int t, int& sweeps, bool warm = fal
 
 // ---- partial trace over the output space into L.pt (calculational.py:5-35); stages x through Mw
 __device__ void partial_trace_out(const Blk& x, Lds& L, int t) {
+    t = opaque(t);
     // staged row-major through Ms (dead between the reconstruction and the next projection), NOT
     // through Mw = Vs: the eigenvectors in Vs must survive for the warm start of the next projection
     cplx* St = L.Ms;
@@ -271,6 +310,7 @@ __device__ void partial_trace_out(const Blk& x, Lds& L, int t) {
 }
 __device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const Lds& L, int t) {
     Blk r = x;
+    t = opaque(t);
     const int I = t / NB, J = t % NB;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -314,16 +354,23 @@ __device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project
 #endif
 // one stored basis (64 KiB, the layout of Vs) from HBM / L2 into LDS without passing through registers: every lane moves
 // four 16-byte entries; the LDS address of a global_load_lds is wave-uniform base + lane * 16
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima): the consumer side
+// of basis_fetch -- global_load_lds is a VMEM load whose completion is counted by vmcnt, not by the LDS counter
+__device__ __forceinline__ void wait_global_loads() { __builtin_amdgcn_s_waitcnt(0x0070); }
+// Ownership: thread t moves entries e * NT + t (e = 0..3) of a stored basis in BOTH directions -- write-back (store_index below) and
+// fetch -- so no thread ever reads global memory another thread wrote, which is what lets the barriers order LDS only.
+__device__ __forceinline__ int store_index(int e, int t) { return e * NT + t; }
 __device__ __forceinline__ void basis_fetch(const cplx* g, cplx* Vs, int t) {
     typedef __attribute__((address_space(1))) const void* gptr;
     typedef __attribute__((address_space(3))) void* lptr;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        __builtin_amdgcn_global_load_lds((gptr)(g + e * NT + t), (lptr)(Vs + e * NT + (t & ~63)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(g + store_index(e, t)), (lptr)(Vs + store_index(e, t & ~63)), 16, 0, 0);
 }
 // block of kron(C, I_d) for the d x d matrix C staged in LDS (leading dimension LDs)
 __device__ __forceinline__ Blk kron_id_blk(const cplx* C, int t) {
     Blk r = blk_zero();
+    t = opaque(t);
     const int I = t / NB, J = t % NB;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -345,8 +392,24 @@ __device__ __forceinline__ Blk kron_id_blk(const cplx* C, int t) {
 // thread of a 1024-thread workgroup has, next to the solver's 80 (rounds 1-2 carried four matrices + the caller's
 // estimate, gradient and counts: 1.4 KB of scratch per lane and 235 GB of spill traffic per 256-item launch).
 // Differences to the literal expressions are rounding-level terms of the stopping functional (threshold 1e-4).
-__device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, int& sweeps, cplx* Tg,
-                             BasisStore* store = nullptr) {
+// `upark` (optional, [2][4][1024] entries per workgroup, HBM / L2): pre_CP and old_CP_change are written there in front of the
+// eigensolver and read back behind it -- explicitly, coalesced, the loads issued before the reconstruction that covers their
+// latency -- instead of being spilled around it by the compiler (the role-split solver of fbx_eigh64.hpp wants the registers).
+__device__ __forceinline__ void park_blk(cplx* g, int t, const Blk& b) {
+    fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[e * NT + t] = fbx_v2d{b.re[e], b.im[e]};
+}
+__device__ __forceinline__ Blk unpark_blk(const cplx* g, int t) {
+    fbx_global_cplx_ptr src = (fbx_global_cplx_ptr)const_cast<cplx*>(g);
+    Blk b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const fbx_v2d w = src[e * NT + t]; b.re[e] = w.x; b.im[e] = w.y; }
+    return b;
+}
+__device__ __forceinline__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t_, int& iters, int& sweeps, cplx* Tg,
+                             BasisStore* store = nullptr, cplx* upark = nullptr) {
+    int t = t_;
     Blk u = x;                       // pre_CP = last_state - old_CP_change
     Blk p = blk_zero();              // old_CP_change
     Blk new_state = x;
@@ -365,17 +428,19 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
         if (store && Tg && it < store->nprev && (it == 0 || store->use_prev)) {
             from_slot = true;
             if (!pf_pending) { FBX_BLOCK_SYNC(); basis_fetch(store->g + (size_t)it * D * D, L.Vs, t); }
-            __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0): this wave's share of the basis has landed in LDS
+            wait_global_loads();                      // this wave's share of the basis has landed in LDS
             FBX_BLOCK_SYNC();
             pf_pending = false;
             warm = true;
         }
         PH3(3);
-        const Blk cp = proj_cp(u, L, t, sweeps, warm, Tg, from_slot);
+        t = opaque(t);
+        if (upark) { park_blk(upark, t, u); park_blk(upark + 4 * NT, t, p); }
+        const Blk cp = proj_cp(u, L, t, sweeps, warm, Tg, from_slot, upark, &u, &p);
         if (store && it < store->cap && (it == 0 || store->write_all)) {      // write-back policy: BasisStore, fbx_choi.hpp
             fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * D * D);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const cplx v = L.Vs[e * NT + t]; dst[e * NT + t] = fbx_v2d{v.re, v.im}; }
+            for (int e = 0; e < 4; ++e) { const cplx v = L.Vs[store_index(e, t)]; dst[store_index(e, t)] = fbx_v2d{v.re, v.im}; }
         }
         PH3(7);
         double red8[8];
@@ -416,6 +481,7 @@ __device__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int t, int& iters, i
 
 // ---- Choi (in registers) -> transposed Pauli coefficients Rt (uses Mw = Vs as staging)
 __device__ void choi_to_pauli(const Blk& x, Lds& L, int t) {
+    t = opaque(t);
     FBX_BLOCK_SYNC();
     blk_store<D, LD>(L.Mw, t, x);
     FBX_BLOCK_SYNC();
@@ -433,6 +499,7 @@ __device__ void choi_to_pauli(const Blk& x, Lds& L, int t) {
 }
 // ---- transposed Pauli coefficients Rt -> Choi block (Mw = Vs as scratch)
 __device__ Blk pauli_to_choi(Lds& L, int t) {
+    t = opaque(t);
     FBX_BLOCK_SYNC();
     for (int idx = t; idx < D * D; idx += NT) {
         const int i = idx % D, j = idx / D;
@@ -458,6 +525,7 @@ __device__ Blk pauli_to_choi(Lds& L, int t) {
 typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ void predict_table(const DesignDev& des, Lds& L, int t) {
     const int S = des.S;
+    t = opaque(t);
     const int lane = t & 63, wave = t >> 6;
     const int mtiles = (S + 15) / 16;
     FBX_BLOCK_SYNC();
@@ -484,6 +552,7 @@ __device__ void predict_table(const DesignDev& des, Lds& L, int t) {
 // 16 x 16 output tile per wave; W from LDS, C from L2.  S is padded with zero terms to a multiple of 4.
 __device__ void gradient_coefficients(const DesignDev& des, Lds& L, const double* W, int t) {
     const int S = des.S;
+    t = opaque(t);
     const int lane = t & 63, wave = t >> 6;
     const int mi = wave / 4, nj = wave % 4;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -509,12 +578,13 @@ __device__ void gradient_coefficients(const DesignDev& des, Lds& L, const double
 // compiler then spills around every one of the ~10 eigendecompositions of the projection.
 template <int MAXJ>
 struct Park3 {
-    static constexpr size_t doubles() { return 2 * (size_t)p3::D * p3::D + (size_t)p3::D * p3::D + 4 * (size_t)MAXJ * p3::NT; }
+    static constexpr size_t doubles() { return 2 * (size_t)p3::D * p3::D + (size_t)p3::D * p3::D + 4 * (size_t)MAXJ * p3::NT + 4 * (size_t)p3::D * p3::D; }
     double* base;
     __device__ cplx* est() const { return (cplx*)base; }                              // [4][1024] blocks, element-major
     __device__ double* rg() const { return base + 2 * p3::D * p3::D; }                // [4096] gradient coefficients (Rt layout)
     __device__ double* pp() const { return rg() + p3::D * p3::D; }                    // [2 MAXJ][1024] probabilities of the estimate
     __device__ double* nn() const { return pp() + 2 * MAXJ * p3::NT; }                // [2 MAXJ][1024] normalised counts
+    __device__ cplx* dyk() const { return (cplx*)(nn() + 2 * MAXJ * p3::NT); }       // [2][4][1024] Dykstra's two matrices around the eigensolver
 };
 
 template <int MAXJ>
@@ -682,7 +752,11 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         { const double tr_ = des.eig_rel_tol * outer_step; L.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }   // as in fbx_pgdb.hip
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch,
-                                       basis.g ? &basis : nullptr);
+#if FBX3_PARK_DYKSTRA
+                                       basis.g ? &basis : nullptr, park.dyk());
+#else
+                                       basis.g ? &basis : nullptr, nullptr);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const cplx v = park.est()[e * NT + t]; est.re[e] = v.re; est.im[e] = v.im; }
         const Blk upd = blk_sub(proj, est);

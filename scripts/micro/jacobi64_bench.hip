@@ -3,6 +3,7 @@
 // the other 8, rotations computed once and published through LDS).  Diagnostics only.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../forest-benchmarking_amd/csrc -I../../include jacobi64_bench.hip -o jacobi64_bench
 #include "fbx_eigh.hpp"
+#include "fbx_eigh64.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -352,6 +353,7 @@ __global__ void __launch_bounds__(NT) k64(const double* A, double* W, double* Vo
         if constexpr (MODE == 0 && NT >= 1024) sweeps += jacobi_eigh_simple<N, (NT >= 1024 ? NT : 1024)>(Ms, Vs, t, true, red);
         else if constexpr (MODE == 1) sweeps += jacobi_eigh_split(Ms, Vs, rot, red, t);
         else if constexpr (MODE == 3) sweeps += jacobi_eigh_phase(Ms, Vs, rot3, red, t);
+        else if constexpr (MODE == 4) { if constexpr (NT >= 1024) sweeps += jacobi_eigh64<1024>(Ms, Vs, t, true, red); }
         else sweeps += jacobi_eigh_two(Ms, Vs, red, t);
         total += __builtin_readcyclecounter() - t0;
         __syncthreads();
@@ -385,6 +387,7 @@ int main(int argc, char** argv) {
     (void)hipFuncSetAttribute((const void*)k64<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k64<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k64<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     { long long* dp; (void)hipMalloc(&dp, 64 * 8); (void)hipMemset(dp, 0, 64 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pt), &dp, sizeof dp); }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float ms = 0;
@@ -393,6 +396,7 @@ int main(int argc, char** argv) {
         if (mode == 0) hipLaunchKernelGGL(k64<0>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
         else if (mode == 1) hipLaunchKernelGGL(k64<1>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
         else if (mode == 3) hipLaunchKernelGGL(k64<3>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
+        else if (mode == 4) hipLaunchKernelGGL(k64<4>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
         else hipLaunchKernelGGL(k64<2>, dim3(B), dim3(NT), lds, 0, dA, dW, dV, dc, ds, reps);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);

@@ -1,7 +1,7 @@
 """Per-phase cycle breakdown of the 3-qubit PGDB kernel (needs libfbx_prof.so: build.py --profile)."""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["FBX_LIBRARY"] = os.path.join(ROOT, "forest-benchmarking_amd", "libfbx_prof.so")
+os.environ["FBX_LIBRARY"] = os.path.join(ROOT, "forest-benchmarking_amd", os.environ.get("FBX_PROF_LIB", "libfbx_prof.so"))
 sys.path.insert(0, os.path.join(ROOT, 'forest-benchmarking_amd'))
 import numpy as np
 from fbx import synthetic, tomography, _lib

@@ -48,7 +48,7 @@ def test_oracle_reproduces_the_timed_mode_fixtures(n, basis, items):
 
 def test_fixture_inputs_are_the_bench_items():
     from fbx import synthetic
-    for n, basis, count in ((2, "pauli", 64), (2, "sic", 16), (3, "sic", 16)):
+    for n, basis, count in ((2, "pauli", 64), (2, "sic", 16), (3, "sic", 16), (3, "pauli", 4)):
         g = _load(n, basis)
         assert g["expectations"].shape[0] == count
         _, us, e, c = synthetic.process_batch(n, basis, 3)
@@ -58,6 +58,21 @@ def test_fixture_inputs_are_the_bench_items():
             assert (g["conv_iter"] <= 100).all()
         ran = np.maximum(g["conv_iter"], 100)                                  # iterations the driver executed per item
         assert all((g["dykstra"][b, :ran[b]] > 0).all() and (g["dykstra"][b, ran[b]:] == -1).all() for b in range(count))
+
+
+def test_oracle_follows_the_pauli_3q_fixture():
+    """BASELINE configs[3]'s stretch design (13 608 settings; the reference's dense A is 1.8 GB, which is why the whole
+    100-iteration run is not repeated here): the oracle with its SPARSE design matrix reproduces the reference's cost and
+    Dykstra / halving counts of the first three iterations of fixture item 0 (costs to 1e-12: another summation order)."""
+    from fbx_oracle import design as od, estimators as oe
+    g = _load(3, "pauli")
+    d = od.process_design(3, "pauli")
+    assert d.m == 13608 and (d.in_labels == g["in_labels"]).all() and (d.paulis == g["paulis"]).all()
+    A = oe.design_matrix_A(d, sparse=True)
+    for k in (1, 3):
+        _, st = oe.pgdb_process_estimate(d, g["expectations"][0], g["counts"][0], A=A, mode="fixed", max_iters=k, return_stats=True)
+        assert st["dykstra"] == int(g["dykstra"][0][:k].sum()) and st["backtracks"] == int(g["backtracks"][0][:k].sum())
+        assert abs(st["cost"] - g["costs"][0][k - 1]) < 1e-12
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -125,7 +140,7 @@ def test_two_qubit_fixed_100_against_the_reference(gpu, basis, nb, tol, tile_to)
 @pytest.mark.gpu
 @pytest.mark.parametrize("tile_to", [0, 2048], ids=["one-wave-kernel", "two-waves-per-simd-kernel"])
 @pytest.mark.parametrize("tol", [None, 0.0])
-@pytest.mark.parametrize("n,basis,nb", [(2, "pauli", 64), (2, "sic", 16), (3, "sic", 16)])
+@pytest.mark.parametrize("n,basis,nb", [(2, "pauli", 64), (2, "sic", 16), (3, "sic", 16), (3, "pauli", 4)])
 def test_converge_mode_against_the_reference_snapshots(gpu, n, basis, nb, tol, tile_to):
     if n == 3 and tile_to:
         pytest.skip("one kernel for three qubits")
@@ -141,11 +156,13 @@ def test_converge_mode_against_the_reference_snapshots(gpu, n, basis, nb, tol, t
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tol", [None, 0.0])
-def test_three_qubit_fixed_100_against_the_reference(gpu, tol):
-    """BASELINE configs[3]'s timed configuration: 100 fixed iterations, 64 x 64 Choi, SIC in-basis."""
-    g, got, st = _run(3, "sic", tol, "fixed")
+@pytest.mark.parametrize("basis", ["sic", "pauli"])
+def test_three_qubit_fixed_100_against_the_reference(gpu, tol, basis):
+    """BASELINE configs[3]'s timed configuration: 100 fixed iterations, 64 x 64 Choi; SIC in-basis (pgdb3_kernel<4>, 16 items)
+    and the Pauli in-basis stretch form (13 608 settings, pgdb3_kernel<14>, 4 items)."""
+    g, got, st = _run(3, basis, tol, "fixed")
     nb = got.shape[0]
-    assert nb >= 8
+    assert nb >= (8 if basis == "sic" else 4)
     _check_traces(g, st, nb, "fixed")
     dev = np.abs(got - g["pgdb_fixed"]).reshape(nb, -1).max(axis=1)
     assert dev.max() <= 1e-9, sorted(dev)[-5:]
