@@ -6,6 +6,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <functional>
+#include <map>
+#include <mutex>
 #include "../../include/fbx.h"
 
 namespace fbx {
@@ -20,7 +23,14 @@ void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 hipStream_t stream();    // the calling thread's stream (created on first use)
 int device_epoch();      // increases whenever fbx_set_device selects a different device: cached device memory is stale then
-int current_device();    // device selected for the process, -1 before the first use
+int current_device();    // device the calling thread works on: the process's (fbx_set_device), or a device worker's own; -1 before the first use
+// One call, several devices (fbx_set_devices; SURVEY.md 8b / 8e "host thread per device does H2D of its slab, launches, D2H"):
+// the host-pointer batch entry points split their batch into contiguous blocks and hand block g to the long-lived worker thread
+// of device list entry g (its own context: stream, staging pool, workspaces).
+int device_list_size();                                                  // entries of fbx_set_devices' list, 0 or 1 = single device
+bool in_device_worker();                                                 // the calling thread is one of those workers
+int run_on_devices(int n_jobs, const std::function<int(int)>& job);     // job(g) on worker g, all waited for; first failure returned (message kept)
+const fbx_design* design_on_this_device(const fbx_design* des, int* rc); // des itself, or its replica on the calling worker's device (created on first use)
 double option_pgdb_eig_rel_tol(int n_qubits);   // fbx_set_option("pgdb_eig_rel_tol" / "pgdb3_eig_rel_tol")
 bool option_eigh_cooperative();                 // fbx_set_option("eigh_cooperative")
 int option_pgdb_packed_1q();                     // fbx_set_option("pgdb_packed_1q"): single-qubit PGDB on the lane-per-item kernel: 0 never, 1 large batches (default), 2 always
@@ -105,6 +115,12 @@ struct DesignDev {
 
 struct fbx_design {
     fbx::DesignDev dev;
+    // what fbx_design_create was given (replicas on other devices are created from it) and the replicas, by device
+    int arg_n = 0, arg_kind = 0, arg_m = 0;
+    std::vector<uint8_t> arg_in_labels, arg_paulis;
+    std::vector<double> arg_coefs;
+    mutable std::mutex replica_mu;
+    mutable std::map<int, fbx_design*> replicas;
     int device = -1;         // device (and selection epoch) the slabs were allocated on
     int epoch = -1;
     void* slab = nullptr;    // one device allocation backing every pointer in dev

@@ -233,6 +233,14 @@ int fbx_pgdb_process_dev(const fbx_design* design, int64_t B, const double* d_ex
                                    d_iters_out, d_dykstra_out, d_backtracks_out, d_cost_out, d_work_out, nullptr, 0);
 }
 
+// the host-pointer call on the calling thread's device; `total_batch` = size of the caller's whole batch when this is one
+// device's block of it (kernels are chosen by the whole, so that the split does not change a single bit of any item)
+static int pgdb_process_host(const fbx_design* design, int64_t B, const double* expect,
+                             const double* counts, int trace_preserving, int mode, int max_iters, double eig_rel_tol,
+                             double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
+                             int32_t* backtracks_out, double* cost_out, int32_t* work_out,
+                             int32_t* trace_out, int trace_iters, int64_t total_batch);
+
 int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expect,
                         const double* counts, int trace_preserving, int mode, int max_iters, double eig_rel_tol,
                         double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
@@ -245,6 +253,36 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
     rc = check_extras(eig_rel_tol, trace_out, trace_iters);
     if (rc) return rc;
     if (B == 0) return FBX_OK;
+    // fbx_set_devices: contiguous blocks of the batch, one per entry of the device list, each on that entry's
+    // worker thread with its own context and a replica of the design; no exchange between devices
+    const int G = device_list_size();
+    if (G > 1 && !in_device_worker() && B >= 2 * (int64_t)G) {
+        const int64_t per = (B + G - 1) / G;
+        const size_t m = design->dev.m, DD = (size_t)design->dev.D * design->dev.D;
+        return run_on_devices(G, [&](int g) -> int {
+            const int64_t lo = (int64_t)g * per < B ? (int64_t)g * per : B, nb = (B - lo < per ? B - lo : per);
+            if (nb <= 0) return FBX_OK;
+            int r = ensure_device();
+            if (r) return r;
+            const fbx_design* dg = design_on_this_device(design, &r);
+            if (r) return r;
+            return pgdb_process_host(dg, nb, expect + lo * m, counts + lo * m, trace_preserving, mode, max_iters, eig_rel_tol,
+                                     choi_out + lo * 2 * DD, iters_out ? iters_out + lo : nullptr, dykstra_out ? dykstra_out + lo : nullptr,
+                                     backtracks_out ? backtracks_out + lo : nullptr, cost_out ? cost_out + lo : nullptr,
+                                     work_out ? work_out + 4 * lo : nullptr, trace_out ? trace_out + (size_t)lo * trace_iters * 2 : nullptr,
+                                     trace_iters, B);
+        });
+    }
+    return pgdb_process_host(design, B, expect, counts, trace_preserving, mode, max_iters, eig_rel_tol, choi_out, iters_out,
+                             dykstra_out, backtracks_out, cost_out, work_out, trace_out, trace_iters, B);
+}
+
+static int pgdb_process_host(const fbx_design* design, int64_t B, const double* expect,
+                             const double* counts, int trace_preserving, int mode, int max_iters, double eig_rel_tol,
+                             double* choi_out, int32_t* iters_out, int32_t* dykstra_out,
+                             int32_t* backtracks_out, double* cost_out, int32_t* work_out,
+                             int32_t* trace_out, int trace_iters, int64_t total_batch) {
+    int rc = FBX_OK;
     const size_t m = design->dev.m, D = design->dev.D;
     const size_t trace_bytes = trace_out ? sizeof(int32_t) * 2 * (size_t)B * trace_iters : 0;
     DevBuf de, dc, dchoi, dit, ddy, dbt, dcost, dsw, dtr;
@@ -255,6 +293,7 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
         (trace_bytes && (rc = dtr.alloc(trace_bytes))))
         return rc;
     PgdbExtras ex; ex.eig_rel_tol = eig_rel_tol; ex.trace = trace_bytes ? dtr.as<int32_t>() : nullptr; ex.trace_iters = trace_bytes ? trace_iters : 0;
+    ex.total_batch = total_batch;
     if (ex.trace) FBX_HIP(hipMemsetAsync(ex.trace, 0, trace_bytes, stream()));
     // Page-locked caller buffers and more than one stage of work: H2D, kernels and D2H overlap on separate streams (SURVEY.md
     // 8d prices the path including both transfers).  What cannot be hidden is the H2D of the first stage and the D2H of the
@@ -301,7 +340,7 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
             FBX_HIP(hipStreamWaitEvent(s_k, ev[2 * k], 0));
             PgdbExtras exk = ex;
             if (exk.trace) exk.trace += (size_t)b0 * exk.trace_iters * 2;
-            exk.launch_stream = s_k; exk.ws_items = ws_total; exk.ws_offset = plan[k].ws_offset; exk.total_batch = B;
+            exk.launch_stream = s_k; exk.ws_items = ws_total; exk.ws_offset = plan[k].ws_offset; exk.total_batch = total_batch > B ? total_batch : B;
             rc = pgdb_dispatch(design, nb, de.as<double>() + b0 * m, dc.as<double>() + b0 * m, trace_preserving, mode, max_iters,
                                dchoi.as<double>() + b0 * 2 * D * D, dit.as<int32_t>() + b0, ddy.as<int32_t>() + b0,
                                dbt.as<int32_t>() + b0, dcost.as<double>() + b0, dsw.as<int32_t>() + 4 * b0, exk);

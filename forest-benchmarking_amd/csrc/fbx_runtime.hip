@@ -4,13 +4,16 @@
 #include <cmath>
 #include <complex>
 #include <atomic>
+#include <condition_variable>
 #include <map>
+#include <thread>
 
 namespace fbx {
 
 static thread_local std::string g_err;
-static std::atomic<int> g_device{-1};     // process-wide: one process per GPU
+static std::atomic<int> g_device{-1};     // process-wide: one process per GPU (the primary device of fbx_set_devices)
 static std::atomic<int> g_epoch{0};
+static thread_local int t_device = -1;    // device workers (fbx_set_devices): the device this thread is bound to
 
 // Per-thread context (see fbx_common.hpp).  Contexts are heap objects that are never destroyed behind
 // the runtime's back (a thread_local destructor could run after the HIP runtime has shut down): a thread
@@ -54,7 +57,7 @@ static ThreadCtx* ctx() {
     const int ep = g_epoch.load();
     if (c->epoch != ep) {                 // first use, or the process moved to another device
         c->drop_all();
-        if (hipSetDevice(g_device.load()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipSetDevice(current_device()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError(); c->stream = nullptr; return nullptr;
         }
@@ -91,7 +94,73 @@ int ensure_device() {
 
 hipStream_t stream() { ThreadCtx* c = ctx(); return c ? c->stream : nullptr; }
 int device_epoch() { return g_epoch.load(); }
-int current_device() { return g_device.load(); }
+int current_device() { return t_device >= 0 ? t_device : g_device.load(); }
+
+// ---- fbx_set_devices: one long-lived worker thread per entry of the device list.  A worker is an ordinary client of the library
+// bound to its device (t_device): its context -- stream, staging pool, workspaces -- persists between calls, so a multi-device
+// call allocates nothing once warm.  Workers are never joined (the process may exit with the HIP runtime already gone): they
+// are parked on their condition variable.
+namespace {
+struct Worker {
+    int device = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false;
+    int rc = FBX_OK;
+    std::string err;
+    void loop() {
+        t_device = device;
+        for (;;) {
+            std::function<int()> j;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return has_job; }); j = job; }
+            int r = FBX_ERR_HIP;
+            g_err.clear();
+            if (hipSetDevice(device) == hipSuccess) r = j(); else { (void)hipGetLastError(); g_err = "libfbx: hipSetDevice failed in a device worker"; }
+            { std::lock_guard<std::mutex> lk(mu); rc = r; err = g_err; has_job = false; done = true; }
+            cv.notify_all();
+        }
+    }
+};
+std::mutex g_workers_mu;                  // serialises multi-device calls and changes of the list
+std::vector<Worker*> g_workers;           // one per list entry (a device may appear twice: two workers share it)
+}  // namespace
+
+int device_list_size() { return (int)g_workers.size(); }
+bool in_device_worker() { return t_device >= 0; }
+
+int run_on_devices(int n_jobs, const std::function<int(int)>& job) {
+    std::lock_guard<std::mutex> call(g_workers_mu);
+    const int n = n_jobs < (int)g_workers.size() ? n_jobs : (int)g_workers.size();
+    for (int g = 0; g < n; ++g) {
+        Worker* w = g_workers[g];
+        { std::lock_guard<std::mutex> lk(w->mu); w->job = [&job, g] { return job(g); }; w->done = false; w->has_job = true; }
+        w->cv.notify_all();
+    }
+    int rc = FBX_OK;
+    for (int g = 0; g < n; ++g) {
+        Worker* w = g_workers[g];
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (w->rc != FBX_OK && rc == FBX_OK) { rc = w->rc; set_error("device " + std::to_string(w->device) + ": " + w->err); }
+    }
+    return rc;
+}
+
+const fbx_design* design_on_this_device(const fbx_design* des, int* rc) {
+    *rc = FBX_OK;
+    const int dev = current_device();
+    if (des->device == dev) return des;
+    std::lock_guard<std::mutex> lk(des->replica_mu);
+    auto it = des->replicas.find(dev);
+    if (it != des->replicas.end() && it->second->epoch == device_epoch()) return it->second;
+    fbx_design* rep = nullptr;
+    *rc = fbx_design_create(des->arg_n, des->arg_kind, des->arg_m, des->arg_in_labels.empty() ? nullptr : des->arg_in_labels.data(),
+                            des->arg_paulis.data(), des->arg_coefs.empty() ? nullptr : des->arg_coefs.data(), &rep);
+    if (*rc) return nullptr;
+    if (it != des->replicas.end()) { fbx_design_destroy(it->second); it->second = rep; } else des->replicas[dev] = rep;
+    return rep;
+}
 
 int copy_streams(hipStream_t* in, hipStream_t* out, hipStream_t* compute2) {
     ThreadCtx* c = ctx();
@@ -179,7 +248,7 @@ void pool_give(void* p) {
 
 int check_design(const fbx_design* des, const char* who) {
     if (!des) { set_error(std::string(who) + ": NULL design"); return FBX_ERR_BAD_ARG; }
-    if (des->device != g_device.load() || des->epoch != g_epoch.load()) {
+    if (des->device != current_device() || des->epoch != g_epoch.load()) {
         set_error(std::string(who) + ": the design was created on another device (or before fbx_set_device "
                   "changed the device); create it again");
         return FBX_ERR_BAD_ARG;
@@ -236,6 +305,30 @@ int fbx_set_device(int device_id) {
         g_epoch.fetch_add(1);
     }
     if (!ctx()) { set_error("libfbx: could not create the calling thread's HIP stream"); return FBX_ERR_HIP; }
+    return FBX_OK;
+}
+
+int fbx_set_devices(const int* device_ids, int count) {
+    FBX_REQUIRE(count >= 0 && (count == 0 || device_ids != nullptr), "fbx_set_devices: bad arguments");
+    FBX_REQUIRE(!in_device_worker(), "fbx_set_devices: called from a device worker");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("libfbx: no HIP device visible -- the MI355X path has no CPU fallback");
+        return FBX_ERR_NO_DEVICE;
+    }
+    for (int k = 0; k < count; ++k) FBX_REQUIRE(device_ids[k] >= 0 && device_ids[k] < n, "fbx_set_devices: device id out of range");
+    if (count > 0) { const int rc = fbx_set_device(device_ids[0]); if (rc) return rc; }
+    std::lock_guard<std::mutex> lk(g_workers_mu);
+    // workers are reused where the list agrees with the old one (their contexts stay warm); surplus workers stay parked
+    std::vector<Worker*> next;
+    for (int k = 0; k < (count > 1 ? count : 0); ++k) {
+        Worker* w = nullptr;
+        for (auto& old : g_workers) if (old && old->device == device_ids[k]) { w = old; old = nullptr; break; }
+        if (!w) { w = new Worker(); w->device = device_ids[k]; std::thread(&Worker::loop, w).detach(); }
+        next.push_back(w);
+    }
+    g_workers.swap(next);
     return FBX_OK;
 }
 
@@ -627,12 +720,18 @@ int fbx_design_create(int n_qubits, int kind, int m, const uint8_t* in_labels,
         des->dev.pinvT = (const double*)(b2 + oPi);
     }
     des->device = current_device(); des->epoch = device_epoch();
+    des->arg_n = n_qubits; des->arg_kind = kind; des->arg_m = m;
+    if (in_labels) des->arg_in_labels.assign(in_labels, in_labels + (size_t)m * n);
+    des->arg_paulis.assign(paulis, paulis + (size_t)m * n);
+    if (coefs) des->arg_coefs.assign(coefs, coefs + m);
     *out = des;
     return FBX_OK;
 }
 
 int fbx_design_destroy(fbx_design* design) {
     if (!design) return FBX_OK;
+    for (auto& kv : design->replicas) fbx_design_destroy(kv.second);
+    design->replicas.clear();
     if (design->slab) (void)hipFree(design->slab);
     if (design->slab2) (void)hipFree(design->slab2);
     delete design;

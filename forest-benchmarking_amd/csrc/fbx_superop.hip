@@ -1509,6 +1509,18 @@ int fbx_kraus_sweep(int n_qubits, int64_t B, int K, const double* kraus, const d
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
     const size_t d = (size_t)1 << n_qubits, D = d * d, nm = D * D * 2 * B;
+    // fbx_set_devices: contiguous blocks of the batch on the workers of the device list (the items are independent)
+    const int G = device_list_size();
+    if (G > 1 && !in_device_worker() && B >= 2 * (int64_t)G) {
+        const int64_t per = (B + G - 1) / G;
+        return run_on_devices(G, [&](int g) -> int {
+            const int64_t lo = (int64_t)g * per < B ? (int64_t)g * per : B, nb = (B - lo < per ? B - lo : per);
+            if (nb <= 0) return FBX_OK;
+            const size_t om = (size_t)lo * D * D * 2;
+            return fbx_kraus_sweep(n_qubits, nb, K, kraus + (size_t)lo * K * D * 2, ptm_ref, choi_out ? choi_out + om : nullptr,
+                                   ptm_out ? ptm_out + om : nullptr, chi_out ? chi_out + om : nullptr, fid_out ? fid_out + lo : nullptr);
+        });
+    }
     HostIO io; double *dk, *dr = nullptr, *dc = nullptr, *dp = nullptr, *dx = nullptr, *df = nullptr;
     FBX_TRY(io.in(kraus, (size_t)K * D * 2 * B, &dk));
     if (ptm_ref) FBX_TRY(io.in(ptm_ref, D * D * 2, &dr));

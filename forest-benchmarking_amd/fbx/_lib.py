@@ -43,6 +43,7 @@ PROTOTYPES = {
     "fbx_last_error": [],
     "fbx_device_count": [C.POINTER(C.c_int)],
     "fbx_set_device": [C.c_int],
+    "fbx_set_devices": [C.POINTER(C.c_int), C.c_int],
     "fbx_device_name": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     "fbx_device_id": [C.POINTER(C.c_int), C.c_char_p, C.c_size_t],
     "fbx_synchronize": [],
@@ -165,9 +166,38 @@ def device_count() -> int:
 def set_device(idx: int):
     """Select the GPU of this process (one process per GPU).  Designs created on another device go
     stale (the library refuses them), so the shim's design cache is dropped."""
+    global _device_list
     check(lib().fbx_set_device(int(idx)))
     from . import design as _design
     _design._design_cache.clear()
+    if _device_list and _device_list[0] != int(idx):
+        check(lib().fbx_set_devices(None, 0))                # the list named another primary device: back to one device
+        _device_list = ()
+
+
+_device_list: tuple = ()
+
+
+def set_devices(ids) -> tuple:
+    """One call, several GPUs (fbx_set_devices): ``ids`` = ``'all'`` or a sequence of device ordinals; ids[0] becomes the
+    process's device, and with more than one entry the host-pointer batch entry points (``pgdb_process_estimate_batch``,
+    ``kraus_sweep``) split their batch into contiguous blocks, one per entry, on worker threads inside the library.  An
+    entry may repeat (two workers share that GPU).  A one-entry list restores the single-device behaviour.  Returns the list."""
+    global _device_list
+    ids = tuple(range(device_count())) if isinstance(ids, str) and ids == "all" else tuple(int(i) for i in ids)
+    if not ids:
+        raise ValueError("set_devices: empty device list")
+    if ids == _device_list:
+        return ids
+    before = C.c_int(-1)
+    lib().fbx_device_id(C.byref(before), None, 0)
+    arr = (C.c_int * len(ids))(*ids)
+    check(lib().fbx_set_devices(arr, len(ids)))
+    if before.value != ids[0]:
+        from . import design as _design
+        _design._design_cache.clear()
+    _device_list = ids
+    return ids
 
 
 def release_workspace():

@@ -276,14 +276,19 @@ def linear_inv_process_estimate(results: List[ExperimentResult], qubits: List[in
 
 def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trace_preserving=True,
                                 mode="converge", max_iters=0, return_stats=False, eig_rel_tol=None,
-                                trace_iters=0, out=None):
+                                trace_iters=0, out=None, devices=None):
     """Batched pgdb_process_estimate.  ``mode='converge'`` is the reference loop (optionally
     capped by ``max_iters``); ``mode='fixed'`` runs exactly ``max_iters`` outer iterations.
     ``eig_rel_tol``: the eigensolver tolerance factor for THIS call (None = the process default,
     0 = the reference's trajectory iteration by iteration; include/fbx.h fbx_pgdb_process_ex).
     ``trace_iters`` > 0 adds ``stats['trace']`` [B, trace_iters, 2]: Dykstra iterations and halvings of
     every outer iteration.  ``out``: a C-contiguous complex128 [B, D, D] array for the result; when it and both inputs
-    are page-locked (``fbx._lib.pinned_empty`` / ``pinned_copy``) the library overlaps transfers and kernels."""
+    are page-locked (``fbx._lib.pinned_empty`` / ``pinned_copy``) the library overlaps transfers and kernels.
+    ``devices``: ``'all'`` or a list of GPU ordinals -- the batch is split into contiguous blocks over those GPUs inside
+    this one call (``fbx._lib.set_devices``; results are bit-identical to the single-GPU call); None keeps the process's
+    current device list."""
+    if devices is not None:
+        _lib.set_devices(devices)
     if mode not in ("converge", "fixed"):
         raise ValueError("mode must be 'converge' or 'fixed'")
     e, c = _batch_arrays(design, expectations, total_counts)

@@ -79,6 +79,16 @@ int         fbx_version(void);
 const char* fbx_last_error(void);
 int         fbx_device_count(int* count);
 int         fbx_set_device(int device_id);          /* one process per GPU: call once */
+/* One call, several GPUs (SURVEY.md 8b "fbx_set_devices(ids, count)", 8e "host thread per device does H2D of its slab,
+ * launches, D2H"; the unit that is split is the reference's independent experiment, e.g. one entry of
+ * get_results_by_qubit_groups, observable_estimation.py:1145-1173).  ids[0] becomes the process's device (fbx_set_device);
+ * with count > 1 the HOST-POINTER batch entry points fbx_pgdb_process[_ex] and fbx_kraus_sweep split a batch of at least
+ * 2 x count items into contiguous blocks and run block g on entry g of the list, on a long-lived worker thread of the
+ * library that owns that device's stream, staging pool, workspaces and a replica of the design -- no exchange between
+ * devices, results bit-identical to the single-device call.  A device may be listed more than once (two workers share
+ * it).  count <= 1 restores the single-device behaviour.  The *_dev entry points and everything else stay on the calling
+ * thread's device; multi-PROCESS runs (one rank per GPU, fbx_comm_*) do not need this call. */
+int         fbx_set_devices(const int* device_ids, int count);
 int         fbx_device_name(char* buf, size_t len, int* compute_units);
 int         fbx_device_id(int* ordinal, char* pci_bus_id, size_t len);   /* the selected device; "0000:05:00.0"-style id (len >= 16) */
 int         fbx_synchronize(void);                  /* the calling thread's stream */
