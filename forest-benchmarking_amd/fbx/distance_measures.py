@@ -255,21 +255,80 @@ def watrous_bounds(choi: np.ndarray) -> Tuple[float, float]:
     return nuclear_norm, choi.shape[0] * nuclear_norm
 
 
+def _watrous_sdp_value(delta: np.ndarray, dim: int, restarts: int = 3, seed: int = 0) -> float:
+    """Optimum of the SDP of ``diamond_norm_distance`` below without a general-purpose solver.
+
+    For fixed rho the inner problem  max tr(J W), 0 <= W <= R := 1 (x) rho  is solved in closed form: with W = S X S,
+    S = 1 (x) T, T Hermitian with T^2 = rho, 0 <= X <= 1, the optimum is the sum of the positive eigenvalues of S J S (X = the
+    projector on its positive eigenspace).  What is left is  max over Hermitian T of  g(T) / tr(T^2),
+    g(T) = tr[(S J S)_+]  -- homogeneous of degree two, d^2 real unknowns (4 / 16 / 64 for 1 / 2 / 3 qubits), the partial
+    maximum of a linear function over a convex set, hence concave in rho.  Gradient (envelope theorem, dS = 1 (x) dT):
+    dg = tr(A (1 (x) dT)),  A = X S J + J S X,  i.e.  grad g = Tr_1(A).  Maximised with L-BFGS from a few starts."""
+    from scipy.optimize import minimize
+    big = dim * dim
+    J = (delta + delta.conj().T) / 2
+
+    def unpack(x):
+        t = np.zeros((dim, dim), dtype=np.complex128)
+        iu = np.triu_indices(dim, 1)
+        nd = len(iu[0])
+        t[np.diag_indices(dim)] = x[:dim]
+        t[iu] = x[dim:dim + nd] + 1j * x[dim + nd:]
+        return t + np.triu(t, 1).conj().T
+
+    def pack(g):                                     # gradient wrt the real parameters of a Hermitian matrix
+        iu = np.triu_indices(dim, 1)
+        return np.concatenate([np.real(np.diag(g)), 2 * np.real(g[iu]), 2 * np.imag(g[iu])])
+
+    def neg_quotient(x):
+        t = unpack(x)
+        n2 = float(np.real(np.trace(t @ t)))
+        s = np.kron(np.eye(dim), t)
+        m = s @ J @ s
+        lam, v = np.linalg.eigh((m + m.conj().T) / 2)
+        pos = lam > 0
+        g = float(lam[pos].sum())
+        xp = (v[:, pos] * 1.0) @ v[:, pos].conj().T
+        a = xp @ s @ J
+        a = a + a.conj().T
+        grad = np.einsum("iaib->ab", a.reshape(dim, dim, dim, dim))      # Tr over the first factor
+        q = g / n2
+        return -q, -pack((grad - 2 * q * t) / n2)
+
+    rs = np.random.RandomState(seed)
+    best = 0.0
+    starts = [np.eye(dim)] + [rs.randn(dim, dim) + 1j * rs.randn(dim, dim) for _ in range(max(restarts - 1, 0))]
+    for t0 in starts:
+        t0 = (t0 + t0.conj().T) / 2
+        t0 = t0 / np.sqrt(np.real(np.trace(t0 @ t0)))
+        iu = np.triu_indices(dim, 1)
+        x0 = np.concatenate([np.real(np.diag(t0)), np.real(t0[iu]), np.imag(t0[iu])])
+        res = minimize(neg_quotient, x0, jac=True, method="L-BFGS-B", options={"maxiter": 500, "ftol": 1e-14, "gtol": 1e-10})
+        best = max(best, -float(res.fun))
+    return best
+
+
 def diamond_norm_distance(choi0: np.ndarray, choi1: np.ndarray) -> float:
     """distance_measures.py:378-437: Watrous' simplified SDP for the diamond norm of the difference
-    of two CPTP maps.  A convex program for a general-purpose solver, not a kernel (SURVEY.md 8a
-    row a29): formulated with cvxpy exactly when cvxpy is importable, ``ImportError`` otherwise --
-    the same behaviour as the reference on an installation without cvxpy.
+    of two CPTP maps.  A convex program, not a kernel: formulated with cvxpy exactly as the
+    reference does when cvxpy is importable.
 
     maximise  Re tr(J^H W)   s.t.  W >= 0,  W <= 1 (x) rho,  rho >= 0,  tr rho = 1
-    with J the Hermitian part of choi0 - choi1; the distance is twice the optimum."""
-    import cvxpy as cvx
+    with J the Hermitian part of choi0 - choi1; the distance is twice the optimum.
+
+    Without cvxpy (this image has none) the same optimum comes from ``_watrous_sdp_value`` -- the SDP reduced to a smooth
+    concave maximisation over the d x d density matrix, host numpy / scipy -- pinned to the reference's known answers
+    (tests/test_distance_measures.py:186-218, rtol 1e-2) in tests/test_extras_cpu.py."""
     assert choi0.shape == choi1.shape
     assert choi0.shape[0] == choi1.shape[1]
     big = choi0.shape[0]
     dim = int(np.sqrt(big))
-    delta = choi0 - choi1
+    delta = np.asarray(choi0) - np.asarray(choi1)
     delta = (delta + delta.conj().T) / 2
+    try:
+        import cvxpy as cvx
+    except ImportError:
+        return 2.0 * _watrous_sdp_value(delta, dim)
     rho = cvx.Variable((dim, dim), hermitian=True)
     w = cvx.Variable((big, big), hermitian=True)
     constraints = [rho >> 0, cvx.trace(rho) == 1, w >> 0, cvx.kron(np.eye(dim), rho) - w >> 0]

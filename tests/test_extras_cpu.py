@@ -82,13 +82,44 @@ def test_oracle_spectral_measures(g):
         assert np.allclose(got, g[f"wat_{name}_out"], rtol=1e-12)
 
 
-def test_diamond_norm_needs_cvxpy_like_the_reference():
+def test_diamond_norm_known_answers_of_the_reference():
+    """distance_measures.py:378-437 with the SDP solved by fbx.distance_measures._watrous_sdp_value when cvxpy is absent
+    (it is, in this image): the reference's own known answers (tests/test_distance_measures.py:186-218, rtol 1e-2 there), the
+    two values its notebook records (docs/examples/distance_measures.ipynb cells 34-35), the closed form for a
+    pair of unitaries on two qubits."""
+    from scipy.linalg import fractional_matrix_power as matpow
     from fbx import distance_measures as dm
-    try:
-        import cvxpy  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            dm.diamond_norm_distance(np.eye(4), np.eye(4))
+    X = np.array([[0, 1], [1, 0]], dtype=complex); Y = np.array([[0, -1j], [1j, 0]]); Z = np.diag([1.0 + 0j, -1.0])
+    I = np.eye(2, dtype=complex); H = np.array([[1, 1], [1, -1]], dtype=complex) / np.sqrt(2)
+
+    def kraus2choi(k):
+        v = k.reshape(-1, 1, order="F")
+        return v @ v.conj().T
+
+    def kraus2superop(k):
+        return np.kron(k.conj(), k)
+
+    def superop2choi(sop, d=2):
+        return sop.reshape([d] * 4).swapaxes(0, 3).reshape(d * d, d * d)
+
+    assert np.isclose(dm.diamond_norm_distance(kraus2choi(I), kraus2choi(X)), 2.0, rtol=1e-6)
+    for turns, target in [[1e-3, 3.141591e-3], [3.1e-3, 9.738899e-3], [1e-2, 3.141463e-2], [3.1e-2, 9.735089e-2],
+                          [1e-1, 3.128689e-1], [3.1e-1, 9.358596e-1]]:
+        assert np.isclose(dm.diamond_norm_distance(kraus2choi(X), kraus2choi(matpow(X, 1 + turns))), target, rtol=1e-5)
+    for p, target in [[1e-3, 2e-3], [3.1e-3, 6.2e-3], [1e-2, 2e-2], [3.1e-2, 6.2e-2], [1e-1, 2e-1], [3.1e-1, 6.2e-1]]:
+        c0 = superop2choi(kraus2superop(I) * (1 - p) + kraus2superop(H) * p)
+        assert np.isclose(dm.diamond_norm_distance(c0, superop2choi(kraus2superop(I))), target, rtol=1e-6)
+    assert np.isclose(dm.diamond_norm_distance(kraus2choi(I), kraus2choi(matpow(Y, 0.5))), np.sqrt(2), rtol=1e-6)
+    # notebook: identity against exp(-0.2 i X) and against X
+    from scipy.linalg import expm
+    u = expm(-0.2j * X)
+    assert np.isclose(dm.diamond_norm_distance(kraus2choi(I), kraus2choi(u)), 0.3973386615692544, rtol=1e-6)
+    # two qubits: identity against exp(-i theta ZZ) -- eigenvalues exp(-+ i theta), distance 2 sin(theta)
+    theta = 0.3
+    u2 = expm(-1j * theta * np.kron(Z, Z))
+    assert np.isclose(dm.diamond_norm_distance(kraus2choi(np.eye(4, dtype=complex)), kraus2choi(u2)), 2 * np.sin(theta), rtol=1e-5)
+    # equal channels: zero
+    assert abs(dm.diamond_norm_distance(kraus2choi(H), kraus2choi(H))) < 1e-9
 
 
 def test_oracle_dfe_matches_reference(g):
