@@ -211,7 +211,7 @@ def pgdb_process_estimate(design: Design, expectations, total_counts, trace_pres
     mode='converge': the reference loop (``max_iters`` > 0 adds a cap, an extension).
     mode='fixed':    exactly ``max_iters`` outer iterations, no convergence test.
     Stats: outer iterations, total Dykstra (= eigh) iterations, total backtracking halvings,
-    final cost (real part)."""
+    final cost (real part), and ``trace``: [(Dykstra iterations, halvings)] of every outer iteration."""
     if A is None:
         A = design_matrix_A(design)
     n = counts_vector(expectations, total_counts)
@@ -221,6 +221,7 @@ def pgdb_process_estimate(design: Design, expectations, total_counts, trace_pres
     mu = 3 / (2 * dim ** 2)
     gamma = .3
     iters = dykstra = backtracks = 0
+    trace = []
     new_cost = old_cost
     while True:
         if mode == "fixed" and iters >= max_iters:
@@ -232,6 +233,7 @@ def pgdb_process_estimate(design: Design, expectations, total_counts, trace_pres
         alpha = 1
         new_cost = cost(A, n, est + alpha * update)
         change = gamma * alpha * np.dot(vec(update).conj().T, vec(gradient))
+        bt0 = backtracks
         while new_cost > old_cost + change:
             alpha = .5 * alpha
             change = .5 * change
@@ -239,6 +241,7 @@ def pgdb_process_estimate(design: Design, expectations, total_counts, trace_pres
             backtracks += 1
             if alpha < 1e-15:
                 break
+        trace.append((d_it, backtracks - bt0))
         est += alpha * update
         iters += 1
         if mode == "converge":
@@ -249,5 +252,5 @@ def pgdb_process_estimate(design: Design, expectations, total_counts, trace_pres
         old_cost = new_cost
     if return_stats:
         return est, {"iterations": iters, "dykstra": dykstra, "backtracks": backtracks,
-                     "cost": float(np.real(new_cost).ravel()[0])}
+                     "cost": float(np.real(new_cost).ravel()[0]), "trace": trace}
     return est

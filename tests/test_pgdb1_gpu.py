@@ -56,17 +56,19 @@ def test_oracle_parity_with_equal_counts(gpu, basis):
     from fbx import synthetic, tomography
     B = 48
     design, _, e, c = synthetic.process_batch(1, basis, B)
-    got, st = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, trace_iters=8)
+    got, st = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, trace_iters=160)
     want, wst = _oracle(design, e, c)
     dev = np.abs(got - want).reshape(B, -1).max(axis=1)
     assert dev.max() < 1e-8 and np.mean(dev < 1e-9) >= 0.9
     for b in range(B):
         assert (st["iterations"][b], st["dykstra"][b]) == (wst[b]["iterations"], wst[b]["dykstra"])
-        # halvings: small steps are tested on the exact cost difference; only a final stalled iteration may differ
-        assert abs(int(st["backtracks"][b]) - wst[b]["backtracks"]) <= 50
-        k = min(8, st["iterations"][b])
-        assert st["trace"][b, :k, 0].sum() <= st["dykstra"][b] and np.all(st["trace"][b, :k, 0] >= 1)
-        assert np.all(st["trace"][b, st["iterations"][b]:] == 0)
+        # per-iteration equality with the oracle: Dykstra iterations everywhere, halvings in every iteration before the last
+        # (small steps are tested on the exact cost difference, DESIGN.md 2.1: only the final, stalled iteration may differ)
+        k = int(st["iterations"][b])
+        wtr = np.array(wst[b]["trace"])
+        assert np.array_equal(st["trace"][b, :k, 0], wtr[:, 0])
+        assert np.array_equal(st["trace"][b, :k - 1, 1], wtr[:k - 1, 1])
+        assert np.all(st["trace"][b, k:] == 0)
 
 
 def test_fixed_mode_trajectory_and_counts(gpu):
