@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <rccl/rccl.h>
 
@@ -81,7 +82,12 @@ int rccl_fail(ncclResult_t r, const char* what) {
 }
 #define FBX_RCCL(call, what) do { ncclResult_t _r = (call); if (_r != ncclSuccess) return rccl_fail(_r, what); } while (0)
 
-int need_comm(const char* who) {
+// A collective USES the communicator under a shared lock taken together with the state check; fbx_comm_destroy takes the
+// exclusive one, so it cannot pull the communicator from under a call that is still enqueuing on it (round-3 review).
+std::shared_mutex g_use;
+struct CommUse { std::shared_lock<std::shared_mutex> lk; ncclComm_t comm = nullptr; int world = 0; };
+int need_comm(const char* who, CommUse& use) {
+    use.lk = std::shared_lock<std::shared_mutex>(g_use);
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_state == COMM_INITIALISING) { set_error(std::string(who) + ": fbx_comm_init is still in progress on another thread"); return FBX_ERR_BAD_ARG; }
     if (g_state == COMM_ABANDONED) { set_error(std::string(who) + ": an earlier fbx_comm_init timed out; this process cannot form a communicator any more"); return FBX_ERR_RCCL; }
@@ -89,6 +95,7 @@ int need_comm(const char* who) {
     if (g_comm_device != current_device()) {
         set_error(std::string(who) + ": the communicator belongs to another device"); return FBX_ERR_BAD_ARG;
     }
+    use.comm = g_comm; use.world = g_world;
     return FBX_OK;
 }
 }  // namespace
@@ -116,7 +123,7 @@ int fbx_comm_unique_id(uint8_t* id_out) {
 namespace {
 struct InitBox {
     std::mutex mu; std::condition_variable cv;
-    bool done = false; ncclResult_t result = ncclSuccess; hipError_t hip = hipSuccess; ncclComm_t comm = nullptr;
+    bool done = false, abandoned = false; ncclResult_t result = ncclSuccess; hipError_t hip = hipSuccess; ncclComm_t comm = nullptr;
 };
 }
 
@@ -140,18 +147,26 @@ int fbx_comm_init_timeout(const uint8_t* id_in, int rank, int world, double time
     memcpy(&id, id_in, sizeof id);
     auto box = std::make_shared<InitBox>();
     const auto init_rank = g_rccl.CommInitRank;
-    std::thread([box, init_rank, id, rank, world, device]() {
+    const auto comm_abort = g_rccl.CommAbort;
+    std::thread([box, init_rank, comm_abort, id, rank, world, device]() {
         ncclComm_t comm = nullptr;
         hipError_t he = hipSetDevice(device);
         ncclResult_t r = he == hipSuccess ? init_rank(&comm, world, id, rank) : ncclUnhandledCudaError;
-        std::lock_guard<std::mutex> lk(box->mu);
-        box->hip = he; box->result = r; box->comm = comm; box->done = true;
-        box->cv.notify_all();
+        bool orphan;
+        {
+            std::lock_guard<std::mutex> lk(box->mu);
+            box->hip = he; box->result = r; box->comm = comm; box->done = true;
+            orphan = box->abandoned;
+            box->cv.notify_all();
+        }
+        // the caller gave up waiting: nobody will ever own this communicator -- release it here instead of leaking it
+        if (orphan && r == ncclSuccess && comm) (void)comm_abort(comm);
     }).detach();
     bool finished;
     {
         std::unique_lock<std::mutex> lk(box->mu);
         finished = box->cv.wait_for(lk, std::chrono::duration<double>(timeout_seconds), [&] { return box->done; });
+        if (!finished) box->abandoned = true;
     }
     std::lock_guard<std::mutex> lk(g_mu);
     if (!finished) {
@@ -187,12 +202,13 @@ int fbx_comm_info(int* rank, int* world, int* rccl_version) {
 // What the COMMUNICATOR says about itself (ncclCommUserRank / ncclCommCount / ncclCommCuDevice), not what the
 // launcher's environment claimed: bench.py prints these per rank.
 int fbx_comm_query(int* rank, int* world, int* device) {
-    int rc = need_comm("fbx_comm_query");
+    CommUse use;
+    int rc = need_comm("fbx_comm_query", use);
     if (rc) return rc;
     int r = -1, w = -1, d = -1;
-    FBX_RCCL(g_rccl.CommUserRank(g_comm, &r), "ncclCommUserRank");
-    FBX_RCCL(g_rccl.CommCount(g_comm, &w), "ncclCommCount");
-    FBX_RCCL(g_rccl.CommCuDevice(g_comm, &d), "ncclCommCuDevice");
+    FBX_RCCL(g_rccl.CommUserRank(use.comm, &r), "ncclCommUserRank");
+    FBX_RCCL(g_rccl.CommCount(use.comm, &w), "ncclCommCount");
+    FBX_RCCL(g_rccl.CommCuDevice(use.comm, &d), "ncclCommCuDevice");
     if (rank) *rank = r;
     if (world) *world = w;
     if (device) *device = d;
@@ -201,6 +217,7 @@ int fbx_comm_query(int* rank, int* world, int* device) {
 
 int fbx_comm_destroy(void) {
     ncclComm_t c;
+    std::unique_lock<std::shared_mutex> excl(g_use);        // waits for collectives that are still enqueuing on the communicator
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_state == COMM_INITIALISING) { set_error("fbx_comm_destroy: fbx_comm_init is still in progress on another thread"); return FBX_ERR_BAD_ARG; }
@@ -213,41 +230,45 @@ int fbx_comm_destroy(void) {
 }
 
 int fbx_comm_allgather_dev(const void* d_send, void* d_recv, size_t bytes_per_rank) {
-    int rc = need_comm("fbx_comm_allgather_dev");
+    CommUse use;
+    int rc = need_comm("fbx_comm_allgather_dev", use);
     if (rc) return rc;
     FBX_REQUIRE(bytes_per_rank == 0 || (d_send && d_recv), "fbx_comm_allgather_dev: NULL buffer");
     if (bytes_per_rank == 0) return FBX_OK;
     // slabs are complex128 / float64 / int32 arrays: moved as bytes (8-byte words when the size allows)
     if (bytes_per_rank % 8 == 0)
-        FBX_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank / 8, ncclUint64, g_comm, stream()), "ncclAllGather");
+        FBX_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank / 8, ncclUint64, use.comm, stream()), "ncclAllGather");
     else
-        FBX_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, g_comm, stream()), "ncclAllGather");
+        FBX_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, use.comm, stream()), "ncclAllGather");
     return FBX_OK;
 }
 
 int fbx_comm_broadcast_dev(void* d_buf, size_t bytes, int root) {
-    int rc = need_comm("fbx_comm_broadcast_dev");
+    CommUse use;
+    int rc = need_comm("fbx_comm_broadcast_dev", use);
     if (rc) return rc;
-    FBX_REQUIRE(root >= 0 && root < g_world, "fbx_comm_broadcast_dev: root out of range");
+    FBX_REQUIRE(root >= 0 && root < use.world, "fbx_comm_broadcast_dev: root out of range");
     FBX_REQUIRE(bytes == 0 || d_buf, "fbx_comm_broadcast_dev: NULL buffer");
     if (bytes == 0) return FBX_OK;
-    FBX_RCCL(g_rccl.Broadcast(d_buf, d_buf, bytes, ncclUint8, root, g_comm, stream()), "ncclBroadcast");
+    FBX_RCCL(g_rccl.Broadcast(d_buf, d_buf, bytes, ncclUint8, root, use.comm, stream()), "ncclBroadcast");
     return FBX_OK;
 }
 
 int fbx_comm_allreduce_f64_dev(const double* d_send, double* d_recv, size_t n, int op) {
-    int rc = need_comm("fbx_comm_allreduce_f64_dev");
+    CommUse use;
+    int rc = need_comm("fbx_comm_allreduce_f64_dev", use);
     if (rc) return rc;
     FBX_REQUIRE(op == FBX_COMM_SUM || op == FBX_COMM_MAX || op == FBX_COMM_MIN, "fbx_comm_allreduce_f64_dev: bad op");
     FBX_REQUIRE(n == 0 || (d_send && d_recv), "fbx_comm_allreduce_f64_dev: NULL buffer");
     if (n == 0) return FBX_OK;
     const ncclRedOp_t rop = op == FBX_COMM_SUM ? ncclSum : op == FBX_COMM_MAX ? ncclMax : ncclMin;
-    FBX_RCCL(g_rccl.AllReduce(d_send, d_recv, n, ncclDouble, rop, g_comm, stream()), "ncclAllReduce");
+    FBX_RCCL(g_rccl.AllReduce(d_send, d_recv, n, ncclDouble, rop, use.comm, stream()), "ncclAllReduce");
     return FBX_OK;
 }
 
 int fbx_comm_allreduce_f64(double* host_inout, size_t n, int op) {
-    int rc = need_comm("fbx_comm_allreduce_f64");
+    int rc;
+    { CommUse use; rc = need_comm("fbx_comm_allreduce_f64", use); }     // (checked here; each piece below takes its own shared lock)
     if (rc) return rc;
     FBX_REQUIRE(n == 0 || host_inout, "fbx_comm_allreduce_f64: NULL buffer");
     if (n == 0) return FBX_OK;

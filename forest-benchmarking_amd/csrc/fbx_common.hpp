@@ -47,7 +47,7 @@ int option_pgdb_packed_1q();                     // fbx_set_option("pgdb_packed_
 int ensure_device();     // FBX_OK or FBX_ERR_NO_DEVICE (message set)
 int copy_streams(hipStream_t* in, hipStream_t* out, hipStream_t* compute2);   // the calling thread's H2D / D2H / second compute stream (created on first use)
 int ordering_events(int n, hipEvent_t** out);            // >= n reusable events of the calling thread (no timing)
-bool host_pointer_is_pinned(const void* p);              // page-locked (fbx_host_alloc / hipHostMalloc / hipHostRegister)
+bool host_pointer_is_pinned(const void* p, size_t bytes);   // the whole range is page-locked (fbx_host_alloc / hipHostMalloc / hipHostRegister)
 long long option_pgdb_host_chunk();                      // fbx_set_option("pgdb_host_chunk")
 
 // per-call arguments of fbx_pgdb_process_ex[_dev] beyond those of fbx_pgdb_process

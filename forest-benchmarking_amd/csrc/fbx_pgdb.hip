@@ -145,7 +145,12 @@ static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, cons
             const int packed = option_pgdb_packed_1q();
             const int64_t total = ex.total_batch > B ? ex.total_batch : B;
             const int64_t from = m <= 12 ? FBX_PACKED_1Q_MIN_BATCH : 2 * FBX_PACKED_1Q_MIN_BATCH;
-            if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && total >= from)))
+            // the lane-per-item kernel always solves to full tolerance: a caller who passes an explicit eigensolver tolerance
+            // (fbx_pgdb_process_ex, eig_rel_tol >= 0) gets the wavefront-per-item kernel, which honours it, whatever the batch size
+            // -- so that an experiment's iterates do not depend on how many neighbours it is batched with (packed == 2 forces
+            // the lane-per-item kernel all the same: a test / diagnostics setting, documented in include/fbx.h)
+            const bool explicit_tol = ex.eig_rel_tol >= 0.0;
+            if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && total >= from && !explicit_tol)))
                 return pgdb1_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         }
         if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
@@ -305,9 +310,14 @@ static int pgdb_process_host(const fbx_design* design, int64_t B, const double* 
     // priority stream -- only fills what the bulk's tail leaves idle and is still computing while the bulk's results go
     // down.  (Round 3 first used equal stages: 8 boundaries for 65 536 items, 94-96 % of the resident rate.)
     const int64_t CH = option_pgdb_host_chunk();
-    if (B > CH && host_pointer_is_pinned(expect) && host_pointer_is_pinned(counts) && host_pointer_is_pinned(choi_out)) {
+    if (B > CH && host_pointer_is_pinned(expect, sizeof(double) * B * m) && host_pointer_is_pinned(counts, sizeof(double) * B * m) &&
+        host_pointer_is_pinned(choi_out, sizeof(double) * 2 * B * D * D)) {
         hipStream_t s_in, s_out, s_c2;
         if ((rc = copy_streams(&s_in, &s_out, &s_c2))) return rc;
+        // every failure inside the pipeline leaves through ONE door that waits for all four streams: copies and kernels may
+        // already be queued on them, and the staging blocks go back to the thread's pool when this function returns
+        auto drain = [&]() { (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(stream()); (void)hipStreamSynchronize(s_c2); (void)hipStreamSynchronize(s_out); };
+#define FBX_HIP_P(call) do { hipError_t _e = (call); if (_e != hipSuccess) { drain(); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
         struct Stage { int64_t b0, nb; bool second; int64_t ws_offset; };
         std::vector<Stage> plan;
         const int64_t MID = 65536;
@@ -322,22 +332,22 @@ static int pgdb_process_host(const fbx_design* design, int64_t B, const double* 
         const int64_t ws_total = two_streams ? first + mid_slots : (first > mid_slots ? first : mid_slots);
         const int nst = (int)plan.size();
         hipEvent_t* ev = nullptr;
-        if ((rc = ordering_events(2 * nst + 1, &ev))) return rc;
+        if ((rc = ordering_events(2 * nst + 1, &ev))) return rc;      // (nothing queued yet)
         // (the staging buffers may still be in use by earlier work of this thread's stream)
-        FBX_HIP(hipEventRecord(ev[2 * nst], stream()));
-        FBX_HIP(hipStreamWaitEvent(s_in, ev[2 * nst], 0));
-        FBX_HIP(hipStreamWaitEvent(s_out, ev[2 * nst], 0));
-        FBX_HIP(hipStreamWaitEvent(s_c2, ev[2 * nst], 0));
+        FBX_HIP_P(hipEventRecord(ev[2 * nst], stream()));
+        FBX_HIP_P(hipStreamWaitEvent(s_in, ev[2 * nst], 0));
+        FBX_HIP_P(hipStreamWaitEvent(s_out, ev[2 * nst], 0));
+        FBX_HIP_P(hipStreamWaitEvent(s_c2, ev[2 * nst], 0));
         for (int k = 0; k < nst; ++k) {                        // uploads in stage order, back to back
             const int64_t b0 = plan[k].b0, nb = plan[k].nb;
-            FBX_HIP(hipMemcpyAsync(de.as<double>() + b0 * m, expect + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
-            FBX_HIP(hipMemcpyAsync(dc.as<double>() + b0 * m, counts + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
-            FBX_HIP(hipEventRecord(ev[2 * k], s_in));
+            FBX_HIP_P(hipMemcpyAsync(de.as<double>() + b0 * m, expect + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
+            FBX_HIP_P(hipMemcpyAsync(dc.as<double>() + b0 * m, counts + b0 * m, sizeof(double) * nb * m, hipMemcpyHostToDevice, s_in));
+            FBX_HIP_P(hipEventRecord(ev[2 * k], s_in));
         }
         for (int k = 0; k < nst; ++k) {
             const int64_t b0 = plan[k].b0, nb = plan[k].nb;
             hipStream_t s_k = plan[k].second ? s_c2 : stream();
-            FBX_HIP(hipStreamWaitEvent(s_k, ev[2 * k], 0));
+            FBX_HIP_P(hipStreamWaitEvent(s_k, ev[2 * k], 0));
             PgdbExtras exk = ex;
             if (exk.trace) exk.trace += (size_t)b0 * exk.trace_iters * 2;
             exk.launch_stream = s_k; exk.ws_items = ws_total; exk.ws_offset = plan[k].ws_offset; exk.total_batch = total_batch > B ? total_batch : B;
@@ -345,31 +355,32 @@ static int pgdb_process_host(const fbx_design* design, int64_t B, const double* 
                                dchoi.as<double>() + b0 * 2 * D * D, dit.as<int32_t>() + b0, ddy.as<int32_t>() + b0,
                                dbt.as<int32_t>() + b0, dcost.as<double>() + b0, dsw.as<int32_t>() + 4 * b0, exk);
             if (rc) break;
-            FBX_HIP(hipEventRecord(ev[2 * k + 1], s_k));
-            FBX_HIP(hipStreamWaitEvent(s_out, ev[2 * k + 1], 0));
-            FBX_HIP(hipMemcpyAsync(choi_out + b0 * 2 * D * D, dchoi.as<double>() + b0 * 2 * D * D, sizeof(double) * 2 * nb * D * D,
+            FBX_HIP_P(hipEventRecord(ev[2 * k + 1], s_k));
+            FBX_HIP_P(hipStreamWaitEvent(s_out, ev[2 * k + 1], 0));
+            FBX_HIP_P(hipMemcpyAsync(choi_out + b0 * 2 * D * D, dchoi.as<double>() + b0 * 2 * D * D, sizeof(double) * 2 * nb * D * D,
                                    hipMemcpyDeviceToHost, s_out));
         }
         if (rc) {
-            (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(stream()); (void)hipStreamSynchronize(s_c2); (void)hipStreamSynchronize(s_out);
+            drain();
             // the pipeline wants workspace slots for the whole bulk at once; when the device cannot give that much the staged path
             // below runs the batch in launches that fit (it halves them until the store does)
             if (rc != FBX_ERR_NOMEM) return rc;
             (void)hipGetLastError();
             goto staged;
         }
-        FBX_HIP(hipEventRecord(ev[2 * nst], s_c2));            // the small outputs below follow BOTH compute streams
-        FBX_HIP(hipStreamWaitEvent(stream(), ev[2 * nst], 0));
-        if (iters_out) FBX_HIP(hipMemcpyAsync(iters_out, dit.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
-        if (dykstra_out) FBX_HIP(hipMemcpyAsync(dykstra_out, ddy.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
-        if (backtracks_out) FBX_HIP(hipMemcpyAsync(backtracks_out, dbt.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
-        if (cost_out) FBX_HIP(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
-        if (work_out) FBX_HIP(hipMemcpyAsync(work_out, dsw.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, stream()));
-        if (trace_bytes) FBX_HIP(hipMemcpyAsync(trace_out, dtr.p, trace_bytes, hipMemcpyDeviceToHost, stream()));
-        FBX_HIP(hipStreamSynchronize(stream()));
-        FBX_HIP(hipStreamSynchronize(s_out));
-        FBX_HIP(hipStreamSynchronize(s_in));
+        FBX_HIP_P(hipEventRecord(ev[2 * nst], s_c2));            // the small outputs below follow BOTH compute streams
+        FBX_HIP_P(hipStreamWaitEvent(stream(), ev[2 * nst], 0));
+        if (iters_out) FBX_HIP_P(hipMemcpyAsync(iters_out, dit.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+        if (dykstra_out) FBX_HIP_P(hipMemcpyAsync(dykstra_out, ddy.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+        if (backtracks_out) FBX_HIP_P(hipMemcpyAsync(backtracks_out, dbt.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, stream()));
+        if (cost_out) FBX_HIP_P(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
+        if (work_out) FBX_HIP_P(hipMemcpyAsync(work_out, dsw.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, stream()));
+        if (trace_bytes) FBX_HIP_P(hipMemcpyAsync(trace_out, dtr.p, trace_bytes, hipMemcpyDeviceToHost, stream()));
+        FBX_HIP_P(hipStreamSynchronize(stream()));
+        FBX_HIP_P(hipStreamSynchronize(s_out));
+        FBX_HIP_P(hipStreamSynchronize(s_in));
         return FBX_OK;
+#undef FBX_HIP_P
     }
 staged:
     FBX_HIP(hipMemcpyAsync(de.p, expect, sizeof(double) * B * m, hipMemcpyHostToDevice, stream()));

@@ -190,11 +190,16 @@ int ordering_events(int n, hipEvent_t** out) {
     return FBX_OK;
 }
 
-bool host_pointer_is_pinned(const void* p) {
+bool host_pointer_is_pinned(const void* p, size_t bytes) {
     if (!p) return false;
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable memory
-    return a.type == hipMemoryTypeHost;
+    // first AND last byte of the range that will be handed to hipMemcpyAsync on the copy streams (a caller may pass a
+    // buffer that only starts inside a page-locked allocation)
+    for (const char* q : {(const char*)p, (const char*)p + (bytes ? bytes - 1 : 0)}) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable memory
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
 }
 
 int workspace(WorkspaceSlot slot, size_t bytes, void** out) {

@@ -251,6 +251,7 @@ class RcclComm:
         q = self.query()
         self.rank, self.world, self.device = q["rank"], q["world"], q["device"]
         if (self.rank, self.world) != (int(rank), int(world)):
+            _lib.lib().fbx_comm_destroy()                     # (or the next init fails with "a communicator already exists")
             raise _lib.FbxError(_lib.FBX_ERR_RCCL, f"communicator reports rank {self.rank} of {self.world}, asked for {rank} of {world}")
 
     def query(self) -> dict:

@@ -107,8 +107,11 @@ int         fbx_release_workspace(void);            /* free the calling thread's
  *   cooperative launch; 0 keeps one workgroup per matrix.
  *   "pgdb_packed_1q" (default 1): single-qubit fbx_pgdb_process* with at most 64 settings and at least 8192 experiments (16 384 for designs of more than 12 settings) runs
  *   64 reconstructions per wavefront, one per lane (csrc/fbx_pgdb1.hip; same line-search rule as the other kernels, the
- *   eigensolver always at full tolerance -- eig_rel_tol does not apply); 2 = for every batch size, 0 = never (the
- *   wavefront-per-reconstruction kernel, which smaller batches and larger designs use). */
+ *   eigensolver always at full tolerance; a call that passes an explicit eig_rel_tol >= 0 to fbx_pgdb_process_ex[_dev]
+ *   therefore stays on the wavefront-per-reconstruction kernel whatever its batch size, so that an experiment's iterates do
+ *   not depend on how many neighbours it is batched with); 2 = the lane-per-item kernel for every batch size and every
+ *   tolerance argument (diagnostics / tests), 0 = never (the wavefront-per-reconstruction kernel, which smaller batches and
+ *   larger designs use). */
 int         fbx_set_option(const char* name, double value);
 int         fbx_get_option(const char* name, double* value);
 
