@@ -63,7 +63,7 @@ def parse():
                     help="input-state basis of the process design (default: pauli for pgdb, sic for pgdb3)")
     ap.add_argument("--cpu-sample", type=int, default=6,
                     help="items run through the oracle for cpu_baseline and the parity self-check (0 = skip)")
-    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "pgdb3", "pgdb1"],
+    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "sweep3", "pgdb3", "pgdb1"],
                     help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "
                          "sweep / pgdb3 / pgdb1 = that workload as the primary line")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
@@ -349,16 +349,19 @@ def pgdb3_cpu_baseline(design, e, c, iters, n_iters=10):
 
 
 # ================================================================================== workloads
-def run_sweep(args, comm, _lib, synthetic, with_cpu):
+def run_sweep(args, comm, _lib, synthetic, with_cpu, n=2):
     """BASELINE configs[2]: kraus2choi -> choi2pauli_liouville -> choi2chi + process_fidelity on
     `--sweep-items` random 2-qubit CPTP Kraus sets (K = 4) per GPU, generated ON THE DEVICE from the
-    counter-based Philox stream keyed by the item id, all three representations written."""
-    n, K, D = 2, 4, 16
-    B = args.sweep_items
+    counter-based Philox stream keyed by the item id, all three representations written.
+    n = 3: the d = 8 leg of the same pipeline (64 x 64 matrices, 65 536 items, fused sweep3_kernel)."""
+    K, D = 4, 4 ** n
+    B = args.sweep_items if n == 2 else min(args.sweep_items, 65536)
     lib = _lib.lib()
     d_k = _lib.DeviceBuffer(B * K * D * 16)
     _lib.check(lib.fbx_random_kraus_dev(n, B, K, 17, comm.rank * B, d_k.ptr))
     cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=np.complex128)
+    if n == 3:
+        cnot = np.kron(cnot, np.array([[1, 1], [1, -1]], dtype=np.complex128) / np.sqrt(2))
     ref = np.empty((1, D, D), dtype=np.complex128)
     _lib.check(lib.fbx_convert(_lib.REP_KRAUS, _lib.REP_PAULI_LIOUVILLE, n, 1,
                                _lib.dptr(np.ascontiguousarray(cnot[None, None]).view(np.float64)), 1,
@@ -375,23 +378,25 @@ def run_sweep(args, comm, _lib, synthetic, with_cpu):
     ksec = kms / 1e3 / args.steps
     gbs = B * bytes_item / ksec / 1e9
     fid = d_f.to_array(np.float64, (min(B, 4096),))
-    line = {"metric": "conversion sweep items/sec (2-qubit Kraus -> Choi -> PTM -> chi + process_fidelity)",
+    line = {"metric": f"conversion sweep items/sec ({n}-qubit Kraus -> Choi -> PTM -> chi + process_fidelity)",
             "value": comm.world * B * args.steps / elapsed, "unit": "items/s", "n_gpus": comm.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{B} random 2-qubit CPTP Kraus sets (K=4) per GPU generated on the device "
+            "config": {"workload": f"{B} random {n}-qubit CPTP Kraus sets (K=4) per GPU generated on the device "
                                    f"(Philox4x32-10 keyed by item id), all three representations + fidelity "
                                    f"written, inputs resident in HBM",
                        "items_per_gpu": B, "parallelism": f"shard{comm.world}",
                        "mean_fidelity_to_cnot": float(fid.mean())},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": _profiled("sweep_kernel_hbm_bytes_per_launch"),
-                         "kernel": "sweep2q_pair_kernel", "kernel_ms": 1e3 * ksec,
-                         "note": "achieved = 13 320 algorithmic bytes per item / HIP-event kernel time"}}
+                         "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": _profiled("sweep_kernel_hbm_bytes_per_launch" if n == 2 else "sweep3_kernel_hbm_bytes_per_launch"),
+                         "kernel": "sweep2q_pair_kernel" if n == 2 else "sweep3_kernel", "kernel_ms": 1e3 * ksec,
+                         "note": f"achieved = {bytes_item} algorithmic bytes per item (K x {D * 16} in, 3 x {D * D * 16} + 8 out) / HIP-event kernel time"}}
     if with_cpu and comm.rank == 0:
-        ks = d_k.to_array(np.complex128, (2000, K, 4, 4))
-        line["cpu_baseline"] = sweep_cpu_baseline(ks, ref[0], 2000)
+        n_cpu = 2000 if n == 2 else 60
+        ks = d_k.to_array(np.complex128, (n_cpu, K, 2 ** n, 2 ** n))
+        line["cpu_baseline"] = sweep_cpu_baseline(ks, ref[0], n_cpu)
     for buf in (d_k, d_r, d_c, d_p, d_x, d_f):
         buf.free()
     return line
@@ -817,6 +822,8 @@ def main():
 
     if args.workload == "sweep":
         line = run_sweep(args, comm, _lib, synthetic, with_cpu)
+    elif args.workload == "sweep3":
+        line = run_sweep(args, comm, _lib, synthetic, with_cpu, n=3)
     elif args.workload == "pgdb3":
         line = run_pgdb3(args, comm, _lib, synthetic, with_cpu)
     elif args.workload == "pgdb1":
@@ -826,6 +833,7 @@ def main():
         if args.workload == "all" and comm.world == 1:
             basis = args.in_basis
             secondary.append(run_sweep(args, comm, _lib, synthetic, with_cpu))
+            secondary.append(run_sweep(args, comm, _lib, synthetic, with_cpu, n=3))
             args.in_basis = None
             secondary.append(run_pgdb3(args, comm, _lib, synthetic, with_cpu))
             args.in_basis = "pauli"                          # the stretch form of configs[3]: 13 608 settings

@@ -1118,9 +1118,90 @@ process_fidelity_kernel(int d, long long B, const double* __restrict__ a, int a_
     }
 }
 
-// Three qubits: the sweep is the composition of the pairwise 64 x 64 conversions (one 1024-thread
-// workgroup per item each) and the fidelity reduction -- same results as the fused kernels, unfused.
-static int launch_sweep3(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi, double* ptm,
+// Three qubits, fused (round 4): one 1024-thread workgroup walks its items through ONE 64 x 64 LDS matrix (68 KB with the
+// Kraus operators: two workgroups per CU), kraus2superop -> six in-place butterfly stages -> Pauli-Liouville matrix out with the
+// process fidelity reduced on the way, then kraus2choi -> Choi out -> the same stages -> chi out (a Kraus set is CP, so
+// chi = c2p Choi c2p^H exactly as kraus2chi, superoperator_transformations.py:82-98).  The operators are read once (K KB), the
+// three 64 KB results written once, coalesced 16 bytes per thread: 4 x 1024 + 3 x 65 536 + 8 algorithmic bytes per item for
+// K = 4.  Replaces the composition of three general 64 x 64 conversions + a fidelity kernel behind fbx_kraus_sweep (each of
+// which re-read the operators and kept two matrices in LDS).  Reference: superoperator_transformations.py:100-182, 339-371;
+// distance_measures.py:315-360.
+__global__ void __launch_bounds__(1024)
+sweep3_kernel(long long B, int K, const double* __restrict__ kraus, const double* __restrict__ ptm_ref,
+              double* __restrict__ choi_out, double* __restrict__ ptm_out, double* __restrict__ chi_out,
+              double* __restrict__ fid_out) {
+    constexpr int NQ = 3, d = 8, D = 64, LD = 64, NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* X = (cplx*)smem;
+    double* red = (double*)(X + D * D);
+    cplx* kb = (cplx*)(red + 16);
+    const int t = threadIdx.x;
+    const double inv_d = 1.0 / d;
+    for (long long item = blockIdx.x; item < B; item += gridDim.x) {
+        __syncthreads();                                   // the previous item's readers of X / kb / red are done
+        const double* kr = kraus + item * (long long)K * D * 2;
+        for (int idx = t; idx < K * D; idx += NT) { kb[idx].re = kr[2 * idx]; kb[idx].im = kr[2 * idx + 1]; }
+        __syncthreads();
+        if (ptm_out || fid_out) {
+            for (int idx = t; idx < D * D; idx += NT) {    // kron(conj(K), K)[(i,k)][(j,l)] = conj(K[i][j]) K[k][l]
+                const int row = idx / D, col = idx % D;
+                const int i = row / d, k = row % d, j = col / d, l = col % d;
+                double re = 0.0, im = 0.0;
+                for (int q = 0; q < K; ++q) {
+                    const cplx a = kb[q * D + i * d + j], b = kb[q * D + k * d + l];
+                    re += a.re * b.re + a.im * b.im;
+                    im += a.re * b.im - a.im * b.re;
+                }
+                cplx o; o.re = re; o.im = im;
+                X[idx] = o;
+            }
+            __syncthreads();
+            site_stages<NQ, false, NT, LD>(X, t);
+            double acc = 0.0;
+            double* dst = ptm_out ? ptm_out + item * (long long)D * D * 2 : nullptr;
+            for (int idx = t; idx < D * D; idx += NT) {
+                cplx v = X[site_index<NQ>(idx / D) * LD + site_index<NQ>(idx % D)];
+                v.re *= inv_d; v.im *= inv_d;
+                if (dst) { dst[2 * idx] = v.re; dst[2 * idx + 1] = v.im; }
+                if (fid_out) acc += ptm_ref[2 * idx] * v.re + ptm_ref[2 * idx + 1] * v.im;
+            }
+            if (fid_out) {
+                acc = block_sum<NT>(acc, red);
+                if (t == 0) fid_out[item] = (d * (acc / (double)(d * d)) + 1.0) / (d + 1.0);
+            }
+            __syncthreads();                               // X is rebuilt below
+        }
+        if (choi_out || chi_out) {
+            double* dst = choi_out ? choi_out + item * (long long)D * D * 2 : nullptr;
+            for (int idx = t; idx < D * D; idx += NT) {    // vec(K)[c d + r] = K[r][c]; choi[row][col] = vK[row] conj(vK[col])
+                const int row = idx / D, col = idx % D;
+                double re = 0.0, im = 0.0;
+                for (int q = 0; q < K; ++q) {
+                    const cplx a = kb[q * D + (row % d) * d + row / d], b = kb[q * D + (col % d) * d + col / d];
+                    re += a.re * b.re + a.im * b.im;
+                    im += a.im * b.re - a.re * b.im;
+                }
+                if (dst) { dst[2 * idx] = re; dst[2 * idx + 1] = im; }
+                cplx o; o.re = re; o.im = im;
+                X[idx] = o;
+            }
+            if (chi_out) {
+                __syncthreads();
+                site_stages<NQ, false, NT, LD>(X, t);
+                double* cx = chi_out + item * (long long)D * D * 2;
+                const double sc = inv_d * inv_d;
+                for (int idx = t; idx < D * D; idx += NT) {
+                    const cplx v = X[site_index<NQ>(idx / D) * LD + site_index<NQ>(idx % D)];
+                    cx[2 * idx] = v.re * sc; cx[2 * idx + 1] = v.im * sc;
+                }
+            }
+        }
+    }
+}
+
+// Three qubits, unfused (kept as the reference form: FBX_SWEEP3_COMPOSED=1 in the environment of a diagnostics build, and the
+// fallback for more than 31 Kraus operators): the composition of the pairwise 64 x 64 conversions and the fidelity reduction.
+static int launch_sweep3_composed(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi, double* ptm,
                          double* chi, double* fid) {
     constexpr size_t D = 64;
     DevBuf tmp;
@@ -1496,7 +1577,16 @@ int fbx_kraus_sweep_dev(int n_qubits, int64_t B, int K, const double* d_kraus, c
     FBX_REQUIRE(!d_fid_out || d_ptm_ref, "fbx_kraus_sweep: fidelity output needs a reference PTM");
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    if (n_qubits == 3) return launch_sweep3(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
+    if (n_qubits == 3) {
+        const size_t lds = sizeof(cplx) * 64 * 64 + sizeof(double) * 16 + sizeof(cplx) * (size_t)K * 64;
+        if (lds > 80 * 1024) return launch_sweep3_composed(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
+        FBX_HIP(hipFuncSetAttribute((const void*)sweep3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const unsigned grid = (unsigned)(B < 2048 ? B : 2048);      // two workgroups per CU, four rounds of the chip: persistent over the items
+        hipLaunchKernelGGL(sweep3_kernel, dim3(grid), dim3(1024), lds, stream(), (long long)B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out,
+                           d_chi_out, d_fid_out);
+        FBX_HIP(hipGetLastError());
+        return FBX_OK;
+    }
     if (n_qubits == 1) return launch_sweep<1>(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
     return launch_sweep<2>(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
 }

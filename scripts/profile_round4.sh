@@ -7,7 +7,7 @@
 # bench.py reads: pmc_traffic.json (HBM bytes per launch) and pmc_flops.json (fp64 operations per launch, counted by the hardware).
 set -u
 TAG=${1:-r04}; shift || true
-WLS=${*:-"pgdb lean8192 lean65536 sweep pgdb3 pgdb3pauli pgdb1"}
+WLS=${*:-"pgdb lean8192 lean65536 sweep sweep3 pgdb3 pgdb3pauli pgdb1"}
 cd "$(dirname "$0")/.."
 REPO=$PWD
 export TMPDIR=/tmp
@@ -20,6 +20,7 @@ bench_args() {
         lean8192)   echo "--workload pgdb --batch 8192" ;;
         lean65536)  echo "--workload pgdb --batch 65536" ;;
         sweep)      echo "--workload sweep" ;;
+        sweep3)     echo "--workload sweep3" ;;
         pgdb3)      echo "--workload pgdb3" ;;
         pgdb3pauli) echo "--workload pgdb3 --in-basis pauli" ;;
         pgdb1)      echo "--workload pgdb1" ;;

@@ -415,8 +415,33 @@ def make_process_fixed(n, basis, batch, n_iters=100, n_direct=2, workers=4, tag=
     print("fixed", n, basis, batch, "done")
 
 
+def make_sweep_3q(batch=6):
+    """The 3-qubit leg of BASELINE configs[2]'s pipeline for `batch` random CPTP Kraus sets (K = 4, 8 x 8 operators): what the
+    reference's kraus2choi / kraus2pauli_liouville / kraus2chi / choi2chi / process_fidelity return (round 4: the fused
+    sweep3_kernel is checked against these; superops_3q.npz holds a single item)."""
+    ks = synthetic.kraus_batch(3, 4, batch, seed=34)
+    cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=complex)
+    had = np.array([[1, 1], [1, -1]], dtype=complex) / np.sqrt(2)
+    ref = OT.kraus2pauli_liouville([np.kron(cnot, had)])
+    out = {"kraus4": ks, "ptm_ref": ref,
+           "choi": np.array([OT.kraus2choi(list(k)) for k in ks]),
+           "ptm": np.array([OT.kraus2pauli_liouville(list(k)) for k in ks]),
+           "chi": np.array([OT.kraus2chi(list(k)) for k in ks])}
+    # (the reference's eigh route choi2chi gives the same matrices for these CP inputs, and its Pauli-Liouville matrices are real:
+    # checked here, stored once)
+    assert max(np.abs(OT.choi2chi(c) - x).max() for c, x in zip(out["choi"], out["chi"])) < 1e-12
+    assert np.abs(out["ptm"].imag).max() < 1e-14 and np.abs(ref.imag).max() < 1e-14
+    out["proc_fid"] = np.array([DM.process_fidelity(ref, p) for p in out["ptm"]])
+    out["ptm"], out["ptm_ref"] = out["ptm"].real.copy(), ref.real.copy()
+    np.savez_compressed(os.path.join(HERE, "sweep_3q.npz"), **out)
+    print("sweep 3q done", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     np.random.seed(0)
+    if "--sweep3q" in sys.argv:
+        make_sweep_3q()
+        sys.exit(0)
     if "--fixed2q" in sys.argv:           # timed-mode fixtures, 2 qubits (a few minutes on 6 cores)
         make_process_fixed(2, "pauli", 64, workers=6)
         make_process_fixed(2, "sic", 16, workers=6)

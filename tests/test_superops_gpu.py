@@ -118,6 +118,42 @@ def test_kraus_sweep_fused(gpu, n):
     assert np.abs(fid2 - fid).max() < 1e-15
 
 
+def test_kraus_sweep_3q_fused_kernel_against_reference_fixtures(gpu):
+    """The fused 3-qubit sweep (csrc/fbx_superop.hip sweep3_kernel: kraus -> superoperator -> Pauli-Liouville + fidelity,
+    kraus -> Choi -> chi through one 64 x 64 LDS matrix) on six random CPTP Kraus sets against what the reference's
+    kraus2choi / kraus2pauli_liouville / kraus2chi / process_fidelity returned (tests/golden/make_goldens.py --sweep3q);
+    every subset of outputs gives the same numbers, and a batch larger than the persistent grid (2048 workgroups) repeats
+    them item for item."""
+    from fbx import _lib
+    g = np.load(os.path.join(GOLD, "sweep_3q.npz"))
+    ks = np.ascontiguousarray(g["kraus4"])
+    B, D = ks.shape[0], 64
+    assert B >= 6
+    ref = np.ascontiguousarray(g["ptm_ref"].astype(np.complex128))
+
+    def run(kraus, want):
+        nb = kraus.shape[0]
+        outs = {k: np.empty((nb, D, D), complex) for k in ("choi", "ptm", "chi") if k in want}
+        fid = np.empty(nb) if "fid" in want else None
+        _lib.check(_lib.lib().fbx_kraus_sweep(3, nb, 4, _lib.dptr(kraus.view(np.float64)), _lib.dptr(ref.view(np.float64)),
+                                              *[_lib.dptr(outs[k].view(np.float64)) if k in outs else None for k in ("choi", "ptm", "chi")],
+                                              _lib.dptr(fid) if fid is not None else None))
+        return outs, fid
+
+    outs, fid = run(ks, ("choi", "ptm", "chi", "fid"))
+    assert np.abs(outs["choi"] - g["choi"]).max() < 1e-13
+    assert np.abs(outs["ptm"] - g["ptm"]).max() < 1e-13
+    assert np.abs(outs["chi"] - g["chi"]).max() < 1e-13
+    assert np.abs(fid - g["proc_fid"]).max() < 1e-13
+    for want in (("fid",), ("chi",), ("ptm", "fid"), ("choi",)):
+        o2, f2 = run(ks, want)
+        assert all(np.array_equal(o2[k], outs[k]) for k in o2) and (f2 is None or np.array_equal(f2, fid))
+    big = np.ascontiguousarray(np.tile(ks, (400, 1, 1, 1)))                # 2400 items > 2048 workgroups
+    ob, fb = run(big, ("ptm", "chi", "fid"))
+    assert np.array_equal(ob["chi"].reshape(400, B, D, D), np.broadcast_to(outs["chi"], (400, B, D, D)))
+    assert np.array_equal(fb.reshape(400, B), np.broadcast_to(fid, (400, B)))
+
+
 def test_reference_signature_wrappers(gpu):
     """Same names / call shapes as forest.benchmarking.operator_tools on single matrices."""
     from fbx import operator_tools as ot
