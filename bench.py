@@ -446,7 +446,7 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
                          "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
                          "executed_flop_measured": meas,
                          "measured_frac": (B * meas / ksec / 1e12 / FP64_PEAK_TFLOPS) if meas else None,
-                         "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch") if basis == "sic" else None,
+                         "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch" if basis == "sic" else "pgdb3pauli_kernel_hbm_bytes_per_launch"),
                          "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
                          "executed_flop": ex, "executed_breakdown": {k: round(v) for k, v in parts.items()},
                          "dense_accounting_tflops": tflops, "dense_accounting_frac": tflops / FP64_PEAK_TFLOPS,
