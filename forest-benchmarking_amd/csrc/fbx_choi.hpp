@@ -68,6 +68,7 @@ template <int NQ, class LdsT>
 __device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool warm = false,
                        bool check_basis = false) {
     constexpr int D = LdsT::D;
+    lane = FBX_LOCAL(lane);
     FBX_WAVE_SYNC();                       // previous readers of Ms / Vs are done
     sys_store<D>(L.Ms, lane, x);
     FBX_WAVE_SYNC();
@@ -142,6 +143,7 @@ __device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool wa
 // keep=[0], dims=[d, d].  Stages `x` through Mw.
 template <int NQ, class LdsT>
 __device__ void partial_trace_out(const Blk& x, LdsT& L, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int d = LdsT::d, D = LdsT::D, LD = LdsT::LDpt, LDs = LdsT::LDs;
     FBX_WAVE_SYNC();
     blk_store<D, LD>(L.Mpt, lane, x);
@@ -162,6 +164,7 @@ __device__ void partial_trace_out(const Blk& x, LdsT& L, int lane) {
 // subtract kron(corr / d, I_d) where corr (d x d) is in L.pt
 template <int NQ, class LdsT>
 __device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const LdsT& L, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int d = LdsT::d, D = LdsT::D, LDs = LdsT::LDs, NB = D / 2;
     Blk r = x;
     if (lane < NB * NB) {
@@ -252,6 +255,7 @@ struct BasisStore {
 // block of -kron(C / d, I_d) for the d x d matrix C staged in LDS: what a TP / TNI projection adds to its argument
 template <class LdsT>
 __device__ __forceinline__ Blk tp_change_blk(const cplx* C, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int d = LdsT::d, D = LdsT::D, LDs = LdsT::LDs, NB = D / 2;
     Blk r = blk_zero();
     if (lane < NB * NB) {
@@ -493,6 +497,7 @@ __device__ __forceinline__ void pauli_coeff_position(int i, int j, int& row, int
 // E staged in Mw (destroyed) -> real coefficients Rb[D*D]
 template <int NQ>
 __device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
 #pragma unroll
     for (int t = NQ - 1; t >= 0; --t) {            // input-qubit sites: row bit NQ + t, col bit NQ + t
@@ -514,6 +519,7 @@ __device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
 // real coefficients Rb -> Choi block of this lane (Mw is scratch)
 template <int NQ>
 __device__ Blk pauli_real_to_choi_blk(const double* Rb, cplx* Mw, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
     FBX_WAVE_SYNC();
     for (int idx = lane; idx < D * D; idx += 64) {

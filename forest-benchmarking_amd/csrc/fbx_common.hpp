@@ -277,6 +277,13 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // them in the 1024-thread kernels, which have 128 registers: hoisted, they are spilled at kernel entry and re-read from
 // scratch (HBM latency, one wait each) in front of every phase.
 __device__ __forceinline__ int opaque(int v) { __asm__ volatile("" : "+v"(v)); return v; }
+// FBX_LOCAL(lane): opaque in the translation units that define FBX_LOCAL_INDEX_MATH (the register-starved two-waves-per-SIMD
+// 2-qubit kernel), the plain value elsewhere (the one-wave kernel has the registers and keeps its hoisted constants).
+#ifdef FBX_LOCAL_INDEX_MATH
+#define FBX_LOCAL(x) fbx::opaque(x)
+#else
+#define FBX_LOCAL(x) (x)
+#endif
 
 // Raw buffer access (buffer_load / buffer_store with an SGPR resource, ONE 32-bit VGPR byte offset and an SGPR / immediate row
 // offset) for per-lane rows of a wave-private slice: no 64-bit per-lane address arithmetic, which the compiler otherwise hoists

@@ -318,6 +318,7 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
                                 double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(LS == 64, "every lane of the wavefront owns one 2x2 block");
+    lane = FBX_LOCAL(lane);
     const int I = lane / NB, J = lane % NB;
     const int me = lane;
     int wm[4], wv[4];
@@ -542,6 +543,7 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
 #ifndef FBX_ROTATE_VALU
 typedef double fbx_v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void jacobi_rotate_into_basis_mfma16(cplx* Ms, const cplx* Vs, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int NB = 8, PS = sys_plane<16>();
     const int c = lane & 15, g = lane >> 4;
     auto at = [](int r, int cc) { return ((r & 1) * 2 + (cc & 1)) * PS + (r >> 1) * NB + (cc >> 1); };
@@ -589,6 +591,7 @@ __device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, in
 // terms with lam[k] == 0 are skipped (wave-uniform branch).
 template <int N>
 __device__ __forceinline__ Blk reconstruct_blk(const cplx* Vs, const double* lam, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     Blk out = blk_zero();
     const bool act = lane < LS;

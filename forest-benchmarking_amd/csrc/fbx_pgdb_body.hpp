@@ -100,6 +100,7 @@ struct PgdbLds {
 // took 16k cycles per call for the 36-state design.
 template <int NQ>
 __device__ void predict_table(const double* Rb, const double* Ct, double* T, int S, int lane) {
+    lane = FBX_LOCAL(lane);
     constexpr int D = ChoiLds<NQ>::D, STEP = 64 / D;
     const int i = lane % D, q = lane / D;
     double r[D];
@@ -136,7 +137,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 #define FBX_FAT_SLOT_UNROLL MAXJ     // (experiment: 1 = the one-wave kernel loops over its slots too)
 #endif
     constexpr int SLOT_UNROLL = LEAN ? 1 : FBX_FAT_SLOT_UNROLL;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;            // (re-made opaque per phase in the lean kernel: FBX_LOCAL, fbx_common.hpp)
     const long long item = item_;
     const int m = des.m, S = des.S;
     PgdbLds<NQ, LEAN> L;
@@ -303,6 +304,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
+        lane = FBX_LOCAL(lane);
         const int dyk_before = dyk, bt_before = backtracks;       // per-iteration trace (fbx_pgdb_process_ex)
         // A stored basis is the product of all rotations applied to its chain since the last cold start, and every
         // rotation costs ~1e-16 of unitarity: the chains are dropped once they have absorbed FBX_BASIS_CHAIN_SWEEPS
@@ -416,6 +418,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 #else
                                                &basis);
 #endif
+        lane = FBX_LOCAL(lane);
         const Blk upd = blk_sub(proj, est);
         Blk grad = blk_zero();
         if (lane < NACT) {

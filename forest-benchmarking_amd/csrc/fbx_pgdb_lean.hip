@@ -1,6 +1,12 @@
 // fbx_pgdb_lean.hip -- the two-wavefronts-per-SIMD form of the 2-qubit PGDB kernel (batches that put more than one reconstruction
 // on a SIMD anyway: BASELINE configs[4], 8192 per GPU).  Its own translation unit so that it keeps the compiler's default
 // instruction scheduling (fbx_pgdb_body.hpp).  Reference: tomography.py:542-633, operator_tools/project_superoperators.py:19-144.
+// -DFBX_LEAN_LOCAL_INDEX_MATH: per-phase index arithmetic recomputed instead of hoisted (fbx_common.hpp, FBX_LOCAL).  Measured in
+// round 4: scratch 160 -> 32 B per lane, and 62.5 against 61.8 ms at 8192 reconstructions (same box) -- the recomputation costs more
+// issue slots than the 32 spilled constants cost waits.  Off by default.
+#ifdef FBX_LEAN_LOCAL_INDEX_MATH
+#define FBX_LOCAL_INDEX_MATH
+#endif
 #include "fbx_pgdb_body.hpp"
 
 namespace fbx {
