@@ -465,8 +465,9 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
 
 def run_pgdb1(args, comm, _lib, synthetic, with_cpu):
     """Single-qubit process tomography to convergence (what the reference's own tests and notebook run,
-    tests/test_process_tomography.py:72-112), 2^20 experiments per GPU on the lane-per-reconstruction kernel
-    (csrc/fbx_pgdb1.hip): 16 384 distinct experiments of the SURVEY 8d recipe, each 64 times."""
+    tests/test_process_tomography.py:72-112), 2^20 experiments per GPU, one reconstruction per lane (csrc/fbx_pgdb1.hip; at
+    this size one launch per outer iteration, the reconstructions re-binned by Dykstra count in between): 16 384 distinct
+    experiments of the SURVEY 8d recipe, each 64 times."""
     distinct, reps = 16384, 64
     B = distinct * reps
     design, _, e0, c0 = synthetic.process_batch(1, "pauli", distinct, first_item=distinct * comm.rank)
@@ -501,11 +502,13 @@ def run_pgdb1(args, comm, _lib, synthetic, with_cpu):
                        "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean())},
             "roofline": {"bound": "mfma", "pipe": "fp64 VALU (one reconstruction per lane)", "achieved": B * ex / ksec / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "pgdb1_packed_kernel", "kernel_ms": 1e3 * ksec, "executed_flop": ex,
-                         "executed_flop_measured": _measured_flop("pgdb1_packed_kernel", B),
+                         "traffic": None, "kernel": "pgdb1_step_kernel (all launches of one call: one per outer iteration)",
+                         "kernel_ms": 1e3 * ksec, "executed_flop": ex,
+                         "executed_flop_measured": _measured_flop("pgdb1_step_kernel", B),
                          "note": "flops executed per reconstruction (work counters x per-unit counts from the source) x batch / "
-                                 "HIP-event kernel time; lanes idle through divergence (a wavefront runs the longest Dykstra / "
-                                 "line-search trip count of its 64 lanes) are not counted as work"}}
+                                 "HIP-event time of the call; lanes idle through divergence (a wavefront runs the longest Dykstra / "
+                                 "line-search trip count of its 64 lanes) are not counted as work; executed_flop_measured = the "
+                                 "hardware's count summed over the call's launches (idle lanes included)"}}
     if with_cpu and comm.rank == 0:
         od, oe, _, _ = _oracle()
         d = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)

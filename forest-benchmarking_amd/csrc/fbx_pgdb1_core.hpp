@@ -22,6 +22,14 @@
 #include <cstdint>
 #include <cmath>
 
+// profiling hooks (defined by fbx_pgdb1.hip in -DFBX_P1_PROFILE builds only): wall cycles between marks, wave-level trip counts
+#ifndef P1_PROF_BEGIN
+#define P1_PROF_BEGIN
+#define P1_PROF(k)
+#define P1_COUNT(k)
+#define P1_COUNT_LANES(k, n)
+#endif
+
 #ifdef FBX_PGDB1_HOST
 #define FBX_P1 inline
 namespace fbx {
@@ -203,6 +211,7 @@ FBX_P1 int p1_eigh(H4& A, V4& V, bool warm = false) {
     }
     int sweeps = 0;
     for (; sweeps < P1_MAX_SWEEPS; ++sweeps) {
+        P1_COUNT(9); P1_COUNT_LANES(10, 1);
         double off = 0.0, dg = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) off = fma(A.re[k], A.re[k], fma(A.im[k], A.im[k], off));
@@ -311,6 +320,7 @@ FBX_P1 H4 p1_proj_physical(const H4& x, bool trace_preserving, int& iters, int& 
     double c0 = 0.0;
     for (int it = 0; it < P1_MAX_DYKSTRA; ++it) {
         ++iters;
+        P1_COUNT(7); P1_COUNT_LANES(8, 1);
         const H4 cp = p1_proj_cp(u, sweeps, terms, basis);
         const H4 new_cp = h4_sub(cp, u);
         const double s1 = h4_norm2(h4_sub(new_cp, p));
@@ -524,10 +534,14 @@ FBX_P1 double p1_line_small(const P1Line& L, double alpha) {
 #pragma unroll
     for (int k = P1_NS - 2; k >= 0; --k) q = fma(alpha, q, L.S[k]);
     double acc = alpha * q;
+    // the exact slots: empty ones (n = 0, log 1 - 0) add nothing -- and a stalled line search is 50 of these steps while the
+    // other lanes of the wavefront wait, so a wavefront without any flagged outcome skips the two logarithms altogether
+    if (L.nflag > 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double pa = fma(alpha, L.fpu[i], L.fpe[i]);
-        acc += L.fn[i] * p1_log(pa < P1_EPS ? P1_EPS : pa) - L.fbase[i];      // (empty slots: n = 0, log 1 - 0)
+        for (int i = 0; i < 2; ++i) {
+            const double pa = fma(alpha, L.fpu[i], L.fpe[i]);
+            acc += L.fn[i] * p1_log(pa < P1_EPS ? P1_EPS : pa) - L.fbase[i];
+        }
     }
     return acc;
 }
@@ -537,6 +551,7 @@ struct P1State {
     H4 est;
     P1Basis basis;
     double old_cost, new_cost;
+    double last_decrease;        // old_cost - new_cost of the last outer iteration (a scheduling hint, never part of the result)
     int iters, dyk, backtracks, sweeps, terms, ls_full, ls_sums;
 };
 template <class Des, class NT>
@@ -550,6 +565,7 @@ FBX_P1 void p1_begin(const Des& des, const NT& nt, P1State& st) {
     p1_choi_to_pauli(st.est, R);
     st.old_cost = p1_cost(des, nt, R);                    // tomography.py:565
     st.new_cost = st.old_cost;
+    st.last_decrease = 1.0;
     st.ls_full = 1; st.ls_sums = 0;
 }
 // One outer iteration (tomography.py:570-592).  Returns true when the reconstruction is finished.
@@ -558,11 +574,15 @@ FBX_P1 bool p1_outer_iteration(const Des& des, const NT& nt, P1State& st, bool t
                                int& dyk_this, int& bt_this) {
     if (mode == 1 /* FBX_MODE_FIXED */ && st.iters >= max_iters) { dyk_this = 0; bt_this = 0; return true; }
     const int dyk_before = st.dyk, bt_before = st.backtracks;
+    P1_PROF_BEGIN;
+    P1_COUNT(5); P1_COUNT_LANES(6, 1);
     double Re[16];
     p1_choi_to_pauli(st.est, Re);
     const H4 grad = p1_gradient(des, nt, Re);
     const H4 x = h4_axpy(st.est, -(8.0 / 3.0), grad);          // est - gradient / mu, mu = 3 / (2 d^2)
+    P1_PROF(0);
     const H4 proj = p1_proj_physical(x, trace_preserving, st.dyk, st.sweeps, st.terms, st.basis);
+    P1_PROF(1);
     const H4 upd = h4_sub(proj, st.est);
     const double ipr = h4_dot(upd, grad);
     double Ru[16];
@@ -577,18 +597,21 @@ FBX_P1 bool p1_outer_iteration(const Des& des, const NT& nt, P1State& st, bool t
         new_cost = p1_cost(des, nt, Ra);
         ++st.ls_full;
     }
+    P1_PROF(2);
     bool ls_exact = false, prepared = false;
     double ls_diff = 0.0;
     P1Line line;
     line.ok = false; line.rmax = 0.0;
     while (ls_exact ? (ls_diff > change) : (new_cost > st.old_cost + change)) {
         alpha *= 0.5; change *= 0.5;
-        if (!prepared) { p1_line_prepare(des, nt, Re, Ru, line); prepared = true; ++st.ls_sums; }
+        P1_COUNT(11); P1_COUNT_LANES(12, 1);
+        if (!prepared) { P1_COUNT(13); p1_line_prepare(des, nt, Re, Ru, line); prepared = true; ++st.ls_sums; }
         if (line.ok && alpha * line.rmax < P1_SMALL_STEP) {
             const double acc = p1_line_small(line, alpha);
             ls_exact = true; ls_diff = -acc;
             new_cost = st.old_cost - acc;
         } else {
+            P1_COUNT(14); P1_COUNT_LANES(15, 1);
             double Ra[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) Ra[k] = fma(alpha, Ru[k], Re[k]);
@@ -599,6 +622,7 @@ FBX_P1 bool p1_outer_iteration(const Des& des, const NT& nt, P1State& st, bool t
         ++st.backtracks;
         if (alpha < P1_ALPHA_MIN) break;
     }
+    P1_PROF(3);
     st.est = h4_axpy(st.est, alpha, upd);                     // tomography.py:588
     st.new_cost = new_cost;
     ++st.iters;
@@ -608,6 +632,7 @@ FBX_P1 bool p1_outer_iteration(const Des& des, const NT& nt, P1State& st, bool t
         if (!(st.old_cost - new_cost >= P1_STOP)) done = true;        // tomography.py:589; a NaN cost also ends the loop
         if (max_iters > 0 && st.iters >= max_iters) done = true;
     } else if (st.iters >= max_iters) done = true;
+    st.last_decrease = st.old_cost - new_cost;
     st.old_cost = new_cost;
     return done;
 }

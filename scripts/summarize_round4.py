@@ -23,10 +23,13 @@ WL = {"pgdb": ("pgdb_kernel<2, 9>", "pgdb_kernel_hbm_bytes_per_launch", 1024, "p
       "sweep3": ("sweep3_kernel", "sweep3_kernel_hbm_bytes_per_launch", 65536, "sweep3_kernel"),
       "pgdb3": ("pgdb3_kernel<4>", "pgdb3_kernel_hbm_bytes_per_launch", 256, "pgdb3_kernel<4>"),
       "pgdb3pauli": ("pgdb3_kernel<14>", "pgdb3pauli_kernel_hbm_bytes_per_launch", 256, "pgdb3_kernel<14>"),
-      "pgdb1": ("pgdb1_packed_kernel", "pgdb1_kernel_hbm_bytes_per_launch", 1 << 20, "pgdb1_packed_kernel")}
+      "pgdb1": ("pgdb1_step_kernel", "pgdb1_kernel_hbm_bytes_per_launch", 1 << 20, "pgdb1_step_kernel")}
+# workloads whose bench step is MANY launches of the kernel (one per outer iteration): counters are summed over a step's launches.
+# The --pmc passes run bench.py with --steps 2 --warmup 1 = 3 calls.
+PER_CALL = {"pgdb1": 3}
 
 lines, summary, traffic, flops = [], {"tag": tag, "kernels": {}}, {"tag": tag}, {"tag": tag}
-summary["note"] = ("means per launch of each workload's dominant kernel; separate --pmc passes (never combined with a trace domain); "
+summary["note"] = ("means per launch of each workload's dominant kernel (pgdb1: sums over the launches of one call); separate --pmc passes (never combined with a trace domain); "
                    "bench.py <workload> --steps 2 --warmup 1 --cpu-sample 0")
 traffic["note"] = ("FETCH_SIZE(KiB) x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE(KiB) x 1024; "
                    "separate --pmc passes; per launch of the bench workload")
@@ -60,7 +63,7 @@ for wl in wls:
             for r in csv.DictReader(open(f)):
                 if sub in r.get("Kernel_Name", ""):
                     pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    e = {c: {"mean": sum(v) / len(v), "launches": len(v)} for c, v in pmc.items()}
+    e = {c: {"mean": sum(v) / (PER_CALL[wl] if wl in PER_CALL else len(v)), "launches": len(v)} for c, v in pmc.items()}
     g = lambda c: e[c]["mean"] if c in e else None
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
         e["hbm_bytes_per_launch"] = g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE") * 1024

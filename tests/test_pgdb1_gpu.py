@@ -228,3 +228,70 @@ def test_explicit_eigensolver_tolerance_keeps_one_kernel_whatever_the_batch(gpu)
     assert np.array_equal(sb["iterations"], se["iterations"]) and sb["jacobi_sweeps"].sum() <= se["jacobi_sweeps"].sum()
     assert np.abs(big - exact).max() < 1e-9 and np.abs(dflt - exact).max() < 1e-8
     assert np.array_equal(sd["iterations"], se["iterations"])
+
+
+class _env:
+    """environment knobs of the binned path (read by the library at every dispatch)"""
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("basis,tp,mode,iters", [("pauli", True, "converge", 0), ("sic", True, "converge", 0),
+                                                 ("pauli", False, "converge", 0), ("pauli", True, "fixed", 12),
+                                                 ("pauli", True, "converge", 7)])
+def test_binned_relaunch_is_bit_identical_to_the_persistent_kernel(gpu, basis, tp, mode, iters):
+    """One launch per outer iteration with the reconstructions re-binned by Dykstra count in between (large batches,
+    csrc/fbx_pgdb1.hip) against the persistent-lanes kernel: every output bit-identical -- estimates, counters, costs, work
+    counters and the per-iteration trace -- on a batch that is not a multiple of 64, cut into three chunks, with the
+    run-to-completion launch taking over at 700 reconstructions left."""
+    from fbx import synthetic, tomography
+    B = 20000 + 37
+    design, _, e, c = synthetic.process_batch(1, basis, B)
+    kw = dict(trace_preserving=tp, mode=mode, max_iters=iters, return_stats=True, trace_iters=24)
+    with _env(FBX_P1_BINNED=0):
+        ref, rst = tomography.pgdb_process_estimate_batch(design, e, c, **kw)
+    with _env(FBX_P1_BINNED=2, FBX_P1_TAIL=700, FBX_P1_CHUNK=8192, FBX_P1_CHECK=3):
+        got, gst = tomography.pgdb_process_estimate_batch(design, e, c, **kw)
+    assert np.array_equal(ref, got)
+    for k in rst:
+        assert np.array_equal(np.asarray(rst[k]), np.asarray(gst[k])), k
+    # and it is what the oracle computes
+    want, wst = _oracle(design, e[:6], c[:6], trace_preserving=tp, mode=mode, max_iters=iters)
+    assert np.abs(got[:6] - want).max() < (1e-9 if mode == "converge" else 1e-8)
+    for b in range(6):
+        assert gst["iterations"][b] == wst[b]["iterations"]
+
+
+def test_binned_relaunch_edge_cases(gpu):
+    from fbx import synthetic, tomography
+    design, _, e, c = synthetic.process_batch(1, "sic", 300)
+    with _env(FBX_P1_BINNED=0):
+        ref = tomography.pgdb_process_estimate_batch(design, e, c)
+    # the whole batch below the tail threshold (first launch, then the run-to-completion one), one item, an empty batch,
+    # a poisoned item whose neighbours are untouched, one outer iteration
+    with _env(FBX_P1_BINNED=2):
+        assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c), ref)
+        assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e[:1], c[:1])[0], ref[0])
+        assert tomography.pgdb_process_estimate_batch(design, e[:0], c[:0]).shape == (0, 4, 4)
+        e2 = e.copy(); e2[70, 2] = np.nan
+        bad = tomography.pgdb_process_estimate_batch(design, e2, c)
+        keep = np.arange(300) != 70
+        assert not np.all(np.isfinite(bad[70])) and np.array_equal(bad[keep], ref[keep])
+        with _env(FBX_P1_BINNED=0):
+            one_ref = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=1)
+        assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=1), one_ref)
+        z = tomography.pgdb_process_estimate_batch(design, e[:3], c[:3], mode="fixed", max_iters=0)
+        assert np.array_equal(z, np.broadcast_to(np.eye(4) / 2, (3, 4, 4)))
+    with _env(FBX_P1_BINNED=2, FBX_P1_TAIL=16, FBX_P1_CHECK=1):
+        assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c), ref)
