@@ -502,7 +502,8 @@ def run_pgdb1(args, comm, _lib, synthetic, with_cpu):
                        "mean_dykstra_iters": float(dyk.mean()), "mean_jacobi_sweeps": float(work[:, 0].mean())},
             "roofline": {"bound": "mfma", "pipe": "fp64 VALU (one reconstruction per lane)", "achieved": B * ex / ksec / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "pgdb1_step_kernel (all launches of one call: one per outer iteration)",
+                         "traffic": _profiled("pgdb1_kernel_hbm_bytes_per_launch") if B == 1 << 20 else None,
+                         "kernel": "pgdb1_step_kernel (all launches of one call: one per outer iteration)",
                          "kernel_ms": 1e3 * ksec, "executed_flop": ex,
                          "executed_flop_measured": _measured_flop("pgdb1_step_kernel", B),
                          "note": "flops executed per reconstruction (work counters x per-unit counts from the source) x batch / "
