@@ -29,3 +29,17 @@ for i, n in enumerate(names):
 print('per eigh jacobi cycles %.0f ; dykstra iters mean %.1f max %d; backtracks mean %.1f max %d' % (
     ph[:, 0].sum() / st['dykstra'].sum(), st['dykstra'].mean(), st['dykstra'].max(), st['backtracks'].mean(), st['backtracks'].max()))
 print('per cost eval cycles %.0f' % (ph[:, 5].sum() / (st['backtracks'].sum() + 100 * B)))
+if os.environ.get("FBX_PHASE_SAVE"):
+    # per-item wave cycles + a list-scheduling model of the launch: 2 x 1024 wave slots (two-waves kernel) or 1024 (one-wave kernel)
+    import heapq
+    np.save(os.environ["FBX_PHASE_SAVE"], ph)
+    def makespan(order, dur, slots):
+        h = [0.0] * slots
+        heapq.heapify(h)
+        for i in order:
+            heapq.heappush(h, heapq.heappop(h) + dur[i])
+        return max(h)
+    slots = 2048 if B >= 2048 else 1024
+    ideal = tot.sum() / slots
+    print('cycles per item: max/mean %.3f p99/mean %.3f p90/mean %.3f' % (tot.max() / tot.mean(), np.percentile(tot, 99) / tot.mean(), np.percentile(tot, 90) / tot.mean()))
+    print('list scheduling on %d slots: natural order makespan / ideal %.4f; longest first %.4f' % (slots, makespan(range(B), tot, slots) / ideal, makespan(np.argsort(-tot), tot, slots) / ideal))
