@@ -310,7 +310,8 @@ static int pgdb1_binned_chunk(const fbx_design* des, long long first, long long 
     const size_t region_doubles = (size_t)(P1_NB / 2) * bins.cap_slots * P1_NF;          // one set of bin regions
     const size_t tab_doubles = (size_t)n * 2 * m;
     void* w = nullptr;
-    { const int rc = workspace(WS_PGDB1_BINS, 256 + (tab_doubles + 2 * region_doubles) * sizeof(double), &w); if (rc) return rc; }
+    // (no room for the bins: the caller falls back to the persistent kernel, which needs none)
+    if (workspace(WS_PGDB1_BINS, 256 + (tab_doubles + 2 * region_doubles) * sizeof(double), &w) != FBX_OK) { (void)hipGetLastError(); return FBX_ERR_NOMEM; }
     int* cnt = (int*)w;                                   // three count arrays of 16 ints
     bins.tab = (double*)((char*)w + 256);
     double* region[2] = {bins.tab + tab_doubles, bins.tab + tab_doubles + region_doubles};
@@ -377,12 +378,15 @@ int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const doub
         // (a stage of the pipelined host entry point shares the calling thread's workspaces with the stage on the other stream:
         // those stay with the persistent kernel)
         if (!ex.launch_stream && !(mode == FBX_MODE_FIXED && max_iters == 0) && (binned == 2 || (binned == 1 && B >= from))) {
-            for (long long f = 0; f < B; f += chunk) {
-                const long long n = B - f < chunk ? B - f : chunk;
-                const int rc = pgdb1_binned_chunk(des, f, n, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex, tail, (int)every);
-                if (rc) return rc;
+            const long long chunk_ = chunk < 4096 ? 4096 : (chunk > (1 << 22) ? (1 << 22) : chunk);
+            int rc = FBX_OK;
+            for (long long f = 0; f < B && rc == FBX_OK; f += chunk_) {
+                const long long n = B - f < chunk_ ? B - f : chunk_;
+                rc = pgdb1_binned_chunk(des, f, n, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex, tail, every < 1 ? 1 : (int)every);
             }
-            return FBX_OK;
+            // out of device memory for the bins (before anything of the chunk was launched: results are per item, the chunks
+            // already done stay valid and are simply recomputed): the persistent kernel below takes the whole batch
+            if (rc != FBX_ERR_NOMEM) return rc;
         }
     }
     const size_t lds = sizeof(double) * 2 * (size_t)des->dev.m * 64;
