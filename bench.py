@@ -353,7 +353,7 @@ def run_sweep(args, comm, _lib, synthetic, with_cpu, n=2):
     """BASELINE configs[2]: kraus2choi -> choi2pauli_liouville -> choi2chi + process_fidelity on
     `--sweep-items` random 2-qubit CPTP Kraus sets (K = 4) per GPU, generated ON THE DEVICE from the
     counter-based Philox stream keyed by the item id, all three representations written.
-    n = 3: the d = 8 leg of the same pipeline (64 x 64 matrices, 65 536 items, fused sweep3_kernel)."""
+    n = 3: the d = 8 leg of the same pipeline (64 x 64 matrices, 65 536 items, fused sweep3_regs_kernel)."""
     K, D = 4, 4 ** n
     B = args.sweep_items if n == 2 else min(args.sweep_items, 65536)
     lib = _lib.lib()
@@ -391,7 +391,7 @@ def run_sweep(args, comm, _lib, synthetic, with_cpu, n=2):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS,
                          "traffic": _profiled("sweep_kernel_hbm_bytes_per_launch" if n == 2 else "sweep3_kernel_hbm_bytes_per_launch"),
-                         "kernel": "sweep2q_pair_kernel" if n == 2 else "sweep3_kernel", "kernel_ms": 1e3 * ksec,
+                         "kernel": "sweep2q_pair_kernel" if n == 2 else "sweep3_regs_kernel", "kernel_ms": 1e3 * ksec,
                          "note": f"achieved = {bytes_item} algorithmic bytes per item (K x {D * 16} in, 3 x {D * D * 16} + 8 out) / HIP-event kernel time"}}
     if with_cpu and comm.rank == 0:
         n_cpu = 2000 if n == 2 else 60

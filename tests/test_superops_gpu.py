@@ -119,7 +119,7 @@ def test_kraus_sweep_fused(gpu, n):
 
 
 def test_kraus_sweep_3q_fused_kernel_against_reference_fixtures(gpu):
-    """The fused 3-qubit sweep (csrc/fbx_superop.hip sweep3_kernel: kraus -> superoperator -> Pauli-Liouville + fidelity,
+    """The fused 3-qubit sweep (csrc/fbx_superop.hip sweep3_regs_kernel: kraus -> superoperator -> Pauli-Liouville + fidelity,
     kraus -> Choi -> chi through one 64 x 64 LDS matrix) on six random CPTP Kraus sets against what the reference's
     kraus2choi / kraus2pauli_liouville / kraus2chi / process_fidelity returned (tests/golden/make_goldens.py --sweep3q);
     every subset of outputs gives the same numbers, and a batch larger than the persistent grid (2048 workgroups) repeats
@@ -169,6 +169,46 @@ def test_reference_signature_wrappers(gpu):
     assert np.abs(p2c - want).max() < 1e-15
     with pytest.raises(ValueError):
         ot.convert_batch("choi", "chi", np.zeros((1, 3, 3)))
+
+
+@pytest.mark.parametrize("B,K", [(1, 4), (5, 1), (67, 3), (2051, 9), (3, 31)])
+def test_fused_sweep_3q_kraus_counts_and_both_forms(gpu, B, K):
+    """The 3-qubit sweep kernel (two butterfly stages per pass in registers, 256 threads) for 1 to 31 Kraus operators and
+    batches on either side of the persistent grid: equal to the pairwise 64 x 64 conversions and to the round's first form
+    of the kernel (one stage per pass through LDS, FBX_SWEEP3_V1=1) to rounding."""
+    from fbx import _lib, synthetic
+    from fbx import distance_measures as dm
+    from fbx.operator_tools import convert_batch
+    n, D = 3, 64
+    nd = min(B, 8)
+    ks = np.ascontiguousarray(synthetic.kraus_batch(n, K, nd, seed=K)[np.arange(B) % nd])
+    ref = np.ascontiguousarray(convert_batch("kraus", "pauli_liouville", synthetic.kraus_batch(n, 1, 1, seed=99))[0])
+
+    def run():
+        choi = np.empty((B, D, D), complex); ptm = np.empty_like(choi); chi = np.empty_like(choi); fid = np.empty(B)
+        _lib.check(_lib.lib().fbx_kraus_sweep(n, B, K, _lib.dptr(ks.view(np.float64)), _lib.dptr(ref.view(np.float64)),
+                                              _lib.dptr(choi.view(np.float64)), _lib.dptr(ptm.view(np.float64)),
+                                              _lib.dptr(chi.view(np.float64)), _lib.dptr(fid)))
+        return choi, ptm, chi, fid
+    choi, ptm, chi, fid = run()
+    old = os.environ.get("FBX_SWEEP3_V1")
+    os.environ["FBX_SWEEP3_V1"] = "1"
+    try:
+        choi1, ptm1, chi1, fid1 = run()
+    finally:
+        if old is None:
+            os.environ.pop("FBX_SWEEP3_V1")
+        else:
+            os.environ["FBX_SWEEP3_V1"] = old
+    assert np.array_equal(choi, choi1)                      # the same sums in the same order
+    assert np.abs(ptm - ptm1).max() < 1e-14 and np.abs(chi - chi1).max() < 1e-14 and np.abs(fid - fid1).max() < 1e-14
+    head = slice(0, nd)
+    assert np.abs(choi[head] - convert_batch("kraus", "choi", ks[head])).max() < 1e-13
+    assert np.abs(ptm[head] - convert_batch("kraus", "pauli_liouville", ks[head])).max() < 1e-13
+    assert np.abs(chi[head] - convert_batch("kraus", "chi", ks[head])).max() < 1e-13
+    assert np.abs(fid[head] - dm.process_fidelity_batch(ref[None], ptm[head])).max() < 1e-13
+    rep = np.arange(B) % nd
+    assert np.array_equal(ptm, ptm[rep]) and np.array_equal(chi, chi[rep]) and np.array_equal(fid, fid[rep])
 
 
 @pytest.mark.parametrize("B,K", [(1, 4), (7, 1), (129, 3), (4097, 16)])
