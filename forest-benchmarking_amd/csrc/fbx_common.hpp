@@ -66,7 +66,7 @@ struct PgdbExtras {
 // Named grow-only device workspaces of the calling thread (kept between calls; released by
 // fbx_release_workspace).  A workspace only ever serves kernels on the calling thread's stream, so
 // growing it (stream sync + hipFree + hipMalloc) cannot pull memory from under another thread's kernel.
-enum WorkspaceSlot { WS_PGDB_BASIS = 0, WS_PGDB3_BASIS = 1, WS_SWEEP_REF = 2, WS_COMM = 3, WS_CONVERT = 4, WS_PGDB1_COUNTER = 5, WS_PGDB1_BINS = 6, WS_COUNT = 7 };
+enum WorkspaceSlot { WS_PGDB_BASIS = 0, WS_PGDB3_BASIS = 1, WS_SWEEP_REF = 2, WS_COMM = 3, WS_CONVERT = 4, WS_PGDB1_COUNTER = 5, WS_PGDB1_BINS = 6, WS_PGDB_PIECES = 7, WS_COUNT = 8 };
 int workspace(WorkspaceSlot slot, size_t bytes, void** out);
 // staging blocks of the host-pointer entry points: taken from / returned to the calling thread's pool
 int pool_take(size_t bytes, void** out);

@@ -15,6 +15,7 @@
 //   _cost / _grad_cost      tomography.py:597-633
 //   proj_choi_to_physical   operator_tools/project_superoperators.py:87-144
 #include "fbx_pgdb_body.hpp"
+#include <cstdlib>
 
 namespace fbx {
 
@@ -109,6 +110,24 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
         a.basis_cap = BASIS_CAP; a.ncounts = ncounts; a.trace = ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr;
         a.trace_iters = ex.trace_iters;
         if constexpr (NQ == 2) {
+            // the two-waves kernel runs its reconstructions in pieces (fbx_pgdb_lean.hip).  FBX_LEAN_PIECES (environment, experiments
+            // and tests): 0 / 1 = whole reconstructions, n = n pieces; FBX_LEAN_PIECE_ITERS: outer iterations per piece.
+            if (lean && !ex.launch_stream) {
+                const char* pv = getenv("FBX_LEAN_PIECES");
+                const char* wv = getenv("FBX_LEAN_PIECE_ITERS");
+                int pieces = pv && *pv ? atoi(pv) : 8;           // (measured 2048 .. 65 536 experiments: 8 >= 4, 16; scripts/pieces_time.py)
+                if (pieces > 64) pieces = 64;
+                if (pieces > 1) {
+                    const int span = mode == FBX_MODE_FIXED || max_iters > 0 ? max_iters : 64;      // to convergence: ~45 iterations on average
+                    a.piece_iters = wv && *wv ? atoi(wv) : (span + pieces - 1) / pieces;
+                    if (a.piece_iters < 1) a.piece_iters = 1;
+                    void* w = nullptr;
+                    const size_t qbytes = (sizeof(int) * (16 + (size_t)nb) + 255) & ~(size_t)255;
+                    if (workspace(WS_PGDB_PIECES, qbytes + sizeof(double) * PGDB_REC * (size_t)nb, &w) == FBX_OK) {
+                        a.pieces = pieces; a.queue = (int*)w; a.recs = (double*)((char*)w + qbytes);
+                    } else (void)hipGetLastError();                  // no room: whole reconstructions
+                }
+            }
             if (lean) {
                 const int rc = pgdb_lean_launch(MAXJ, lds, st, a);
                 if (rc) return rc;

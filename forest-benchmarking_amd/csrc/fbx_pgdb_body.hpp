@@ -119,7 +119,10 @@ __device__ void predict_table(const double* Rb, const double* Ct, double* T, int
     }
 }
 
-template <int NQ, int MAXJ, bool LEAN>
+// record of a paused reconstruction (pieces, below): the estimate's blocks [8][64], then 13 scalars
+constexpr int PGDB_REC_EST = 8 * 64, PGDB_REC = PGDB_REC_EST + 16;
+
+template <int NQ, int MAXJ, bool LEAN, bool PIECES = false>
 __device__ __forceinline__ void
 pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const double* __restrict__ expect,
           const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
@@ -127,7 +130,8 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
           int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
           double* __restrict__ cost_out, int* __restrict__ work_out,
           long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
-          double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
+          double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters,
+          double* __restrict__ rec = nullptr, int piece_stop = 0x7fffffff, bool resume = false) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
     // The passes over a lane's MAXJ outcome slots (cost, gradient weights, clip detection, power sums) are straight-line code in
     // the one-wave kernel and LOOPS in the lean one (the slot index is wave-uniform: register arrays are indexed through
@@ -301,9 +305,25 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     PH_START(pc);
     double old_cost = 0.0, new_cost = 0.0;
     bool have_cost = false;
+    // A reconstruction cut into PIECES of outer iterations (fbx_pgdb_lean.hip, pgdb_lean_pieces_kernel): everything the loop
+    // carries from one outer iteration to the next -- the estimate, the counters, the state of the basis store (whose bases stay
+    // where they are, in the item's slice of the workspace), the previous step and cost -- is in `rec` (PGDB_REC doubles) between
+    // two pieces; the arithmetic of an iteration does not know where the previous one ran, so the result is bit-identical.
+    bool paused = false;
+    if (PIECES && resume) {
+        if (rec[PGDB_REC_EST + 12] != 0.0) return;        // finished in an earlier piece (converge mode): results are out
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { est.re[e] = rec[(2 * e) * 64 + lane]; est.im[e] = rec[(2 * e + 1) * 64 + lane]; }
+        const double* sc = rec + PGDB_REC_EST;
+        iters = (int)sc[0]; dyk = (int)sc[1]; backtracks = (int)sc[2]; sweeps = (int)sc[3]; ls_full = (int)sc[4]; ls_sums = (int)sc[5];
+        basis.nprev = (int)sc[6]; chain_start = (int)sc[7]; L.choi.terms = (int)sc[8];
+        outer_step = sc[9]; old_cost = sc[10]; new_cost = sc[11];
+        have_cost = true;
+    }
 
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
+        if (PIECES && iters >= piece_stop) { paused = true; break; }
         lane = FBX_LOCAL(lane);
         const int dyk_before = dyk, bt_before = backtracks;       // per-iteration trace (fbx_pgdb_process_ex)
         // A stored basis is the product of all rotations applied to its chain since the last cold start, and every
@@ -643,6 +663,18 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         old_cost = new_cost;
     }
 
+    if (PIECES && paused) {                             // the next piece of this item continues from here
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rec[(2 * e) * 64 + lane] = est.re[e]; rec[(2 * e + 1) * 64 + lane] = est.im[e]; }
+        if (lane == 0) {
+            double* sc = rec + PGDB_REC_EST;
+            sc[0] = iters; sc[1] = dyk; sc[2] = backtracks; sc[3] = sweeps; sc[4] = ls_full; sc[5] = ls_sums;
+            sc[6] = basis.nprev; sc[7] = chain_start; sc[8] = L.choi.terms;
+            sc[9] = outer_step; sc[10] = old_cost; sc[11] = new_cost; sc[12] = 0.0;
+        }
+        return;
+    }
+    if (PIECES && lane == 0) rec[PGDB_REC_EST + 12] = 1.0;
     // ---- write back
     if (lane < NACT) {
         const int I = lane / NB, J = lane % NB;
@@ -672,6 +704,9 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 struct PgdbLaunch {
     DesignDev dev; long long nb; const double* e; const double* c; int tp, mode, max_iters; double* choi;
     int *it, *dy, *bt; double* cost; int* sw; long long* phase; cplx* basis; int basis_cap; double* ncounts; int* trace; int trace_iters;
+    // pieces (the two-waves kernel only; pieces <= 1: one reconstruction per workgroup from start to end): `piece_iters` outer
+    // iterations per piece, `queue` [0] the ticket counter + [16 ..] one progress flag per item, `recs` [nb][PGDB_REC]
+    int pieces = 0, piece_iters = 0; int* queue = nullptr; double* recs = nullptr;
 };
 // fbx_pgdb_lean.hip: the two-wavefronts-per-SIMD kernel for 2 qubits, MAXJ in {4, 9, 16}
 size_t pgdb_lean_lds(int maxj, int S);

@@ -29,8 +29,74 @@ pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                               ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64, trace_out, trace_iters);
 }
 
+// The same, in PIECES (launches of 2048 .. 32 768 reconstructions, i.e. 1 .. 16 per wave slot).  A launch of whole reconstructions
+// ends when its slowest wave slot does: the items of a batch differ by +-20 % in time (max / mean 1.6), and with four items per
+// slot the launch lasts 1.19 x the mean load (list scheduling of the measured per-item times, scripts/piece_study.py) -- the gap
+// between 133 k/s at 8192 experiments and 155 k/s at 65 536.  Here 2048 persistent workgroups draw TICKETS from one counter;
+// ticket e is piece e / nb (outer iterations [piece * W, (piece + 1) * W), the last piece open-ended) of item e % nb, so all
+// first pieces are handed out before any second piece.  What a slot is stuck with at the end of the launch is a piece, not
+// a reconstruction: 1.07 x the mean load with four pieces in the same model.  Between two pieces a reconstruction lives in
+// its record (fbx_pgdb_body.hpp) and in its slice of the basis store; the piece that continues it may run on another XCD,
+// whose L2 is not coherent with the producer's: the producer drains its stores, issues an agent-scope release fence (L2
+// write-back) and publishes `piece + 1` in the item's progress flag; the consumer polls the flag (relaxed, s_sleep), issues an
+// agent-scope acquire fence and reads.  A ticket's predecessor was drawn nb tickets earlier by a workgroup that is running, so the
+// wait is almost never entered and cannot deadlock.  Results are bit-identical to the one-launch-per-reconstruction form.
+template <int NQ, int MAXJ>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+pgdb_lean_pieces_kernel(DesignDev des, long long B, const double* __restrict__ expect,
+                        const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
+                        double* __restrict__ choi_out, int* __restrict__ iters_out,
+                        int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
+                        double* __restrict__ cost_out, int* __restrict__ work_out,
+                        long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
+                        double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters,
+                        int pieces, int piece_iters, int* __restrict__ queue, double* __restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* flags = queue + 16;
+    const long long total = (long long)pieces * B;
+    for (;;) {
+        long long e = 0;
+        if ((threadIdx.x & 63) == 0) e = (long long)__hip_atomic_fetch_add((unsigned*)queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e = __builtin_amdgcn_readfirstlane((int)e);
+        if (e >= total) break;
+        const int piece = (int)(e / B);
+        const long long item = e % B;
+        if (piece > 0) {
+            // the previous piece of this item has been published (bounded: a lost flag must not hang the device)
+            long long spins = 0;
+            while (__hip_atomic_load(&flags[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1ll << 26)) __builtin_trap();
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const int stop = piece + 1 < pieces ? (piece + 1) * piece_iters : 0x7fffffff;
+        pgdb_body<NQ, MAXJ, true, true>(smem, item, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+                                  dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
+                                  ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64, trace_out, trace_iters,
+                                  recs + (size_t)item * PGDB_REC, stop, piece > 0);
+        if (piece + 1 < pieces) {
+            // publish: the record and the bases written by this piece, then the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&flags[item], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_barrier();                      // (one wavefront: orders this piece's LDS accesses before the next one's)
+    }
+}
+
 template <int MAXJ>
 static int lean_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {
+    if (a.pieces > 1) {
+        FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_pieces_kernel<2, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FBX_HIP(hipMemsetAsync(a.queue, 0, sizeof(int) * (16 + (size_t)a.nb), st));
+        const unsigned grid = (unsigned)(a.nb < 2048 ? a.nb : 2048);
+        hipLaunchKernelGGL((pgdb_lean_pieces_kernel<2, MAXJ>), dim3(grid), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
+                           a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters,
+                           a.pieces, a.piece_iters, a.queue, a.recs);
+        return FBX_OK;
+    }
     FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<2, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((pgdb_lean_kernel<2, MAXJ>), dim3((unsigned)a.nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
                        a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters);

@@ -275,6 +275,44 @@ def test_lean_two_waves_per_simd_kernel_agrees_with_the_one_wave_kernel(gpu, bas
         assert np.abs(sb["cost"][:128] - ss["cost"]).max() < 1e-10
 
 
+@pytest.mark.parametrize("kw,pieces,piece_iters", [(dict(mode="fixed", max_iters=30), 8, None), (dict(mode="converge"), 3, 7),
+                                                   (dict(mode="converge", trace_preserving=False), 5, None),
+                                                   (dict(mode="converge", max_iters=9), 16, 1), (dict(mode="fixed", max_iters=5), 8, None)])
+def test_two_waves_kernel_in_pieces_is_bit_identical_to_whole_reconstructions(gpu, kw, pieces, piece_iters):
+    """Batches of >= 1280 two-qubit reconstructions run as PIECES of outer iterations drawn from one ticket counter by
+    persistent workgroups (pgdb_lean_pieces_kernel, csrc/fbx_pgdb_lean.hip): a reconstruction's state travels through a record
+    in HBM and its slice of the basis store from the workgroup that ran one piece to the one that runs the next -- possibly on
+    another XCD, behind an agent-scope release / acquire pair.  Every output must equal the whole-reconstruction launch
+    (FBX_LEAN_PIECES=1) bit for bit: estimates, counters, costs, work counters, per-iteration traces -- on a batch that is not a
+    multiple of the wavefront or grid size, with uneven work (to convergence), with pieces longer and shorter than the runs."""
+    from fbx import synthetic, tomography
+    B = 2500 + 13
+    design, _, e, c = synthetic.process_batch(2, "pauli", B)
+    env = {"FBX_LEAN_PIECES": "1"}
+    def run(env):
+        old = {k: os.environ.get(k) for k in ("FBX_LEAN_PIECES", "FBX_LEAN_PIECE_ITERS")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            return tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, trace_iters=12, **kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+    whole, ws = run({"FBX_LEAN_PIECES": "1"})
+    env = {"FBX_LEAN_PIECES": str(pieces)}
+    if piece_iters:
+        env["FBX_LEAN_PIECE_ITERS"] = str(piece_iters)
+    got, gs = run(env)
+    assert np.array_equal(whole, got)
+    for k in ws:
+        assert np.array_equal(np.asarray(ws[k]), np.asarray(gs[k])), k
+    dflt, ds = run({})                                       # the default (8 pieces)
+    assert np.array_equal(whole, dflt) and all(np.array_equal(np.asarray(ws[k]), np.asarray(ds[k])) for k in ws)
+
+
 def test_survey_outliers_stay_within_the_reference_own_spread(gpu):
     """The four items of the 704-item survey beyond 1e-9 in converge mode: the kernel must keep the
     oracle's outer-iteration and Dykstra counts and stay within twice the distance the oracle itself moves when the
