@@ -577,7 +577,7 @@ def pgdb_roofline(batch, st, kernel_s, iters):
     dense = B * ALGO_FLOP_PER_RECON * (iters / 100.0) / kernel_s / 1e12
     ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"])
     algo_bytes = 2 * m * 8 + 4096
-    kernel = ("pgdb_lean_kernel" if B >= 1280 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
+    kernel = ("pgdb_lean_pieces_kernel" if B >= 1280 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
     measured = _measured_flop(kernel, B)
     out = {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": B * ex / kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": B * ex / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
@@ -680,7 +680,7 @@ def strong_anchor(args, comm, _lib, synthetic):
            "steps": steps, "warmup": 1, "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": kms / steps,
            "workload": f"{total} independent 2-qubit process tomographies (BASELINE configs[4], items 0..{total - 1}, all "
                        f"distinct) on one GPU, {args.in_basis} in-basis, {args.iters} fixed PGDB iterations, inputs resident in HBM",
-           "kernel": "pgdb_lean_kernel<2,9>" if batch.design.m > 256 else "pgdb_lean_kernel<2,4>",
+           "kernel": "pgdb_lean_pieces_kernel<2,9>" if batch.design.m > 256 else "pgdb_lean_pieces_kernel<2,4>",
            "mean_outer_iters": float(st["iterations"].mean()), "mean_dykstra_iters": float(st["dykstra"].mean()),
            "mean_jacobi_sweeps": float(st["work"][:, 0].mean()), "host_input_generation_s": t_gen,
            "roofline": pgdb_roofline(batch, st, kms / 1e3 / steps, args.iters),
