@@ -112,7 +112,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
         if constexpr (NQ == 2) {
             // the two-waves kernel runs its reconstructions in pieces (fbx_pgdb_lean.hip).  FBX_LEAN_PIECES (environment, experiments
             // and tests): 0 / 1 = whole reconstructions, n = n pieces; FBX_LEAN_PIECE_ITERS: outer iterations per piece.
-            if (lean && !ex.launch_stream) {
+            if (lean) {
                 const char* pv = getenv("FBX_LEAN_PIECES");
                 const char* wv = getenv("FBX_LEAN_PIECE_ITERS");
                 int pieces = pv && *pv ? atoi(pv) : 8;           // (measured 2048 .. 65 536 experiments: 8 >= 4, 16; scripts/pieces_time.py)
@@ -121,10 +121,14 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
                     const int span = mode == FBX_MODE_FIXED || max_iters > 0 ? max_iters : 64;      // to convergence: ~45 iterations on average
                     a.piece_iters = wv && *wv ? atoi(wv) : (span + pieces - 1) / pieces;
                     if (a.piece_iters < 1) a.piece_iters = 1;
+                    // per workspace slot a progress flag and a record; two ticket counters: the pipelined host entry point has one
+                    // launch in flight on each of its two compute streams, on disjoint slot ranges (ws_offset 0 / > 0)
                     void* w = nullptr;
-                    const size_t qbytes = (sizeof(int) * (16 + (size_t)nb) + 255) & ~(size_t)255;
-                    if (workspace(WS_PGDB_PIECES, qbytes + sizeof(double) * PGDB_REC * (size_t)nb, &w) == FBX_OK) {
-                        a.pieces = pieces; a.queue = (int*)w; a.recs = (double*)((char*)w + qbytes);
+                    const size_t fbytes = (sizeof(int) * (size_t)n_slots + 255) & ~(size_t)255;
+                    if (workspace(WS_PGDB_PIECES, 512 + fbytes + sizeof(double) * PGDB_REC * (size_t)n_slots, &w) == FBX_OK) {
+                        a.pieces = pieces; a.queue = (int*)w + (ex.ws_offset ? 64 : 0);
+                        a.flags = (int*)((char*)w + 512) + ex.ws_offset;
+                        a.recs = (double*)((char*)w + 512 + fbytes) + (size_t)ex.ws_offset * PGDB_REC;
                     } else (void)hipGetLastError();                  // no room: whole reconstructions
                 }
             }
@@ -322,7 +326,7 @@ static int pgdb_process_host(const fbx_design* design, int64_t B, const double* 
     // Page-locked caller buffers and more than one stage of work: H2D, kernels and D2H overlap on separate streams (SURVEY.md
     // 8d prices the path including both transfers).  What cannot be hidden is the H2D of the first stage and the D2H of the
     // last, and every boundary between stages costs a launch tail (a stage's slowest items run while SIMDs idle): so the plan
-    // is a SMALL first stage (fbx_set_option("pgdb_host_chunk") items, default 2048 = one wavefront per slot of the chip; at
+    // is a SMALL first stage (fbx_set_option("pgdb_host_chunk") items, default 4096 = two reconstructions per wave slot of the two-waves kernel, which runs them in pieces; at
     // most half the batch), a small last one, and everything in between in as few launches as the per-item workspace allows
     // (65 536 items each) on a second, HIGH-PRIORITY compute stream: the first stage's kernel covers the upload of the rest,
     // the bulk takes the SIMDs over as soon as it has arrived, and the last stage -- queued behind the first on the normal-

@@ -705,8 +705,8 @@ struct PgdbLaunch {
     DesignDev dev; long long nb; const double* e; const double* c; int tp, mode, max_iters; double* choi;
     int *it, *dy, *bt; double* cost; int* sw; long long* phase; cplx* basis; int basis_cap; double* ncounts; int* trace; int trace_iters;
     // pieces (the two-waves kernel only; pieces <= 1: one reconstruction per workgroup from start to end): `piece_iters` outer
-    // iterations per piece, `queue` [0] the ticket counter + [16 ..] one progress flag per item, `recs` [nb][PGDB_REC]
-    int pieces = 0, piece_iters = 0; int* queue = nullptr; double* recs = nullptr;
+    // iterations per piece, `queue` the ticket counter, `flags` one progress flag per item, `recs` [nb][PGDB_REC]
+    int pieces = 0, piece_iters = 0; int* queue = nullptr; int* flags = nullptr; double* recs = nullptr;
 };
 // fbx_pgdb_lean.hip: the two-wavefronts-per-SIMD kernel for 2 qubits, MAXJ in {4, 9, 16}
 size_t pgdb_lean_lds(int maxj, int S);

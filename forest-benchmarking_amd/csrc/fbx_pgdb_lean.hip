@@ -50,9 +50,8 @@ pgdb_lean_pieces_kernel(DesignDev des, long long B, const double* __restrict__ e
                         double* __restrict__ cost_out, int* __restrict__ work_out,
                         long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
                         double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters,
-                        int pieces, int piece_iters, int* __restrict__ queue, double* __restrict__ recs) {
+                        int pieces, int piece_iters, int* __restrict__ queue, int* __restrict__ flags, double* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* flags = queue + 16;
     const long long total = (long long)pieces * B;
     for (;;) {
         long long e = 0;
@@ -90,11 +89,12 @@ template <int MAXJ>
 static int lean_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {
     if (a.pieces > 1) {
         FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_pieces_kernel<2, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FBX_HIP(hipMemsetAsync(a.queue, 0, sizeof(int) * (16 + (size_t)a.nb), st));
+        FBX_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), st));
+        FBX_HIP(hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)a.nb, st));
         const unsigned grid = (unsigned)(a.nb < 2048 ? a.nb : 2048);
         hipLaunchKernelGGL((pgdb_lean_pieces_kernel<2, MAXJ>), dim3(grid), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
                            a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters,
-                           a.pieces, a.piece_iters, a.queue, a.recs);
+                           a.pieces, a.piece_iters, a.queue, a.flags, a.recs);
         return FBX_OK;
     }
     FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<2, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

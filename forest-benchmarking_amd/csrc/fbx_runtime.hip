@@ -271,7 +271,7 @@ namespace {
 std::atomic<double> g_eig_rel_tol2{FBX_JTOL_REL};     // 1- and 2-qubit PGDB (fbx_pgdb.hip)
 std::atomic<double> g_eig_rel_tol3{FBX3_JTOL_REL};     // 3-qubit PGDB (fbx_pgdb3.hip)
 std::atomic<int> g_eigh_coop{1};                      // large eigendecompositions may use a cooperative launch
-std::atomic<long long> g_host_chunk{2048};            // items of the first / last stage of the pipelined host-pointer PGDB entry point
+std::atomic<long long> g_host_chunk{4096};            // items of the first / last stage of the pipelined host-pointer PGDB entry point
 }
 long long option_pgdb_host_chunk() { return g_host_chunk.load(); }
 double option_pgdb_eig_rel_tol(int n_qubits) { return n_qubits >= 3 ? g_eig_rel_tol3.load() : g_eig_rel_tol2.load(); }

@@ -101,7 +101,7 @@ int         fbx_release_workspace(void);            /* free the calling thread's
  *   an inexact projection whose error is that fraction of the distance the estimate still moves per iteration.
  *   0 reproduces the reference's eigh-to-machine-precision trajectory iteration by iteration (tests use it);
  *   the defaults leave the converged estimates within 1e-9 of the reference's.  Range [0, 1e-3].
- *   "pgdb_host_chunk" (default 2048): items of the first and of the last stage of the pipelined host-pointer form of
+ *   "pgdb_host_chunk" (default 4096): items of the first and of the last stage of the pipelined host-pointer form of
  *   fbx_pgdb_process (see fbx_host_alloc); the bulk in between goes in one launch per 65 536 items.
  *   "eigh_cooperative" (default 1): fbx_eigh of a few matrices with N >= 128 spreads each matrix over the whole chip with a
  *   cooperative launch; 0 keeps one workgroup per matrix.
@@ -154,7 +154,7 @@ int fbx_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 
 /* page-locked host memory: caller buffers allocated here cross PCIe at the full rate and asynchronously; when
  * expect, counts and choi_out of fbx_pgdb_process[_ex] are all page-locked and the batch exceeds one stage
- * (fbx_set_option "pgdb_host_chunk", default 2048 items), the call overlaps H2D, kernels and D2H: a small first stage covers the
+ * (fbx_set_option "pgdb_host_chunk", default 4096 items), the call overlaps H2D, kernels and D2H: a small first stage covers the
  * upload of the rest, the bulk runs on a high-priority stream, a small last stage covers the download of the bulk's results */
 int fbx_host_alloc(void** host_ptr, size_t bytes);
 int fbx_host_free(void* host_ptr);

@@ -27,7 +27,16 @@ for B in (int(x) for x in (sys.argv[1:] or ["8192", "65536"])):
         ts.append(time.perf_counter() - t0)
     same = np.array_equal(out, ref)
     r, h = min(res[1:]), 1e3 * float(np.median(ts[1:]))
-    print(f"B={B}: resident {r:.2f} ms, host call (pinned, pipelined) {h:.2f} ms = {100 * r / h:.1f} % of resident; identical results: {same}", flush=True)
+    print(f"B={B}: resident {r:.2f} ms, host call (pinned, as dispatched) {h:.2f} ms = {100 * r / h:.1f} % of resident; identical results: {same}", flush=True)
+    for chunk, name in ((1 << 20, "one upload, one launch, one download"), (2048, "pipelined, first / last stage 2048"), (4096, "pipelined, 4096"), (8192, "pipelined, 8192")):
+        with _lib.option("pgdb_host_chunk", float(chunk)):
+            ts = []
+            for rep in range(4):
+                t0 = time.perf_counter()
+                tomography.pgdb_process_estimate_batch(design, pe, pc, mode="fixed", max_iters=100, out=out)
+                ts.append(time.perf_counter() - t0)
+        h2 = 1e3 * float(np.median(ts[1:]))
+        print(f"      {name}: {h2:.2f} ms = {100 * r / h2:.1f} %  identical {np.array_equal(out, ref)}", flush=True)
     del pe, pc, out
     for b in (d_e, d_c, d_choi): b.free()
     _lib.release_workspace()
