@@ -65,7 +65,7 @@ pgdb_lean_pieces_kernel(DesignDev des, long long B, const double* __restrict__ e
             long long spins = 0;
             while (__hip_atomic_load(&flags[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) {
                 __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1ll << 26)) __builtin_trap();
+                if (++spins > (1ll << 21)) __builtin_trap();      // ~2 s; a predecessor piece lasts milliseconds
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
