@@ -585,13 +585,22 @@ static int launch_convert3_fast(int64_t B, const double* in, double* out) {
     return FBX_OK;
 }
 
+template <int ROUTE> static int launch_convert3_regs(int64_t B, const double* in, double* out);     // further down: two stages per pass in registers
+static int launch_sweep3_regs(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi, double* ptm, double* chi, double* fid);
+
 static int launch_convert3(int from, int to, int64_t B, const double* in, int K, double* out) {
     constexpr size_t D = 64;
 #ifndef FBX_CONVERT3_GENERAL_ONLY
-    if (from == FBX_REP_CHOI && to == FBX_REP_PAULI_LIOUVILLE) return launch_convert3_fast<0>(B, in, out);
+    const char* v1s = getenv("FBX_CONVERT3_V1");            // 1 = the one-stage-per-pass kernels (A/B, tests)
+    const bool v1 = v1s && atoi(v1s) != 0;
+    // from Kraus operators: the sweep kernel with one output (operators read once, the result written once, coalesced)
+    if (!v1 && from == FBX_REP_KRAUS && K >= 1 && K <= 31 && (to == FBX_REP_CHOI || to == FBX_REP_PAULI_LIOUVILLE || to == FBX_REP_CHI))
+        return launch_sweep3_regs(B, K, in, nullptr, to == FBX_REP_CHOI ? out : nullptr, to == FBX_REP_PAULI_LIOUVILLE ? out : nullptr,
+                                  to == FBX_REP_CHI ? out : nullptr, nullptr);
+    if (from == FBX_REP_CHOI && to == FBX_REP_PAULI_LIOUVILLE) return v1 ? launch_convert3_fast<0>(B, in, out) : launch_convert3_regs<0>(B, in, out);
     if (from == FBX_REP_PAULI_LIOUVILLE && to == FBX_REP_CHOI) return launch_convert3_fast<1>(B, in, out);
-    if (from == FBX_REP_SUPEROP && to == FBX_REP_PAULI_LIOUVILLE) return launch_convert3_fast<2>(B, in, out);
-    if (from == FBX_REP_PAULI_LIOUVILLE && to == FBX_REP_SUPEROP) return launch_convert3_fast<3>(B, in, out);
+    if (from == FBX_REP_SUPEROP && to == FBX_REP_PAULI_LIOUVILLE) return v1 ? launch_convert3_fast<2>(B, in, out) : launch_convert3_regs<2>(B, in, out);
+    if (from == FBX_REP_PAULI_LIOUVILLE && to == FBX_REP_SUPEROP) return v1 ? launch_convert3_fast<3>(B, in, out) : launch_convert3_regs<3>(B, in, out);
     if ((from == FBX_REP_CHOI && to == FBX_REP_SUPEROP) || (from == FBX_REP_SUPEROP && to == FBX_REP_CHOI)) return launch_convert3_fast<4>(B, in, out);
 #endif
     const size_t lds = 2 * sizeof(cplx) * D * D + sizeof(double) * 128 + sizeof(cplx) * (size_t)(K > 0 ? K : 1) * D;
@@ -1370,6 +1379,119 @@ sweep3_regs_kernel(long long B, int K, const double* __restrict__ kraus, const d
     }
 }
 
+// The pairwise 3-qubit routes between Choi / superoperator / Pauli-Liouville in the same three register passes (round 4): 64 KB
+// in, 64 KB out per item, 256-thread workgroups, one swizzled 64 KB tile.  ROUTE as convert3_fast_kernel: 0 choi->PL,
+// 2 superop->PL, 3 PL->superop (route 1, PL->choi, keeps the one-stage-per-pass kernel: its result leaves reshuffled, i.e. as
+// 16-byte pieces 8 KB apart from any register layout -- measured 7 x slower than a shuffle on the LDS side).  P1 loads the tile
+// straight from HBM into its registers (route 0: reshuffled, scattered 16-byte reads that L2 absorbs; route 3: the Pauli index
+// permuted to the site order, 256-byte runs), P3 stores whole rows; route 3 runs the inverse butterflies in the same order
+// (the stages commute).
+__device__ __forceinline__ void two_sites_inv(cplx (&x)[16], double y1, double y2) {
+    auto site = [](cplx& c00, cplx& c11, cplx& c01, cplx& c10, double ys) {   // (I, Z, X, Y) at (00, 11, 01, 10)
+        cplx o00, o11, o01, o10;
+        o00.re = 0.5 * (c00.re + c11.re); o00.im = 0.5 * (c00.im + c11.im);
+        o11.re = 0.5 * (c00.re - c11.re); o11.im = 0.5 * (c00.im - c11.im);
+        const double yr = -ys * c10.im, yi = ys * c10.re;                      // s * i * Y
+        o01.re = 0.5 * (c01.re - yr); o01.im = 0.5 * (c01.im - yi);
+        o10.re = 0.5 * (c01.re + yr); o10.im = 0.5 * (c01.im + yi);
+        c00 = o00; c11 = o11; c01 = o01; c10 = o10;
+    };
+#pragma unroll
+    for (int cd = 0; cd < 4; ++cd) site(x[cd], x[12 | cd], x[4 | cd], x[8 | cd], y1);
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) site(x[ab << 2], x[(ab << 2) | 3], x[(ab << 2) | 1], x[(ab << 2) | 2], y2);
+}
+
+template <int ROUTE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+convert3_regs_kernel(long long B, const double* __restrict__ in, double* __restrict__ out) {
+    static_assert(ROUTE == 0 || ROUTE == 2 || ROUTE == 3, "route 1 stays with convert3_fast_kernel");
+    constexpr int d = 8, D = 64;
+    constexpr bool TO_PL = ROUTE != 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* X = (cplx*)smem;
+    const int t = threadIdx.x;
+    auto bit = [](int v, int b) { return (v >> b) & 1; };
+    const int w0 = bit(t, 6), w1 = bit(t, 7);
+    const int row1 = bit(t, 2) | bit(t, 5) << 1 | w0 << 3 | w1 << 4;
+    const int col1 = bit(t, 0) | bit(t, 1) << 1 | bit(t, 3) << 3 | bit(t, 4) << 4;
+    const int row2 = bit(t, 5) | bit(t, 1) << 1 | w0 << 2 | bit(t, 2) << 3 | bit(t, 4) << 4 | w1 << 5;
+    const int col2 = bit(t, 0) << 2 | bit(t, 3) << 5;
+    const int row3 = w0 << 2 | w1 << 5;
+    const int col3 = bit(t, 0) | bit(t, 2) << 1 | bit(t, 4) << 2 | bit(t, 1) << 3 | bit(t, 3) << 4 | bit(t, 5) << 5;
+    const int lcol = t & 63, krow = (t >> 6) * 16;
+    auto reg_row1 = [](int r) { return ((r >> 3) & 1) << 5 | ((r >> 2) & 1) << 2; };
+    auto reg_col1 = [](int r) { return ((r >> 1) & 1) << 5 | (r & 1) << 2; };
+    auto reg_col2 = [](int r) { return ((r >> 3) & 1) << 4 | ((r >> 2) & 1) << 1 | ((r >> 1) & 1) << 3 | (r & 1); };
+    auto reg_row3 = [](int r) { return ((r >> 3) & 1) << 4 | ((r >> 2) & 1) << 1 | ((r >> 1) & 1) << 3 | (r & 1); };
+    const int base1 = s3_addr(row1, col1), base2 = s3_addr(row2, col2), base3 = row3 * 64 + col3;
+    // Pauli label of a tile row / column (inverse of site_index: label bit 2t = index bit t, 2t + 1 = index bit 3 + t)
+    auto label = [](int x) { return (x & 1) | ((x >> 3) & 1) << 1 | ((x >> 1) & 1) << 2 | ((x >> 4) & 1) << 3 | ((x >> 2) & 1) << 4 | ((x >> 5) & 1) << 5; };
+    // HBM index the tile entry (row, col) is loaded from
+    auto load_index = [&](int row, int col) {
+        if (ROUTE == 2) return row * D + col;
+        if (ROUTE == 3) return label(row) * D + label(col);
+        const int p = row / d, q = row % d, r = col / d, s_ = col % d;       // route 0: entry (p,q),(r,s) <- Choi entry (s,q),(r,p)
+        return (s_ * d + q) * D + r * d + p;
+    };
+    const double inv_d = 1.0 / d;
+    const double sc_in = TO_PL ? 1.0 : inv_d * D, sc_out = TO_PL ? inv_d : 1.0;
+    auto sites = [](cplx (&x)[16], double y1, double y2) { if (TO_PL) two_sites(x, y1, y2); else two_sites_inv(x, y1, y2); };
+    for (long long item = blockIdx.x; item < B; item += gridDim.x) {
+        const double* src = in + item * (long long)D * D * 2;
+        double* dst = out + item * (long long)D * D * 2;
+        cplx x[16];
+        __syncthreads();                                   // the previous item's readers of X are done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double2 v = *reinterpret_cast<const double2*>(src + 2 * load_index(row1 | reg_row1(r), col1 | reg_col1(r)));
+            x[r].re = v.x * sc_in; x[r].im = v.y * sc_in;
+        }
+        sites(x, -1.0, +1.0);                              // row site 2 (-i), column site 2 (+i)
+        const int b1 = opaque(base1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[b1 ^ (reg_row1(r) * 64 + reg_col1(r))] = x[r];
+        __syncthreads();
+        const int b2 = opaque(base2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = X[b2 ^ reg_col2(r)];
+        sites(x, +1.0, +1.0);                              // column sites 1, 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[b2 ^ reg_col2(r)] = x[r];
+        __syncthreads();
+        const int b3 = opaque(base3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = X[b3 ^ (reg_row3(r) * 64 + s3_swz(reg_row3(r)))];
+        sites(x, -1.0, -1.0);                              // row sites 1, 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double2 v; v.x = x[r].re * sc_out; v.y = x[r].im * sc_out;
+            // towards PL: Pauli row 16 w + r, column = lane; route 3: tile row / column as they are
+            const long long o = TO_PL ? ((long long)(krow + r) * D + lcol) : ((long long)(row3 | reg_row3(r)) * D + col3);
+            FBX_STREAM_STORE(reinterpret_cast<double2*>(dst + 2 * o), v);
+        }
+    }
+}
+static int launch_sweep3_regs(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi, double* ptm, double* chi, double* fid) {
+    const size_t lds = sizeof(cplx) * 64 * 64 + sizeof(double) * 16 + sizeof(cplx) * (size_t)K * 64;
+    FBX_HIP(hipFuncSetAttribute((const void*)sweep3_regs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)(B < 2048 ? B : 2048);
+    hipLaunchKernelGGL(sweep3_regs_kernel, dim3(grid), dim3(256), lds, stream(), (long long)B, K, kraus, ptm_ref, choi, ptm, chi, fid);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+template <int ROUTE>
+static int launch_convert3_regs(int64_t B, const double* in, double* out) {
+    const size_t lds = sizeof(cplx) * 64 * 64;
+    auto kern = convert3_regs_kernel<ROUTE>;
+    FBX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)(B < 2048 ? B : 2048);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream(), (long long)B, in, out);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 // Three qubits, unfused (kept as the reference form: FBX_SWEEP3_COMPOSED=1 in the environment of a diagnostics build, and the
 // fallback for more than 31 Kraus operators): the composition of the pairwise 64 x 64 conversions and the fidelity reduction.
 static int launch_sweep3_composed(int64_t B, int K, const double* kraus, const double* ptm_ref, double* choi, double* ptm,
@@ -1758,11 +1880,7 @@ int fbx_kraus_sweep_dev(int n_qubits, int64_t B, int K, const double* d_kraus, c
             FBX_HIP(hipFuncSetAttribute((const void*)sweep3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(sweep3_kernel, dim3(grid), dim3(1024), lds, stream(), (long long)B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out,
                                d_chi_out, d_fid_out);
-        } else {
-            FBX_HIP(hipFuncSetAttribute((const void*)sweep3_regs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(sweep3_regs_kernel, dim3(grid), dim3(256), lds, stream(), (long long)B, K, d_kraus, d_ptm_ref, d_choi_out,
-                               d_ptm_out, d_chi_out, d_fid_out);
-        }
+        } else return launch_sweep3_regs(B, K, d_kraus, d_ptm_ref, d_choi_out, d_ptm_out, d_chi_out, d_fid_out);
         FBX_HIP(hipGetLastError());
         return FBX_OK;
     }

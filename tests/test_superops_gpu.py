@@ -43,6 +43,33 @@ def test_pairwise_conversions(gpu, n):
         assert np.abs(got - g[kout]).max() < 1e-11, (src, dst)
 
 
+def test_pairwise_conversions_3q_register_passes_against_the_first_form(gpu):
+    """The 3-qubit routes between Choi / superoperator / Pauli-Liouville run two butterfly stages per pass in registers
+    (convert3_regs_kernel, csrc/fbx_superop.hip); the one-stage-per-pass kernels stay behind FBX_CONVERT3_V1=1.  Arbitrary
+    complex matrices (the conversions are linear maps: no structure of the input may be assumed), a batch larger than the
+    persistent grid: both forms agree to rounding, the reshuffle routes bit for bit where no arithmetic is involved, and
+    every route followed by its inverse returns the input."""
+    from fbx.operator_tools import convert_batch
+    rs = np.random.RandomState(5)
+    B = 2048 + 77
+    x = rs.randn(B, 64, 64) + 1j * rs.randn(B, 64, 64)
+
+    def both(src, dst, a):
+        new = convert_batch(src, dst, a)
+        os.environ["FBX_CONVERT3_V1"] = "1"
+        try:
+            old = convert_batch(src, dst, a)
+        finally:
+            os.environ.pop("FBX_CONVERT3_V1")
+        return new, old
+    for src, dst in (("choi", "pauli_liouville"), ("superop", "pauli_liouville"), ("pauli_liouville", "choi"), ("pauli_liouville", "superop")):
+        new, old = both(src, dst, x)
+        scale = np.abs(old).max()
+        assert np.abs(new - old).max() < 1e-14 * scale, (src, dst)
+        back = convert_batch(dst, src, new)
+        assert np.abs(back - x).max() < 1e-13 * np.abs(x).max(), (src, dst)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3])
 def test_choi2chi_non_cp_goes_through_abs(gpu, n):
     """Reference quirk: choi2chi of a non-CP matrix is the chi form of |C|."""
@@ -203,9 +230,17 @@ def test_fused_sweep_3q_kraus_counts_and_both_forms(gpu, B, K):
     assert np.array_equal(choi, choi1)                      # the same sums in the same order
     assert np.abs(ptm - ptm1).max() < 1e-14 and np.abs(chi - chi1).max() < 1e-14 and np.abs(fid - fid1).max() < 1e-14
     head = slice(0, nd)
-    assert np.abs(choi[head] - convert_batch("kraus", "choi", ks[head])).max() < 1e-13
-    assert np.abs(ptm[head] - convert_batch("kraus", "pauli_liouville", ks[head])).max() < 1e-13
-    assert np.abs(chi[head] - convert_batch("kraus", "chi", ks[head])).max() < 1e-13
+    os.environ["FBX_CONVERT3_V1"] = "1"        # the general pairwise kernels (by default kraus -> X is this very sweep kernel)
+    try:
+        assert np.abs(choi[head] - convert_batch("kraus", "choi", ks[head])).max() < 1e-13
+        assert np.abs(ptm[head] - convert_batch("kraus", "pauli_liouville", ks[head])).max() < 1e-13
+        assert np.abs(chi[head] - convert_batch("kraus", "chi", ks[head])).max() < 1e-13
+    finally:
+        os.environ.pop("FBX_CONVERT3_V1")
+    # ... and the default pairwise route from Kraus operators (the sweep kernel with one output) gives the sweep's numbers
+    assert np.array_equal(convert_batch("kraus", "pauli_liouville", ks[head]), ptm[head])
+    assert np.array_equal(convert_batch("kraus", "chi", ks[head]), chi[head])
+    assert np.array_equal(convert_batch("kraus", "choi", ks[head]), choi[head])
     assert np.abs(fid[head] - dm.process_fidelity_batch(ref[None], ptm[head])).max() < 1e-13
     rep = np.arange(B) % nd
     assert np.array_equal(ptm, ptm[rep]) and np.array_equal(chi, chi[rep]) and np.array_equal(fid, fid[rep])
