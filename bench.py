@@ -577,7 +577,7 @@ def pgdb_roofline(batch, st, kernel_s, iters):
     dense = B * ALGO_FLOP_PER_RECON * (iters / 100.0) / kernel_s / 1e12
     ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"])
     algo_bytes = 2 * m * 8 + 4096
-    kernel = ("pgdb_lean_pieces_kernel" if B >= 1280 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
+    kernel = ("pgdb_lean_pieces_kernel" if B > 1024 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
     measured = _measured_flop(kernel, B)
     out = {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": B * ex / kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": B * ex / kernel_s / 1e12 / FP64_PEAK_TFLOPS,

@@ -8,8 +8,10 @@
 #include <cstdlib>
 #include <vector>
 #ifndef FBX_LEAN_MIN_BATCH
-#define FBX_LEAN_MIN_BATCH 1280     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits): measured crossover with the
-                                    // one-wave kernel between 1100 and 1280 reconstructions in both modes (1280: 18.8 against 20.4 ms)
+#define FBX_LEAN_MIN_BATCH 1025     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits): one reconstruction more than
+                                    // the chip has SIMDs.  The one-wave kernel is the faster chain (1024 items: 12.7 against 15.3 ms), but item
+                                    // 1025 starts a second round on it (1152 items: 19.8 against 16.1 ms; scripts/lean_crossover.py; round 3's
+                                    // crossover, before the pieces, lay between 1100 and 1280)
 #endif
 #ifndef FBX_PACKED_1Q_MIN_BATCH
 #define FBX_PACKED_1Q_MIN_BATCH 8192  // single-qubit batches from which the lane-per-item kernel is used (fbx_pgdb1.hip)

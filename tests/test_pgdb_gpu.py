@@ -254,7 +254,7 @@ def test_config5_whole_batch_on_one_gpu(gpu):
 
 @pytest.mark.parametrize("basis", ["pauli", "sic"])
 def test_lean_two_waves_per_simd_kernel_agrees_with_the_one_wave_kernel(gpu, basis):
-    """Batches of >= 1280 two-qubit reconstructions (2048 here) run pgdb_lean_kernel (16.5 KB of LDS, <= 256 registers, two
+    """Batches of > 1024 two-qubit reconstructions (2048 here) run pgdb_lean_kernel (16.5 KB of LDS, <= 256 registers, two
     wavefronts per SIMD).  Since round 3 it carries Dykstra's state as two matrices + an 8-number
     summary instead of four matrices (fbx_choi.hpp proj_physical_blk_compact: same projections and stopping rule, the
     stopping functional assembled from algebraically equal terms), so its trajectory equals the one-wave kernel's to
@@ -279,7 +279,7 @@ def test_lean_two_waves_per_simd_kernel_agrees_with_the_one_wave_kernel(gpu, bas
                                                    (dict(mode="converge", trace_preserving=False), 5, None),
                                                    (dict(mode="converge", max_iters=9), 16, 1), (dict(mode="fixed", max_iters=5), 8, None)])
 def test_two_waves_kernel_in_pieces_is_bit_identical_to_whole_reconstructions(gpu, kw, pieces, piece_iters):
-    """Batches of >= 1280 two-qubit reconstructions run as PIECES of outer iterations drawn from one ticket counter by
+    """Batches of > 1024 two-qubit reconstructions run as PIECES of outer iterations drawn from one ticket counter by
     persistent workgroups (pgdb_lean_pieces_kernel, csrc/fbx_pgdb_lean.hip): a reconstruction's state travels through a record
     in HBM and its slice of the basis store from the workgroup that ran one piece to the one that runs the next -- possibly on
     another XCD, behind an agent-scope release / acquire pair.  Every output must equal the whole-reconstruction launch
