@@ -33,6 +33,8 @@ int run_on_devices(int n_jobs, const std::function<int(int)>& job);     // job(g
 const fbx_design* design_on_this_device(const fbx_design* des, int* rc); // des itself, or its replica on the calling worker's device (created on first use)
 double option_pgdb_eig_rel_tol(int n_qubits);   // fbx_set_option("pgdb_eig_rel_tol" / "pgdb3_eig_rel_tol")
 bool option_eigh_cooperative();                 // fbx_set_option("eigh_cooperative")
+int option_pgdb_pieces();                        // fbx_set_option("pgdb_pieces"): pieces per reconstruction of the two-waves 2-qubit kernel
+int option_pgdb1_binned();                       // fbx_set_option("pgdb1_binned"): binned relaunch of the lane-per-item single-qubit kernel 0 / 1 / 2
 int option_pgdb_packed_1q();                     // fbx_set_option("pgdb_packed_1q"): single-qubit PGDB on the lane-per-item kernel: 0 never, 1 large batches (default), 2 always
 // Defaults of those options: the eigensolver of PGDB's CP projections stops at an off-diagonal norm of
 // <this> x the previous outer step (relative to ||H||_F), never tighter than 1e-13; 0 = always 1e-13.

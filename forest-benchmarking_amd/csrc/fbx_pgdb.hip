@@ -110,12 +110,12 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
         a.basis_cap = BASIS_CAP; a.ncounts = ncounts; a.trace = ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr;
         a.trace_iters = ex.trace_iters;
         if constexpr (NQ == 2) {
-            // the two-waves kernel runs its reconstructions in pieces (fbx_pgdb_lean.hip).  FBX_LEAN_PIECES (environment, experiments
-            // and tests): 0 / 1 = whole reconstructions, n = n pieces; FBX_LEAN_PIECE_ITERS: outer iterations per piece.
+            // the two-waves kernel runs its reconstructions in pieces (fbx_pgdb_lean.hip): fbx_set_option("pgdb_pieces"), 1 = whole
+            // reconstructions.  FBX_LEAN_PIECES / FBX_LEAN_PIECE_ITERS (environment, experiments and tests) override it per call.
             if (lean) {
                 const char* pv = getenv("FBX_LEAN_PIECES");
                 const char* wv = getenv("FBX_LEAN_PIECE_ITERS");
-                int pieces = pv && *pv ? atoi(pv) : 8;           // (measured 2048 .. 65 536 experiments: 8 >= 4, 16; scripts/pieces_time.py)
+                int pieces = pv && *pv ? atoi(pv) : option_pgdb_pieces();     // default 8 (measured 2048 .. 65 536 experiments: 8 >= 4, 16; scripts/pieces_time.py)
                 if (pieces > 64) pieces = 64;
                 if (pieces > 1) {
                     const int span = mode == FBX_MODE_FIXED || max_iters > 0 ? max_iters : 64;      // to convergence: ~45 iterations on average

@@ -369,10 +369,10 @@ int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const doub
     {
         // Binned relaunch from the batch sizes at which it wins (scripts/pgdb1_binned_time.py; below them a launch per outer
         // iteration costs more than the grouping returns): to convergence 2^20 experiments (2^19 for designs of <= 12
-        // settings), a fixed iteration count -- where nothing ever leaves the batch -- 2^17.  Environment, for experiments:
-        // FBX_P1_BINNED = 0 never / 1 by these rules / 2 always; FBX_P1_TAIL the number of reconstructions left at which the
+        // settings), a fixed iteration count -- where nothing ever leaves the batch -- 2^17.  fbx_set_option("pgdb1_binned") = 0 never /
+        // 1 by these rules / 2 always; environment, for experiments: FBX_P1_BINNED overrides it per call; FBX_P1_TAIL the number of reconstructions left at which the
         // last launch takes over; FBX_P1_CHUNK the largest number binned at once (its workspace is 3.5 KB + 16 m bytes per reconstruction).
-        const long long binned = env_ll("FBX_P1_BINNED", 1), chunk = env_ll("FBX_P1_CHUNK", 1 << 20), tail = env_ll("FBX_P1_TAIL", 8192),
+        const long long binned = env_ll("FBX_P1_BINNED", option_pgdb1_binned()), chunk = env_ll("FBX_P1_CHUNK", 1 << 20), tail = env_ll("FBX_P1_TAIL", 8192),
                         every = env_ll("FBX_P1_CHECK", 8);
         const long long from = mode == FBX_MODE_FIXED ? (1 << 17) : (des->dev.m <= 12 ? (1 << 19) : (1 << 20));
         // (a stage of the pipelined host entry point shares the calling thread's workspaces with the stage on the other stream:

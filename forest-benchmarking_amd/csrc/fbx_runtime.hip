@@ -278,6 +278,10 @@ double option_pgdb_eig_rel_tol(int n_qubits) { return n_qubits >= 3 ? g_eig_rel_
 bool option_eigh_cooperative() { return g_eigh_coop.load() != 0; }
 std::atomic<int> g_packed_1q{1};                      // single-qubit PGDB: 64 reconstructions per wavefront (fbx_pgdb1.hip)
 int option_pgdb_packed_1q() { return g_packed_1q.load(); }
+std::atomic<int> g_pieces{8};                         // 2-qubit two-waves kernel: pieces per reconstruction (fbx_pgdb_lean.hip)
+std::atomic<int> g_binned_1q{1};                      // single-qubit lane-per-item kernel: binned relaunch 0 never / 1 large batches / 2 always
+int option_pgdb_pieces() { return g_pieces.load(); }
+int option_pgdb1_binned() { return g_binned_1q.load(); }
 }  // namespace fbx
 
 extern "C" {
@@ -382,6 +386,14 @@ int fbx_set_option(const char* name, double value) {
         FBX_REQUIRE(value >= 256.0 && value <= 1048576.0, "fbx_set_option: pgdb_host_chunk must be in [256, 1048576]");
         fbx::g_host_chunk.store((long long)value); return FBX_OK;
     }
+    if (n == "pgdb_pieces") {
+        FBX_REQUIRE(value >= 1.0 && value <= 64.0 && value == (double)(int)value, "fbx_set_option: pgdb_pieces must be an integer in [1, 64]");
+        fbx::g_pieces.store((int)value); return FBX_OK;
+    }
+    if (n == "pgdb1_binned") {
+        FBX_REQUIRE(value == 0.0 || value == 1.0 || value == 2.0, "fbx_set_option: pgdb1_binned must be 0 (never), 1 (large batches) or 2 (always)");
+        fbx::g_binned_1q.store((int)value); return FBX_OK;
+    }
     set_error("fbx_set_option: unknown option '" + n + "'");
     return FBX_ERR_BAD_ARG;
 }
@@ -394,6 +406,8 @@ int fbx_get_option(const char* name, double* value) {
     if (n == "eigh_cooperative") { *value = fbx::g_eigh_coop.load(); return FBX_OK; }
     if (n == "pgdb_packed_1q") { *value = fbx::g_packed_1q.load(); return FBX_OK; }
     if (n == "pgdb_host_chunk") { *value = (double)fbx::g_host_chunk.load(); return FBX_OK; }
+    if (n == "pgdb_pieces") { *value = fbx::g_pieces.load(); return FBX_OK; }
+    if (n == "pgdb1_binned") { *value = fbx::g_binned_1q.load(); return FBX_OK; }
     set_error("fbx_get_option: unknown option '" + n + "'");
     return FBX_ERR_BAD_ARG;
 }

@@ -71,3 +71,26 @@ def test_argument_errors_map_to_value_error():
     assert rc == _lib.FBX_ERR_BAD_ARG and b"n_qubits" in lib.fbx_last_error()
     rc = lib.fbx_design_create(4, 1, 1, None, None, None, ctypes.byref(h))           # process designs: 1..3
     assert rc == _lib.FBX_ERR_BAD_ARG and b"n_qubits" in lib.fbx_last_error()
+
+
+def test_options_are_validated_without_a_device(lib):
+    """fbx_set_option / fbx_get_option: every option the header documents has its default, rejects values outside its range
+    (a bad-argument code and a message, nothing changed) and reads back what was set."""
+    lib.fbx_set_option.argtypes = [ctypes.c_char_p, ctypes.c_double]
+    lib.fbx_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+    lib.fbx_last_error.restype = ctypes.c_char_p
+    v = ctypes.c_double()
+    defaults = {b"pgdb_eig_rel_tol": 1e-8, b"pgdb3_eig_rel_tol": 1e-7, b"eigh_cooperative": 1.0, b"pgdb_packed_1q": 1.0,
+                b"pgdb_host_chunk": 4096.0, b"pgdb_pieces": 8.0, b"pgdb1_binned": 1.0}
+    header = open(HEADER).read()
+    for name, want in defaults.items():
+        assert ('"%s"' % name.decode()) in header
+        assert lib.fbx_get_option(name, ctypes.byref(v)) == 0 and v.value == want, name
+    for name, bad in ((b"pgdb_pieces", 0.0), (b"pgdb_pieces", 65.0), (b"pgdb_pieces", 2.5), (b"pgdb1_binned", 3.0),
+                      (b"pgdb_packed_1q", -1.0), (b"pgdb_host_chunk", 3.0), (b"pgdb_eig_rel_tol", 1.0), (b"no_such_option", 1.0)):
+        assert lib.fbx_set_option(name, bad) != 0, (name, bad)
+        assert lib.fbx_last_error()
+    for name, ok in ((b"pgdb_pieces", 16.0), (b"pgdb1_binned", 2.0)):
+        assert lib.fbx_set_option(name, ok) == 0
+        assert lib.fbx_get_option(name, ctypes.byref(v)) == 0 and v.value == ok
+        assert lib.fbx_set_option(name, defaults[name]) == 0

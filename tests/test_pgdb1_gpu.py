@@ -295,3 +295,7 @@ def test_binned_relaunch_edge_cases(gpu):
         assert np.array_equal(z, np.broadcast_to(np.eye(4) / 2, (3, 4, 4)))
     with _env(FBX_P1_BINNED=2, FBX_P1_TAIL=16, FBX_P1_CHECK=1):
         assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c), ref)
+    from fbx import _lib
+    with _lib.option("pgdb1_binned", 2.0):                   # the same switch as a library option
+        assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c), ref)
+    assert _lib.get_option("pgdb1_binned") == 1.0

@@ -311,6 +311,11 @@ def test_two_waves_kernel_in_pieces_is_bit_identical_to_whole_reconstructions(gp
         assert np.array_equal(np.asarray(ws[k]), np.asarray(gs[k])), k
     dflt, ds = run({})                                       # the default (8 pieces)
     assert np.array_equal(whole, dflt) and all(np.array_equal(np.asarray(ws[k]), np.asarray(ds[k])) for k in ws)
+    from fbx import _lib
+    with _lib.option("pgdb_pieces", 3.0):                    # the same knob as a library option
+        opt, os_ = run({})
+    assert _lib.get_option("pgdb_pieces") == 8.0
+    assert np.array_equal(whole, opt) and all(np.array_equal(np.asarray(ws[k]), np.asarray(os_[k])) for k in ws)
 
 
 def test_survey_outliers_stay_within_the_reference_own_spread(gpu):
