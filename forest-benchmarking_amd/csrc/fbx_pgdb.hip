@@ -36,6 +36,25 @@ pgdb_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                                trace_out, trace_iters);
 }
 
+// The same kernel in PIECES (fbx_pgdb_lean.hip has the description): for launches that put more than one reconstruction on a
+// SIMD but cannot use the two-waves kernel -- single-qubit designs on the wavefront-per-item kernel (1025 .. 8191 / 16 383
+// experiments), 2-qubit designs with more than 50 input states.  1024 persistent workgroups.
+template <int NQ, int MAXJ>
+__global__ void __launch_bounds__(64)
+pgdb_pieces_kernel(DesignDev des, long long B, const double* __restrict__ expect,
+                   const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
+                   double* __restrict__ choi_out, int* __restrict__ iters_out,
+                   int* __restrict__ dykstra_out, int* __restrict__ backtracks_out,
+                   double* __restrict__ cost_out, int* __restrict__ work_out,
+                   long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
+                   int* __restrict__ trace_out, int trace_iters,
+                   int pieces, int piece_iters, int* __restrict__ queue, int* __restrict__ flags, double* __restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    pgdb_pieces_run<NQ, MAXJ, false>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out, dykstra_out,
+                                     backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, nullptr, trace_out,
+                                     trace_iters, pieces, piece_iters, queue, flags, recs);
+}
+
 #ifdef FBX_DIAGNOSTICS
 __global__ void debug_log_kernel(const double* x, double* out, long long n) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -109,10 +128,14 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
         a.cost = cost ? cost + b0 : nullptr; a.sw = sw ? sw + 4 * b0 : nullptr; a.phase = FBX_PHASE_OUT(b0); a.basis = basis;
         a.basis_cap = BASIS_CAP; a.ncounts = ncounts; a.trace = ex.trace ? ex.trace + (size_t)b0 * ex.trace_iters * 2 : nullptr;
         a.trace_iters = ex.trace_iters;
-        if constexpr (NQ == 2) {
+        // more than one reconstruction per SIMD on the one-wave kernel: in pieces too -- except single-qubit batches to convergence,
+        // whose outer iterations last microseconds (a piece's set-up and hand-over then cost what the tail saves: 8000 Pauli
+        // experiments 8.6 -> 10.3 ms, while 100 fixed iterations of the SIC design gain 25-35 %; scripts/pieces_time_1q.py)
+        const bool fat_pieces = !lean && nb > 1024 && (NQ == 2 || mode == FBX_MODE_FIXED);
+        {
             // the two-waves kernel runs its reconstructions in pieces (fbx_pgdb_lean.hip): fbx_set_option("pgdb_pieces"), 1 = whole
             // reconstructions.  FBX_LEAN_PIECES / FBX_LEAN_PIECE_ITERS (environment, experiments and tests) override it per call.
-            if (lean) {
+            if (lean || fat_pieces) {
                 const char* pv = getenv("FBX_LEAN_PIECES");
                 const char* wv = getenv("FBX_LEAN_PIECE_ITERS");
                 int pieces = pv && *pv ? atoi(pv) : option_pgdb_pieces();     // default 8 (measured 2048 .. 65 536 experiments: 8 >= 4, 16; scripts/pieces_time.py)
@@ -132,11 +155,22 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
                     } else (void)hipGetLastError();                  // no room: whole reconstructions
                 }
             }
+        }
+        if constexpr (NQ == 2) {
             if (lean) {
                 const int rc = pgdb_lean_launch(MAXJ, lds, st, a);
                 if (rc) return rc;
                 continue;
             }
+        }
+        if (fat_pieces && a.pieces > 1) {
+            FBX_HIP(hipFuncSetAttribute((const void*)pgdb_pieces_kernel<NQ, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FBX_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), st));
+            FBX_HIP(hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)a.nb, st));
+            hipLaunchKernelGGL((pgdb_pieces_kernel<NQ, MAXJ>), dim3(1024), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
+                               a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.trace, a.trace_iters,
+                               a.pieces, a.piece_iters, a.queue, a.flags, a.recs);
+            continue;
         }
         hipLaunchKernelGGL((pgdb_kernel<NQ, MAXJ>), dim3((unsigned)nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
                            a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.trace, a.trace_iters);

@@ -702,6 +702,49 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 #endif
 }
 
+// The ticket loop of the pieces kernels (pgdb_lean_pieces_kernel, fbx_pgdb_lean.hip: the protocol is described there;
+// pgdb_pieces_kernel, fbx_pgdb.hip): persistent workgroups draw (item, piece) tickets from `queue` until none is left.
+template <int NQ, int MAXJ, bool LEAN>
+__device__ __forceinline__ void
+pgdb_pieces_run(char* smem, const DesignDev& des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
+                int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out, int* __restrict__ iters_out,
+                int* __restrict__ dykstra_out, int* __restrict__ backtracks_out, double* __restrict__ cost_out, int* __restrict__ work_out,
+                long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap, double* __restrict__ ncounts,
+                int* __restrict__ trace_out, int trace_iters, int pieces, int piece_iters, int* __restrict__ queue,
+                int* __restrict__ flags, double* __restrict__ recs) {
+    const long long total = (long long)pieces * B;
+    for (;;) {
+        long long e = 0;
+        if ((threadIdx.x & 63) == 0) e = (long long)__hip_atomic_fetch_add((unsigned*)queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e = __builtin_amdgcn_readfirstlane((int)e);
+        if (e >= total) break;
+        const int piece = (int)(e / B);
+        const long long item = e % B;
+        if (piece > 0) {
+            // the previous piece of this item has been published (bounded: a lost flag must not hang the device)
+            long long spins = 0;
+            while (__hip_atomic_load(&flags[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1ll << 21)) __builtin_trap();      // ~2 s; a predecessor piece lasts milliseconds
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const int stop = piece + 1 < pieces ? (piece + 1) * piece_iters : 0x7fffffff;
+        pgdb_body<NQ, MAXJ, LEAN, true>(smem, item, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+                                  dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
+                                  LEAN ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters,
+                                  recs + (size_t)item * PGDB_REC, stop, piece > 0);
+        if (piece + 1 < pieces) {
+            // publish: the record and the bases written by this piece, then the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&flags[item], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_barrier();                      // (one wavefront: orders this piece's LDS accesses before the next one's)
+    }
+}
+
 // what a launcher hands to either kernel
 struct PgdbLaunch {
     DesignDev dev; long long nb; const double* e; const double* c; int tp, mode, max_iters; double* choi;

@@ -52,37 +52,9 @@ pgdb_lean_pieces_kernel(DesignDev des, long long B, const double* __restrict__ e
                         double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters,
                         int pieces, int piece_iters, int* __restrict__ queue, int* __restrict__ flags, double* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const long long total = (long long)pieces * B;
-    for (;;) {
-        long long e = 0;
-        if ((threadIdx.x & 63) == 0) e = (long long)__hip_atomic_fetch_add((unsigned*)queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        e = __builtin_amdgcn_readfirstlane((int)e);
-        if (e >= total) break;
-        const int piece = (int)(e / B);
-        const long long item = e % B;
-        if (piece > 0) {
-            // the previous piece of this item has been published (bounded: a lost flag must not hang the device)
-            long long spins = 0;
-            while (__hip_atomic_load(&flags[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1ll << 21)) __builtin_trap();      // ~2 s; a predecessor piece lasts milliseconds
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        const int stop = piece + 1 < pieces ? (piece + 1) * piece_iters : 0x7fffffff;
-        pgdb_body<NQ, MAXJ, true, true>(smem, item, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
-                                  dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
-                                  ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64, trace_out, trace_iters,
-                                  recs + (size_t)item * PGDB_REC, stop, piece > 0);
-        if (piece + 1 < pieces) {
-            // publish: the record and the bases written by this piece, then the flag
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&flags[item], piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __builtin_amdgcn_s_barrier();                      // (one wavefront: orders this piece's LDS accesses before the next one's)
-    }
+    pgdb_pieces_run<NQ, MAXJ, true>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out, dykstra_out,
+                                    backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, ncounts, trace_out,
+                                    trace_iters, pieces, piece_iters, queue, flags, recs);
 }
 
 template <int MAXJ>

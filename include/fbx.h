@@ -112,8 +112,8 @@ int         fbx_release_workspace(void);            /* free the calling thread's
  *   not depend on how many neighbours it is batched with); 2 = the lane-per-item kernel for every batch size and every
  *   tolerance argument (diagnostics / tests), 0 = never (the wavefront-per-reconstruction kernel, which smaller batches and
  *   larger designs use).
- *   "pgdb_pieces" (default 8): two-qubit fbx_pgdb_process* of more than 1024 experiments runs every reconstruction as that
- *   many pieces of outer iterations, drawn from a ticket counter by persistent workgroups, so that a launch does not wait for
+ *   "pgdb_pieces" (default 8): two-qubit fbx_pgdb_process* of more than 1024 experiments (and single-qubit ones of 1025 .. 8191
+ *   with a fixed iteration count) runs every reconstruction as that many pieces of outer iterations, drawn from a ticket counter by persistent workgroups, so that a launch does not wait for
  *   whole reconstructions at its end (csrc/fbx_pgdb_lean.hip); 1 = whole reconstructions.  Results do not depend on it.
  *   "pgdb1_binned" (default 1): the lane-per-reconstruction single-qubit kernel runs one launch per outer iteration with the
  *   reconstructions re-binned by Dykstra count in between from 2^20 experiments to convergence (2^19 for at most 12 settings;

@@ -299,3 +299,23 @@ def test_binned_relaunch_edge_cases(gpu):
     with _lib.option("pgdb1_binned", 2.0):                   # the same switch as a library option
         assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c), ref)
     assert _lib.get_option("pgdb1_binned") == 1.0
+
+
+@pytest.mark.parametrize("basis", ["pauli", "sic"])
+def test_wave_per_item_kernel_in_pieces_is_bit_identical(gpu, basis):
+    """Single-qubit batches of 1025 .. 8191 experiments with a fixed iteration count run the wavefront-per-item kernel in pieces
+    (pgdb_pieces_kernel, csrc/fbx_pgdb.hip: the ticket loop of the two-waves kernel on 1024 persistent workgroups): every
+    output equal to whole reconstructions bit for bit; forced pieces to convergence as well."""
+    from fbx import synthetic, tomography
+    B = 3000 + 7
+    design, _, e, c = synthetic.process_batch(1, basis, B)
+    with _packed(False):
+        for kw in (dict(mode="fixed", max_iters=20), dict(mode="converge")):
+            with _env(FBX_LEAN_PIECES=1):
+                ref, rs = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, trace_iters=8, **kw)
+            for env in (dict(), dict(FBX_LEAN_PIECES=5), dict(FBX_LEAN_PIECES=16, FBX_LEAN_PIECE_ITERS=1)):
+                with _env(**env):
+                    got, gs = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, trace_iters=8, **kw)
+                assert np.array_equal(ref, got), (kw, env)
+                for k in rs:
+                    assert np.array_equal(np.asarray(rs[k]), np.asarray(gs[k])), (k, kw, env)
