@@ -63,6 +63,9 @@ for wl in wls:
             for r in csv.DictReader(open(f)):
                 if sub in r.get("Kernel_Name", ""):
                     pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if wl not in PER_CALL:
+        # launches of the same kernel that are not the workload's (sweep3: the one-item conversion that builds the reference matrix)
+        pmc = {c: [x for x in v if x >= 0.01 * max(v)] if max(v) > 0 else v for c, v in pmc.items()}
     e = {c: {"mean": sum(v) / (PER_CALL[wl] if wl in PER_CALL else len(v)), "launches": len(v)} for c, v in pmc.items()}
     g = lambda c: e[c]["mean"] if c in e else None
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
