@@ -29,7 +29,7 @@ int current_device();    // device the calling thread works on: the process's (f
 // of device list entry g (its own context: stream, staging pool, workspaces).
 int device_list_size();                                                  // entries of fbx_set_devices' list, 0 or 1 = single device
 bool in_device_worker();                                                 // the calling thread is one of those workers
-int run_on_devices(int n_jobs, const std::function<int(int)>& job);     // job(g) on worker g, all waited for; first failure returned (message kept)
+int run_on_devices(const std::function<int(int, int)>& job);            // job(g, G) on worker g of the G-entry list (G read once, under the list's lock); all waited for; first failure returned
 const fbx_design* design_on_this_device(const fbx_design* des, int* rc); // des itself, or its replica on the calling worker's device (created on first use)
 double option_pgdb_eig_rel_tol(int n_qubits);   // fbx_set_option("pgdb_eig_rel_tol" / "pgdb3_eig_rel_tol")
 bool option_eigh_cooperative();                 // fbx_set_option("eigh_cooperative")

@@ -144,6 +144,14 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
                     const int span = mode == FBX_MODE_FIXED || max_iters > 0 ? max_iters : 64;      // to convergence: ~45 iterations on average
                     a.piece_iters = wv && *wv ? atoi(wv) : (span + pieces - 1) / pieces;
                     if (a.piece_iters < 1) a.piece_iters = 1;
+                    // A consumer waits for its predecessor piece with a BOUNDED spin (pgdb_pieces_run) that scales with piece_iters
+                    // and allows ~10 ms per outer iteration -- 50 x what one costs on a device that several launches share.  Long
+                    // pieces buy nothing (the tail of a launch is one piece either way): a caller with a huge fixed iteration
+                    // count gets more pieces (up to 64) and, beyond 512 iterations per piece, whole reconstructions.
+                    while (a.piece_iters > 64 && pieces < 64 && (int64_t)pieces * 2 * nb < (int64_t)1 << 30) { pieces *= 2; a.piece_iters = (span + pieces - 1) / pieces; }
+                    if (a.piece_iters > 512) pieces = 1;
+                }
+                if (pieces > 1) {
                     // per workspace slot a progress flag and a record; two ticket counters: the pipelined host entry point has one
                     // launch in flight on each of its two compute streams, on disjoint slot ranges (ws_offset 0 / > 0)
                     void* w = nullptr;
@@ -317,11 +325,10 @@ int fbx_pgdb_process_ex(const fbx_design* design, int64_t B, const double* expec
     if (B == 0) return FBX_OK;
     // fbx_set_devices: contiguous blocks of the batch, one per entry of the device list, each on that entry's
     // worker thread with its own context and a replica of the design; no exchange between devices
-    const int G = device_list_size();
-    if (G > 1 && !in_device_worker() && B >= 2 * (int64_t)G) {
-        const int64_t per = (B + G - 1) / G;
+    if (device_list_size() > 1 && !in_device_worker() && B >= 2 * (int64_t)device_list_size()) {
         const size_t m = design->dev.m, DD = (size_t)design->dev.D * design->dev.D;
-        return run_on_devices(G, [&](int g) -> int {
+        return run_on_devices([&](int g, int G) -> int {       // G: the list's length as run_on_devices read it, under its lock
+            const int64_t per = (B + G - 1) / G;
             const int64_t lo = (int64_t)g * per < B ? (int64_t)g * per : B, nb = (B - lo < per ? B - lo : per);
             if (nb <= 0) return FBX_OK;
             int r = ensure_device();

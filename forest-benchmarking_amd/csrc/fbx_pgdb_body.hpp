@@ -722,10 +722,15 @@ pgdb_pieces_run(char* smem, const DesignDev& des, long long B, const double* __r
         const long long item = e % B;
         if (piece > 0) {
             // the previous piece of this item has been published (bounded: a lost flag must not hang the device)
+            // The bound follows the length of a piece: ~8000 polls (>= 1 us each) per outer iteration of the predecessor + a
+            // fixed 2^21 (~2-4 s), i.e. > 10 ms per iteration where one costs 0.15 ms (0.5 ms on a device shared by several
+            // launches); the host keeps piece_iters <= 512 (launch_pgdb).  Beyond it the flag is lost -- a protocol error, not
+            // a slow neighbour -- and the launch is aborted rather than left spinning.
             long long spins = 0;
+            const long long spin_limit = (1ll << 21) + ((long long)piece_iters << 13);
             while (__hip_atomic_load(&flags[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) {
                 __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1ll << 21)) __builtin_trap();      // ~2 s; a predecessor piece lasts milliseconds
+                if (++spins > spin_limit) __builtin_trap();
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }

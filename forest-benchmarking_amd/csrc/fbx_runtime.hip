@@ -124,25 +124,37 @@ struct Worker {
 };
 std::mutex g_workers_mu;                  // serialises multi-device calls and changes of the list
 std::vector<Worker*> g_workers;           // one per list entry (a device may appear twice: two workers share it)
+std::vector<Worker*> g_retired;           // workers of earlier lists, parked with their device memory released; reused by later lists
+std::atomic<int> g_worker_count{0};       // g_workers.size(), readable without the lock (the pre-check of the batch entry points)
+
+// hand `j` to worker `w` / wait for it (g_workers_mu held by the caller)
+void worker_post(Worker* w, std::function<int()> j) {
+    { std::lock_guard<std::mutex> lk(w->mu); w->job = std::move(j); w->done = false; w->has_job = true; }
+    w->cv.notify_all();
+}
+int worker_wait(Worker* w) {
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->done; });
+    return w->rc;
+}
 }  // namespace
 
-int device_list_size() { return (int)g_workers.size(); }
+int device_list_size() { return g_worker_count.load(); }
 bool in_device_worker() { return t_device >= 0; }
 
-int run_on_devices(int n_jobs, const std::function<int(int)>& job) {
-    std::lock_guard<std::mutex> call(g_workers_mu);
-    const int n = n_jobs < (int)g_workers.size() ? n_jobs : (int)g_workers.size();
-    for (int g = 0; g < n; ++g) {
-        Worker* w = g_workers[g];
-        { std::lock_guard<std::mutex> lk(w->mu); w->job = [&job, g] { return job(g); }; w->done = false; w->has_job = true; }
-        w->cv.notify_all();
-    }
+// job(g, G) for g = 0 .. G - 1 with G = the length of the device list, read ONCE under the lock that fbx_set_devices takes: the
+// caller derives its split from the G it is handed, so a concurrent change of the list can neither leave a block uncomputed nor
+// address a worker that has gone.  A list of fewer than two entries runs job(0, 1) on the calling thread.
+int run_on_devices(const std::function<int(int, int)>& job) {
+    std::unique_lock<std::mutex> call(g_workers_mu);
+    const int G = (int)g_workers.size();
+    if (G < 2) { call.unlock(); return job(0, 1); }
+    for (int g = 0; g < G; ++g) worker_post(g_workers[g], [&job, g, G] { return job(g, G); });
     int rc = FBX_OK;
-    for (int g = 0; g < n; ++g) {
+    for (int g = 0; g < G; ++g) {
         Worker* w = g_workers[g];
-        std::unique_lock<std::mutex> lk(w->mu);
-        w->cv.wait(lk, [&] { return w->done; });
-        if (w->rc != FBX_OK && rc == FBX_OK) { rc = w->rc; set_error("device " + std::to_string(w->device) + ": " + w->err); }
+        const int r = worker_wait(w);
+        if (r != FBX_OK && rc == FBX_OK) { rc = r; set_error("device " + std::to_string(w->device) + ": " + w->err); }
     }
     return rc;
 }
@@ -329,15 +341,23 @@ int fbx_set_devices(const int* device_ids, int count) {
     for (int k = 0; k < count; ++k) FBX_REQUIRE(device_ids[k] >= 0 && device_ids[k] < n, "fbx_set_devices: device id out of range");
     if (count > 0) { const int rc = fbx_set_device(device_ids[0]); if (rc) return rc; }
     std::lock_guard<std::mutex> lk(g_workers_mu);
-    // workers are reused where the list agrees with the old one (their contexts stay warm); surplus workers stay parked
+    // Workers are reused -- from the current list first, then from the pool of retired ones -- so that alternating lists
+    // ([0] -> [0, 1] -> [0] -> ...) neither start a thread per change nor strand a parked thread with its context.  A worker
+    // that leaves the list gives its device memory back (staging pool, workspaces up to the multi-GB basis stores) before it
+    // is parked: nothing else could, fbx_release_workspace() only reaches the calling thread's context.
     std::vector<Worker*> next;
     for (int k = 0; k < (count > 1 ? count : 0); ++k) {
         Worker* w = nullptr;
         for (auto& old : g_workers) if (old && old->device == device_ids[k]) { w = old; old = nullptr; break; }
+        if (!w) for (auto& old : g_retired) if (old && old->device == device_ids[k]) { w = old; old = nullptr; break; }
         if (!w) { w = new Worker(); w->device = device_ids[k]; std::thread(&Worker::loop, w).detach(); }
         next.push_back(w);
     }
+    g_retired.erase(std::remove(g_retired.begin(), g_retired.end(), (Worker*)nullptr), g_retired.end());
+    for (Worker* old : g_workers) if (old) { worker_post(old, [] { return fbx_release_workspace(); }); g_retired.push_back(old); }
+    for (Worker* old : g_workers) if (old) (void)worker_wait(old);
     g_workers.swap(next);
+    g_worker_count.store((int)g_workers.size());
     return FBX_OK;
 }
 
@@ -413,7 +433,13 @@ int fbx_get_option(const char* name, double* value) {
 }
 
 int fbx_release_workspace(void) {
-    if (g_device.load() < 0 || !t_ctx) return FBX_OK;
+    if (g_device.load() < 0) return FBX_OK;
+    if (!in_device_worker() && device_list_size() > 1) {      // the workers of the device list hold the memory of multi-device calls
+        std::lock_guard<std::mutex> lk(g_workers_mu);
+        for (Worker* w : g_workers) worker_post(w, [] { return fbx_release_workspace(); });
+        for (Worker* w : g_workers) (void)worker_wait(w);
+    }
+    if (!t_ctx) return FBX_OK;
     ThreadCtx* c = t_ctx;
     if (c->stream && c->epoch == g_epoch.load()) FBX_HIP(hipStreamSynchronize(c->stream));
     c->drop_memory();

@@ -1897,10 +1897,9 @@ int fbx_kraus_sweep(int n_qubits, int64_t B, int K, const double* kraus, const d
     if (B == 0) return FBX_OK;
     const size_t d = (size_t)1 << n_qubits, D = d * d, nm = D * D * 2 * B;
     // fbx_set_devices: contiguous blocks of the batch on the workers of the device list (the items are independent)
-    const int G = device_list_size();
-    if (G > 1 && !in_device_worker() && B >= 2 * (int64_t)G) {
-        const int64_t per = (B + G - 1) / G;
-        return run_on_devices(G, [&](int g) -> int {
+    if (device_list_size() > 1 && !in_device_worker() && B >= 2 * (int64_t)device_list_size()) {
+        return run_on_devices([&](int g, int G) -> int {       // G: the list's length as run_on_devices read it, under its lock
+            const int64_t per = (B + G - 1) / G;
             const int64_t lo = (int64_t)g * per < B ? (int64_t)g * per : B, nb = (B - lo < per ? B - lo : per);
             if (nb <= 0) return FBX_OK;
             const size_t om = (size_t)lo * D * D * 2;

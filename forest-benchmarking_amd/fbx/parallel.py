@@ -92,13 +92,23 @@ class FileRendezvous:
         # purged the directory), when its files were purged under it, or when the ack of this generation does not echo
         # its token (a complete-looking dead attempt).  Only such a generation is skipped from then on.
         dead = set()
+        last_error = None                                      # a PERSISTENT OSError (ENOSPC, EACCES, a stale NFS handle) must end in
+        delay = 1e-3                                           # an error at the deadline, not in a rank spinning at 100 % CPU
         while True:
+            if time.monotonic() > deadline:
+                if last_error is not None:
+                    raise last_error
+                raise TimeoutError(f"rendezvous: could not join a generation in {self.dir}")
+            if last_error is not None:                         # back off between attempts that failed on the file system
+                time.sleep(delay)
+                delay = min(delay * 2, 0.1)
             self.gen = self._read(gen_path, deadline, skip=dead)
             token = os.urandom(8).hex().encode()
             self._mine = []
             try:
                 self._publish(token, "join")
-            except OSError:                                    # rank 0 purged the directory under us: read ``gen`` again
+            except OSError as exc:                             # rank 0 purged the directory under us: read ``gen`` again
+                last_error = exc
                 continue
             while True:
                 try:
@@ -106,10 +116,12 @@ class FileRendezvous:
                     if len(ack) == self.world and ack[self.rank] == token:
                         return self.gen
                     dead.add(self.gen)                         # an ack that cannot be about this join: a dead attempt
+                    last_error = None
                     break
                 except TimeoutError:
                     pass
-                except OSError:
+                except OSError as exc:
+                    last_error = exc
                     break
                 if time.monotonic() > deadline:
                     raise TimeoutError(f"rendezvous: rank 0 never acknowledged generation {self.gen} in {self.dir}")

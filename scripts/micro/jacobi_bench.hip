@@ -4,6 +4,9 @@
 #ifdef FBX_JACOBI_CHAIN_FIRST
 #include "jacobi_chain_first.hpp"      // round-3 experiment (measured, not adopted)
 #endif
+#ifdef FBX_JACOBI_REGPIVOT
+#include "jacobi_regpivot.hpp"         // round-5 experiment: next-round pivots through registers (measured, not adopted)
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -28,6 +31,8 @@ __global__ void __launch_bounds__(64) k_eigh(const double* A, double* W, double*
         long long t0 = __builtin_readcyclecounter();
 #ifdef FBX_JACOBI_CHAIN_FIRST
         sweeps += jacobi_eigh_wave_chain_first<N>(M, V, lane, true);
+#elif defined(FBX_JACOBI_REGPIVOT)
+        sweeps += jacobi_eigh_wave_regpivot<N>(M, V, lane, true);
 #else
         sweeps += jacobi_eigh_lds<N>(M, V, rot, lane);
 #endif
@@ -145,6 +150,7 @@ __global__ void __launch_bounds__(128) k_eigh2w(const double* A, double* W, doub
 
 int main(int argc, char** argv) {
     const bool two = argc > 2 && atoi(argv[2]) == 2;
+    const int pad = argc > 3 ? atoi(argv[3]) : 0;      // extra dynamic LDS per block: 31744 / 11264 / 4400 / 1024 -> 1 / 2 / 3 / 4 waves per SIMD
     const int N = 16, B = argc > 1 ? atoi(argv[1]) : 1024, reps = 20;
     std::vector<double> A((size_t)B * N * N * 2);
     srand(1);
@@ -165,7 +171,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 2; ++it) {
         hipEventRecord(e0);
         if (two) hipLaunchKernelGGL(k_eigh2w<N>, dim3(B), dim3(128), 0, 0, dA, dW, dV, dc, ds, reps, dsimd);
-        else hipLaunchKernelGGL(k_eigh<N>, dim3(B), dim3(64), 0, 0, dA, dW, dV, dc, ds, reps);
+        else hipLaunchKernelGGL(k_eigh<N>, dim3(B), dim3(64), pad, 0, dA, dW, dV, dc, ds, reps);
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -196,6 +202,7 @@ int main(int argc, char** argv) {
         int same = 0; for (int b = 0; b < B; ++b) same += (((sid[2 * b] >> 4) & 3) == ((sid[2 * b + 1] >> 4) & 3));
         printf("HW_ID item0: wave0 %04x wave1 %04x; items with both waves on the same SIMD: %d / %d\n", sid[0], sid[1], same, B);
     }
+    printf("pad=%d ", pad);
     printf("B=%d reps=%d kernel %.3f ms; per eigh: %.0f cycles, %.2f sweeps, %.0f cycles/round; residual %.2e; eigh/s %.3e\n",
            B, reps, ms, csum / B / reps, ssum / B / reps, csum / ssum / (N - 1), res, B * reps / (ms * 1e-3));
     return 0;
