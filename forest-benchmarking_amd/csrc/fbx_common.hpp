@@ -111,6 +111,7 @@ struct DesignDev {
     const int* pptr;         // [D+1]
     const double* pinvT;     // [m][D]: R[i][:] = sum_{g in group i} e[porder[g]] * pinvT[g][:]
     double eig_rel_tol;      // PGDB only, filled in by the launcher: fbx_set_option("pgdb[3]_eig_rel_tol")
+    int ls_reference;        // PGDB only, filled in by the launcher: FBX_MODE_LS_REFERENCE of the call's mode argument
 };
 
 }  // namespace fbx

@@ -75,6 +75,8 @@ template <int NQ, int MAXJ>
 static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const double* c, int tp,
                        int mode, int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt,
                        double* cost, int32_t* sw, const PgdbExtras& ex) {
+    const bool ls_reference = (mode & FBX_MODE_LS_REFERENCE) != 0;      // per call: the line search taken literally (include/fbx.h)
+    mode &= 0xff;
     // batches that put several reconstructions on a SIMD take the lean two-waves-per-SIMD kernel (2 qubits)
     bool lean = NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH;
     size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
@@ -119,6 +121,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     const size_t m = des->dev.m;
     DesignDev dev = des->dev;
     dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(NQ);     // per call, else the process default
+    dev.ls_reference = ls_reference ? 1 : 0;
     hipStream_t st = ex.launch_stream ? ex.launch_stream : stream();
     for (int64_t b0 = 0; b0 < B; b0 += CHUNK) {
         const int64_t nb = B - b0 < CHUNK ? B - b0 : CHUNK;
@@ -214,7 +217,7 @@ static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, cons
             // (fbx_pgdb_process_ex, eig_rel_tol >= 0) gets the wavefront-per-item kernel, which honours it, whatever the batch size
             // -- so that an experiment's iterates do not depend on how many neighbours it is batched with (packed == 2 forces
             // the lane-per-item kernel all the same: a test / diagnostics setting, documented in include/fbx.h)
-            const bool explicit_tol = ex.eig_rel_tol >= 0.0;
+            const bool explicit_tol = ex.eig_rel_tol >= 0.0 || (mode & FBX_MODE_LS_REFERENCE);      // (the flag too: the wave kernel honours it)
             if (pgdb1_eligible(des) && (packed == 2 || (packed == 1 && total >= from && !explicit_tol)))
                 return pgdb1_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         }
@@ -238,7 +241,7 @@ static int pgdb_check(const fbx_design* des, int64_t B, const void* e, const voi
     FBX_REQUIRE(des->dev.kind == FBX_KIND_PROCESS, "fbx_pgdb_process: needs a process design");
     FBX_REQUIRE(B >= 0, "fbx_pgdb_process: negative batch");
     FBX_REQUIRE(B == 0 || (e && c && choi), "fbx_pgdb_process: NULL buffer");
-    FBX_REQUIRE(mode == FBX_MODE_CONVERGE || mode == FBX_MODE_FIXED, "fbx_pgdb_process: bad mode");
+    FBX_REQUIRE((mode & ~FBX_MODE_LS_REFERENCE) == FBX_MODE_CONVERGE || (mode & ~FBX_MODE_LS_REFERENCE) == FBX_MODE_FIXED, "fbx_pgdb_process: bad mode");
     FBX_REQUIRE(max_iters >= 0, "fbx_pgdb_process: negative max_iters");
     return FBX_OK;
 }

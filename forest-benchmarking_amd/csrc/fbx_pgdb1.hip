@@ -366,6 +366,7 @@ int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const doub
 #endif
 int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode, int max_iters,
                    double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw, const PgdbExtras& ex) {
+    mode &= 0xff;          // (a call with FBX_MODE_LS_REFERENCE only gets here with pgdb_packed_1q = 2, a diagnostics setting: the flag is dropped)
     {
         // Binned relaunch from the batch sizes at which it wins (scripts/pgdb1_binned_time.py; below them a launch per outer
         // iteration costs more than the grouping returns): to convergence 2^20 experiments (2^19 for designs of <= 12

@@ -993,6 +993,7 @@ int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const doub
                    int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw,
                    const PgdbExtras& ex) {
     const int m = des->dev.m;
+    mode &= 0xff;          // FBX_MODE_LS_REFERENCE: this kernel's line search always evaluates the full cost with the rounded test
     if (m <= 4096) return launch3<4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     if (m <= 14336) return launch3<14>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     set_error("fbx_pgdb_process: 3-qubit designs are limited to 14336 settings");

@@ -545,7 +545,8 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         double Sk[NS];
         bool have_sums = false;
         auto small_regime = [&](double alpha) __attribute__((always_inline)) -> bool {
-            return small_ok && (near_clip == 0u || clip_listed) && alpha * rmax < FBX_SMALL_STEP_LIMIT;
+            // (des.ls_reference: FBX_MODE_LS_REFERENCE of the call -- every halving a full cost sum, the rounded test below)
+            return !des.ls_reference && small_ok && (near_clip == 0u || clip_listed) && alpha * rmax < FBX_SMALL_STEP_LIMIT;
         };
         auto series = [&](double alpha) __attribute__((always_inline)) -> double {      // alpha may differ per lane
             double q = Sk[NS - 1];

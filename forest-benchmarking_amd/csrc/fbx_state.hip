@@ -1467,6 +1467,97 @@ int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out) {
     return FBX_OK;
 }
 
+// ---- choi2kraus for a batch (superoperator_transformations.py:325-336): fbx_eigh_dev + one assembling kernel.
+// One workgroup per item.  Eigenpair k is kept when |lambda_k| > tol (the reference's test); its operator is
+// sqrt(lambda_k) unvec(v_k) -- numpy's scimath square root, i sqrt(|lambda|) for a negative eigenvalue -- with the phase of v_k
+// fixed so that its first component above 1e-12 ||v_k|| is real and positive (the convention of the host form this replaces,
+// fbx/operator_tools/superoperator_transformations.py: what LAPACK hands the reference on the operators its tests compare
+// entry by entry).  unvec is column stacking: K[r][c] = v[c d + r].  Kept operators are packed at the front of the item's D
+// slots in ascending eigenvalue order (the order of the reference's list), the other slots are zeroed.
+__global__ void __launch_bounds__(256)
+kraus_assemble_kernel(int D, int d, long long B, const double* __restrict__ w, const double* __restrict__ V, double tol,
+                      double* __restrict__ out, int* __restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) char kraus_smem[];
+    double* fre = (double*)kraus_smem;
+    double* fim = fre + D;
+    int* keep = (int*)(fim + D);
+    int* pos = keep + D;
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const cplx* Vb = (const cplx*)V + (size_t)b * D * D;
+    const double* wb = w + (size_t)b * D;
+    for (int k = tid; k < D; k += 256) {
+        const double ev = wb[k];
+        const bool kp = fabs(ev) > tol;
+        double fr = 0.0, fi = 0.0;
+        if (kp) {
+            double n2 = 0.0;
+            for (int i = 0; i < D; ++i) { const cplx x = Vb[(size_t)i * D + k]; n2 = fma(x.re, x.re, fma(x.im, x.im, n2)); }
+            const double thr = 1e-12 * sqrt(n2);
+            double pr = 1.0, pi = 0.0;
+            for (int i = 0; i < D; ++i) {
+                const cplx x = Vb[(size_t)i * D + k];
+                const double a = sqrt(fma(x.re, x.re, x.im * x.im));
+                if (a > thr) { pr = x.re / a; pi = -x.im / a; break; }       // |x| / x
+            }
+            const double sq = sqrt(fabs(ev));
+            if (ev >= 0.0) { fr = pr * sq; fi = pi * sq; } else { fr = -pi * sq; fi = pr * sq; }    // i (pr + i pi)
+        }
+        keep[k] = kp ? 1 : 0; fre[k] = fr; fim[k] = fi;
+    }
+    __syncthreads();
+    for (int k = tid; k < D; k += 256) { int c = 0; for (int j = 0; j < k; ++j) c += keep[j]; pos[k] = c; }
+    __syncthreads();
+    const int total = pos[D - 1] + keep[D - 1];
+    cplx* ob = (cplx*)out + (size_t)b * D * D;
+    for (int idx = tid; idx < D * D; idx += 256) {
+        const int i = idx / D, k = idx % D;                    // k fastest: coalesced reads of V[i][.]
+        if (!keep[k]) continue;
+        const cplx x = Vb[idx];
+        const int r = i % d, c = i / d;
+        cplx o; o.re = fre[k] * x.re - fim[k] * x.im; o.im = fre[k] * x.im + fim[k] * x.re;
+        ob[((size_t)pos[k] * d + r) * d + c] = o;
+    }
+    for (int idx = total * D + tid; idx < D * D; idx += 256) { cplx z; z.re = 0.0; z.im = 0.0; ob[idx] = z; }
+    if (tid == 0 && count) count[b] = total;
+}
+
+int fbx_choi2kraus_dev(int n_qubits, int64_t B, const double* d_choi, double tol, double* d_kraus_out, int32_t* d_count_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 5, "fbx_choi2kraus: n_qubits must be 1..5");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (d_choi && d_kraus_out)), "fbx_choi2kraus: bad batch / NULL buffer");
+    FBX_REQUIRE(tol >= 0.0, "fbx_choi2kraus: negative tolerance");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const int d = 1 << n_qubits, D = d * d;
+    // the eigenvectors of a block of items at a time: 16 MiB per 5-qubit item
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, ((int64_t)1 << 28) / ((int64_t)D * D * 16)));
+    DevBuf dw, dv;
+    FBX_TRY(dw.alloc(sizeof(double) * D * (size_t)chunk));
+    FBX_TRY(dv.alloc(sizeof(double) * 2 * D * D * (size_t)chunk));
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = std::min(chunk, B - b0);
+        FBX_TRY(fbx_eigh_dev(D, nb, d_choi + (size_t)b0 * D * D * 2, dw.as<double>(), dv.as<double>()));
+        hipLaunchKernelGGL(kraus_assemble_kernel, dim3((unsigned)nb), dim3(256), (size_t)D * 24, stream(), D, d, (long long)nb,
+                           dw.as<double>(), dv.as<double>(), tol, d_kraus_out + (size_t)b0 * D * D * 2,
+                           d_count_out ? d_count_out + b0 : nullptr);
+        FBX_HIP(hipGetLastError());
+    }
+    return FBX_OK;
+}
+
+int fbx_choi2kraus(int n_qubits, int64_t B, const double* choi, double tol, double* kraus_out, int32_t* count_out) {
+    FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 5, "fbx_choi2kraus: n_qubits must be 1..5");
+    FBX_REQUIRE(B >= 0 && (B == 0 || (choi && kraus_out)), "fbx_choi2kraus: bad batch / NULL buffer");
+    FBX_TRY(ensure_device());
+    if (B == 0) return FBX_OK;
+    const size_t D = (size_t)1 << (2 * n_qubits), nn = D * D * 2 * (size_t)B;
+    HostIO io; double *dc, *dk; int32_t* dn;
+    FBX_TRY(io.in(choi, nn, &dc)); FBX_TRY(io.out(nn, &dk)); FBX_TRY(io.out((size_t)B, &dn));
+    FBX_TRY(fbx_choi2kraus_dev(n_qubits, B, dc, tol, dk, dn));
+    FBX_TRY(io.back(kraus_out, dk, nn)); FBX_TRY(io.back(count_out, dn, (size_t)B));
+    return io.sync();
+}
+
 int fbx_proj_state_physical_dev(int n_qubits, int64_t B, const double* d_rho, double* d_out) {
     FBX_REQUIRE(n_qubits >= 1 && n_qubits <= 3, "fbx_proj_state_physical: n_qubits must be 1..3");
     FBX_REQUIRE(B >= 0 && (B == 0 || (d_rho && d_out)), "fbx_proj_state_physical: bad batch / NULL buffer");

@@ -12,6 +12,7 @@ COMM_ID_BYTES = 128
 COMM_SUM, COMM_MAX, COMM_MIN = range(3)
 KIND_STATE, KIND_PROCESS = 0, 1
 MODE_CONVERGE, MODE_FIXED = 0, 1
+MODE_LS_REFERENCE = 0x100       # flag: the line search of tomography.py:575-585 taken literally (include/fbx.h)
 REP_KRAUS, REP_CHOI, REP_SUPEROP, REP_PAULI_LIOUVILLE, REP_CHI = range(5)
 PROJ_CP, PROJ_TP, PROJ_TNI, PROJ_PHYSICAL_TP, PROJ_PHYSICAL_TNI = range(5)
 RAND_GINIBRE, RAND_UNITARY, RAND_STATE_VECTOR, RAND_GINIBRE_STATE, RAND_BURES_STATE = range(5)
@@ -111,6 +112,8 @@ PROTOTYPES = {
     "fbx_apply_choi_dev": [C.c_int, _i64, _vp, _vp, _vp],
     "fbx_state_measures_dev": [C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "fbx_eigh_dev": [C.c_int, _i64, _vp, _vp, _vp],
+    "fbx_choi2kraus": [C.c_int, _i64, _dp, C.c_double, _dp, _ip],
+    "fbx_choi2kraus_dev": [C.c_int, _i64, _vp, C.c_double, _vp, _vp],
     "fbx_convert_general": [C.c_int, C.c_int, C.c_int, _i64, _dp, C.c_int, _dp],
     "fbx_convert_general_dev": [C.c_int, C.c_int, C.c_int, _i64, _vp, C.c_int, _vp],
     "fbx_partial_trace": [C.c_int, C.c_int, C.c_int, _i64, _dp, _dp],

@@ -4,8 +4,9 @@ Mirror of operator_tools/superoperator_transformations.py:33-438.  ``vec`` / ``u
 host-side reshapes exactly as in the reference; every conversion runs in libfbx
 (``fbx_convert``).  ``*_batch`` helpers accept stacked inputs ``[B, ...]``.  Conversions *to*
 Kraus operators are eigenvector-valued (defined only up to phase / degeneracy,
-superoperator_transformations.py:325-336): the eigendecomposition runs on the device (``fbx_eigh``),
-the list of operators is assembled on the host with a fixed phase convention (``choi2kraus``).
+superoperator_transformations.py:325-336): ``fbx_choi2kraus`` runs the eigendecomposition and assembles
+the operators on the device with a fixed phase convention (``choi2kraus_batch``; ``choi2kraus`` is its
+B = 1 case and keeps a host assembly around ``fbx_eigh`` for dimensions that are not qubit systems).
 """
 from typing import Optional, Tuple
 
@@ -22,7 +23,7 @@ __all__ = ["vec", "unvec", "convert_batch", "kraus2chi", "kraus2superop", "kraus
            "pauli_liouville2superop", "pauli_liouville2choi", "choi2chi", "choi2superop",
            "choi2pauli_liouville", "pauli2computational_basis_matrix",
            "computational2pauli_basis_matrix", "choi2kraus", "superop2kraus", "pauli_liouville2kraus",
-           "chi2kraus"]
+           "chi2kraus", "choi2kraus_batch", "superop2kraus_batch", "pauli_liouville2kraus_batch", "chi2kraus_batch"]
 
 
 def vec(matrix: np.ndarray) -> np.ndarray:
@@ -177,14 +178,54 @@ def pauli_liouville2choi(pl_matrix):
     return _one("pauli_liouville", "choi", pl_matrix)
 
 
+def choi2kraus_batch(choi, tol: float = 1e-9):
+    """superoperator_transformations.py:325-336 for a stack of n-qubit Choi matrices [B, D, D] (n <= 5), on the device
+    (``fbx_choi2kraus``: eigendecomposition + assembly).  Returns ``(kraus [B, D, d, d], counts [B])``: the first
+    ``counts[b]`` operators of item b are sqrt(lambda_i) unvec(v_i) for the eigenpairs with |lambda_i| > tol in ascending
+    eigenvalue order -- the reference's list --, the other slots are zero.  The phase of each eigenvector is fixed so that its
+    first non-negligible component is real and positive."""
+    choi = _lib.c128(choi)
+    if choi.ndim != 3 or choi.shape[-1] != choi.shape[-2]:
+        raise ValueError("choi input must be [B, D, D]")
+    B, D = choi.shape[0], choi.shape[-1]
+    n = _nq_from_D(D)
+    if n is None:
+        raise ValueError("choi2kraus_batch serves qubit systems (D = 4^n, n <= 5); use choi2kraus for other dimensions")
+    d = 2 ** n
+    kraus = np.empty((B, D, d, d), dtype=np.complex128)
+    counts = np.zeros(B, dtype=np.int32)
+    _lib.check(_lib.lib().fbx_choi2kraus(n, B, _lib.dptr(choi.view(np.float64)), float(tol),
+                                         _lib.dptr(kraus.view(np.float64)), _lib.iptr(counts)))
+    return kraus, counts
+
+
+def superop2kraus_batch(superop, tol: float = 1e-9):
+    """superoperator_transformations.py:229-238 for a stack [B, D, D]; see choi2kraus_batch."""
+    return choi2kraus_batch(convert_batch("superop", "choi", superop), tol)
+
+
+def pauli_liouville2kraus_batch(pl_matrix, tol: float = 1e-9):
+    """superoperator_transformations.py:280-288 for a stack [B, D, D]; see choi2kraus_batch."""
+    return choi2kraus_batch(convert_batch("pauli_liouville", "choi", pl_matrix), tol)
+
+
+def chi2kraus_batch(chi_matrix, tol: float = 1e-9):
+    """superoperator_transformations.py:195-204 for a stack [B, D, D]; see choi2kraus_batch."""
+    return choi2kraus_batch(convert_batch("chi", "choi", chi_matrix), tol)
+
+
 def choi2kraus(choi, tol: float = 1e-9):
     """superoperator_transformations.py:325-336: one Kraus operator sqrt(lambda_i) unvec(v_i) per
-    eigenpair of the Choi matrix with |lambda_i| > tol (eigendecomposition on the device).  The operators
-    are defined up to the phase of each eigenvector; the phase is fixed here so that the first non-zero
-    component of every eigenvector is real and positive, which is what LAPACK hands the reference for the
-    operators its tests compare entry by entry (tests/test_superoperator_transformations.py:215-216,
-    IZKraus; probed on Haar unitaries)."""
+    eigenpair of the Choi matrix with |lambda_i| > tol.  The operators are defined up to the phase of each
+    eigenvector; the phase is fixed so that the first non-zero component of every eigenvector is real and
+    positive, which is what LAPACK hands the reference for the operators its tests compare entry by entry
+    (tests/test_superoperator_transformations.py:215-216, IZKraus; probed on Haar unitaries).  Qubit systems run
+    ``fbx_choi2kraus`` (the B = 1 case of choi2kraus_batch); any other dimension (a qutrit's 9 x 9 Choi matrix)
+    takes its eigendecomposition from ``fbx_eigh`` and assembles the list here with the same convention."""
     choi = np.asarray(choi, dtype=np.complex128)
+    if choi.ndim == 2 and _nq_from_D(choi.shape[0]) is not None and choi.shape[0] == choi.shape[1]:
+        kraus, counts = choi2kraus_batch(choi[None], tol)
+        return [np.array(kraus[0, i]) for i in range(int(counts[0]))]
     w, v = _lib.eigh_batch(choi[None])
     ops = []
     for ev, evec in zip(w[0], v[0].T):

@@ -276,7 +276,7 @@ def linear_inv_process_estimate(results: List[ExperimentResult], qubits: List[in
 
 def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trace_preserving=True,
                                 mode="converge", max_iters=0, return_stats=False, eig_rel_tol=None,
-                                trace_iters=0, out=None, devices=None):
+                                trace_iters=0, out=None, devices=None, line_search="exact"):
     """Batched pgdb_process_estimate.  ``mode='converge'`` is the reference loop (optionally
     capped by ``max_iters``); ``mode='fixed'`` runs exactly ``max_iters`` outer iterations.
     ``eig_rel_tol``: the eigensolver tolerance factor for THIS call (None = the process default,
@@ -286,11 +286,16 @@ def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trac
     are page-locked (``fbx._lib.pinned_empty`` / ``pinned_copy``) the library overlaps transfers and kernels.
     ``devices``: ``'all'`` or a list of GPU ordinals -- the batch is split into contiguous blocks over those GPUs inside
     this one call (``fbx._lib.set_devices``; results are bit-identical to the single-GPU call); None keeps the process's
-    current device list."""
+    current device list.
+    ``line_search``: ``'exact'`` (default) tests the exact cost difference of a small step; ``'reference'`` evaluates the
+    full cost at every halving and uses the reference's rounded comparison (``FBX_MODE_LS_REFERENCE``, include/fbx.h) --
+    identical up to the reference's own stopping point, another rounding-driven walk past it."""
     if devices is not None:
         _lib.set_devices(devices)
     if mode not in ("converge", "fixed"):
         raise ValueError("mode must be 'converge' or 'fixed'")
+    if line_search not in ("exact", "reference"):
+        raise ValueError("line_search must be 'exact' or 'reference'")
     e, c = _batch_arrays(design, expectations, total_counts)
     B, D = e.shape[0], design.dim ** 2
     if out is None:
@@ -307,8 +312,8 @@ def pgdb_process_estimate_batch(design: Design, expectations, total_counts, trac
     trace = np.zeros((B, int(trace_iters), 2), dtype=np.int32) if trace_iters > 0 else None
     _lib.check(_lib.lib().fbx_pgdb_process_ex(
         design.handle, B, _lib.dptr(e), _lib.dptr(c), int(bool(trace_preserving)),
-        _lib.MODE_FIXED if mode == "fixed" else _lib.MODE_CONVERGE, int(max_iters),
-        -1.0 if eig_rel_tol is None else float(eig_rel_tol),
+        (_lib.MODE_FIXED if mode == "fixed" else _lib.MODE_CONVERGE) | (_lib.MODE_LS_REFERENCE if line_search == "reference" else 0),
+        int(max_iters), -1.0 if eig_rel_tol is None else float(eig_rel_tol),
         _lib.dptr(choi.view(np.float64)), _lib.iptr(iters), _lib.iptr(dyk), _lib.iptr(bt),
         _lib.dptr(cost), _lib.iptr(work), _lib.iptr(trace), int(trace_iters) if trace is not None else 0))
     if return_stats:

@@ -57,6 +57,15 @@ extern "C" {
 #define FBX_MODE_CONVERGE 0   /* reference loop: stop when old_cost - new_cost < 1e-10
                                  (tomography.py:589); max_iters > 0 adds a cap */
 #define FBX_MODE_FIXED    1   /* exactly max_iters outer iterations (benchmark mode) */
+/* Flag, OR-ed into either mode of fbx_pgdb_process* (per call): the backtracking line search of tomography.py:575-585 taken
+ * LITERALLY -- every halving evaluates the full cost sum and the acceptance test is the reference's rounded comparison
+ * `new_cost > old_cost + change` -- instead of the default, which knows the cost DIFFERENCE of a small step exactly (a power
+ * series in alpha) and tests that.  The two agree wherever the comparison is not decided by the rounding of the cost sums,
+ * i.e. in every iteration up to the reference's own stopping point (tests hold the halving counts equal there); past it
+ * (FBX_MODE_FIXED beyond convergence) the reference performs a rounding-driven walk that no other summation order
+ * reproduces, and this flag yields ANOTHER such walk, not the reference's.  Slower: ~50 full cost
+ * evaluations per stalled iteration.  Ignored for 3 qubits, whose kernel always evaluates this way. */
+#define FBX_MODE_LS_REFERENCE 0x100
 
 /* superoperator representations for fbx_convert */
 #define FBX_REP_KRAUS   0
@@ -266,7 +275,7 @@ int fbx_state_log_likelihood_dev(const fbx_design* design, int64_t B, const doub
 /* ---------------------------------------------------------------- operator tools
  * fbx_convert: the pairwise conversions of operator_tools/superoperator_transformations.py
  * :82-371.  `in` is [B][K][d][d] for FBX_REP_KRAUS (K operators per item), else [B][D][D];
- * `out` is [B][D][D].  Conversions *to* Kraus are not offered (eigenvector-valued outputs
+ * `out` is [B][D][D].  Conversions *to* Kraus are fbx_choi2kraus below (eigenvector-valued outputs
  * are only defined up to phase, superoperator_transformations.py:325-336).  n_qubits 1..5; for
  * 4 and 5 qubits (256^2 / 1024^2 matrices, work matrices in HBM) the conversions INTO chi from a Choi /
  * superoperator / Pauli-Liouville matrix -- which the reference routes through a D x D eigendecomposition
@@ -455,6 +464,18 @@ int fbx_partial_trace_dev(int dim_a, int dim_b, int keep, int64_t B, const doubl
  * w_out[B][N]; v_out[B][N][N] holds the eigenvectors as columns (phases arbitrary), may be NULL. */
 int fbx_eigh(int N, int64_t B, const double* a, double* w_out, double* v_out);
 int fbx_eigh_dev(int N, int64_t B, const double* d_a, double* d_w_out, double* d_v_out);
+
+/* choi2kraus (superoperator_transformations.py:325-336) for a batch of n-qubit Choi matrices, n in 1..5 (D = 4^n, d = 2^n):
+ * kraus_out[B][D][d][d] complex128, row-major d x d operators; operator i of an item is sqrt(lambda_i) unvec(v_i) for the
+ * i-th eigenpair with |lambda_i| > tol in ascending eigenvalue order (the order of the reference's list; numpy's scimath
+ * square root: i sqrt(|lambda|) for a negative eigenvalue), the remaining slots are zero; count_out[B] (may be NULL) = the
+ * number of operators kept.  Kraus operators are defined up to the phase of each eigenvector: it is fixed so that the
+ * eigenvector's first component above 1e-12 of its norm is real and positive -- the convention under which the reference's
+ * entry-by-entry tests hold (tests/test_superoperator_transformations.py:215-216); compare |K| or kraus2choi(K) otherwise,
+ * as :219-224, :263-271 do.  Also the tail of superop2kraus (:229-238), pauli_liouville2kraus (:280-288) and chi2kraus
+ * (:195-204): fbx_convert to Choi first.  fbx_eigh + one assembling kernel; the result may alias nothing. */
+int fbx_choi2kraus(int n_qubits, int64_t B, const double* choi, double tol, double* kraus_out, int32_t* count_out);
+int fbx_choi2kraus_dev(int n_qubits, int64_t B, const double* d_choi, double tol, double* d_kraus_out, int32_t* d_count_out);
 
 #ifdef __cplusplus
 }

@@ -415,6 +415,43 @@ def make_process_fixed(n, basis, batch, n_iters=100, n_direct=2, workers=4, tag=
     print("fixed", n, basis, batch, "done")
 
 
+# Round 5: how far the reference's OWN fixed-100 estimate moves when the very same experiment is handed to it with its
+# settings in another order (another summation order inside A @ vec(E) and n.T @ log p -- nothing else changes).  Past its
+# stopping point the loop of tomography.py:578-585 is decided by the rounding of those sums, so this spread is the
+# reproducibility of the reference in the timed mode, item by item; the GPU tests bound the kernel's deviation by it.
+def _spread_worker(job):
+    n, basis, b, n_iters, seed = job
+    qubits = list(range(n))
+    _, _, e, c = synthetic.process_batch(n, basis, 1, first_item=b)
+    settings = process_settings(qubits, basis)
+    perm = np.random.RandomState(1000 * seed + b).permutation(len(settings))
+    res = ref_results([settings[k] for k in perm], e[0][perm], c[0][perm])
+    tr = ref_pgdb_trace(res, qubits, n_iters)
+    return b, seed, tr["fixed"], tr["conv"], int(tr["conv_iter"]), int(tr["backtracks"][:n_iters].sum()), int(tr["dykstra"][:n_iters].sum())
+
+
+def make_fixed_spread(n, basis, seeds=(1, 2, 3), workers=8):
+    import multiprocessing as mp
+    g = np.load(os.path.join(HERE, f"process_{n}q_{basis}_fixed100.npz"))
+    batch, n_iters = g["expectations"].shape[0], int(g["n_iters"])
+    jobs = [(n, basis, b, n_iters, s) for b in range(batch) for s in seeds]
+    with mp.Pool(workers) as pool:
+        out = pool.map(_spread_worker, jobs, chunksize=1)
+    K = len(seeds)
+    fixed = np.zeros((batch, K)); conv = np.zeros((batch, K)); bts = np.zeros((batch, K), dtype=np.int64)
+    for b, s, fx, cv, ci, bt, dy in out:
+        k = seeds.index(s)
+        assert ci == int(g["conv_iter"][b]) and dy == int(g["dykstra"][b][:n_iters].sum()), "a re-ordering changed an iteration count"
+        fixed[b, k] = np.abs(fx - g["pgdb_fixed"][b]).max()
+        conv[b, k] = np.abs(cv - g["pgdb_conv"][b]).max()
+        bts[b, k] = bt
+    np.savez_compressed(os.path.join(HERE, f"process_{n}q_{basis}_fixed100_spread.npz"), seeds=np.array(seeds),
+                        fixed_spread=fixed, conv_spread=conv, backtracks=bts,
+                        backtracks_unpermuted=np.array([int(g["backtracks"][b][:n_iters].sum()) for b in range(batch)]))
+    print(f"spread {n}q {basis}: fixed-100 max {fixed.max():.2e} median of per-item max {np.median(fixed.max(axis=1)):.2e}; "
+          f"converge max {conv.max():.2e}")
+
+
 def make_sweep_3q(batch=6):
     """The 3-qubit leg of BASELINE configs[2]'s pipeline for `batch` random CPTP Kraus sets (K = 4, 8 x 8 operators): what the
     reference's kraus2choi / kraus2pauli_liouville / kraus2chi / choi2chi / process_fidelity return (round 4: the fused
@@ -441,6 +478,10 @@ if __name__ == "__main__":
     np.random.seed(0)
     if "--sweep3q" in sys.argv:
         make_sweep_3q()
+        sys.exit(0)
+    if "--fixed-spread" in sys.argv:      # round 5: the reference against its own re-ordered self (about a minute on 8 cores)
+        make_fixed_spread(2, "pauli")
+        make_fixed_spread(2, "sic")
         sys.exit(0)
     if "--fixed2q" in sys.argv:           # timed-mode fixtures, 2 qubits (a few minutes on 6 cores)
         make_process_fixed(2, "pauli", 64, workers=6)

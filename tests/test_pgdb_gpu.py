@@ -268,11 +268,15 @@ def test_lean_two_waves_per_simd_kernel_agrees_with_the_one_wave_kernel(gpu, bas
         small, ss = tomography.pgdb_process_estimate_batch(design, e, c, return_stats=True, **kw)
         big, sb = tomography.pgdb_process_estimate_batch(design, eb, cb, return_stats=True, **kw)
         assert np.array_equal(big[:128], big[-128:])                     # position independent, bit for bit
-        assert np.abs(big[:128] - small).max() < (1e-10 if kw["mode"] == "converge" else 2e-7)
-        for k in ("iterations", "dykstra"):
+        # to convergence (the reference's semantics): rounding level and EVERY count equal, halvings included (measured 6e-14);
+        # 60 fixed iterations run past convergence, where the halving count of a stalled iteration is decided at rounding level
+        # (measured 2.7e-10 / +-152 halvings in 60 iterations; scripts/lean_vs_onewave_diffs.py)
+        conv = kw["mode"] == "converge"
+        assert np.abs(big[:128] - small).max() < (1e-12 if conv else 1e-9)
+        for k in ("iterations", "dykstra") + (("backtracks",) if conv else ()):
             assert np.array_equal(sb[k][:128], ss[k]) and np.array_equal(sb[k][-128:], ss[k]), k
-        assert np.abs(sb["backtracks"][:128].astype(int) - ss["backtracks"]).max() <= (50 if kw["mode"] == "converge" else 400)
-        assert np.abs(sb["cost"][:128] - ss["cost"]).max() < 1e-10
+        assert np.abs(sb["backtracks"][:128].astype(int) - ss["backtracks"]).max() <= (0 if conv else 200)
+        assert np.abs(sb["cost"][:128] - ss["cost"]).max() < 1e-13
 
 
 @pytest.mark.parametrize("kw,pieces,piece_iters", [(dict(mode="fixed", max_iters=30), 8, None), (dict(mode="converge"), 3, 7),
