@@ -464,7 +464,7 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
                          "executed_flop": ex, "executed_breakdown": {k: round(v) for k, v in parts.items()},
                          "dense_accounting_tflops": tflops, "dense_accounting_frac": tflops / FP64_PEAK_TFLOPS,
                          "note": "achieved / frac = flops the Kronecker-form kernel really performs per reconstruction, from its "
-                                 "work counters (DESIGN.md 2.2), x batch / HIP-event kernel time; executed_flop_measured = the "
+                                 "work counters (DESIGN.md 4.4), x batch / HIP-event kernel time; executed_flop_measured = the "
                                  "hardware's count of the same launch (profiles/pmc_flops.json).  dense_accounting_tflops = the "
                                  "same launch priced in the reference's dense formulation (3 x 2m x 4096 complex MACs per outer "
                                  "iteration + ~25 N^3 per 64 x 64 eigendecomposition): an accounting figure that exceeds the fp64 "

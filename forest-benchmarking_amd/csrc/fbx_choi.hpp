@@ -32,6 +32,7 @@ struct ChoiLds {
     static constexpr bool lean = LEAN;
     cplx* Mw;      // [D * LD]   row-major staging matrix (Pauli transforms); LEAN: = Ms, running into Vs
     cplx* Mpt;     // partial-trace staging: Mw, or Ms (LEAN)
+    cplx* Ts;      // scratch of the generic warm-start basis change (D != 16): Mw, or (LEAN, where Mw IS Ms) a block of its own
     cplx* Ms;      // [sys_elems<D>()]  Jacobi work matrix, element-major block layout (fbx_eigh.hpp)
     cplx* Vs;      // [sys_elems<D>()]  eigenvectors, same layout
     double* lam;   // [D]
@@ -45,13 +46,14 @@ struct ChoiLds {
     double jtol2 = FBX_JACOBI_TOL2;   // off-norm^2 / norm^2 at which the CP projections' eigensolver stops
     static constexpr size_t bytes() {
         static_assert(!LEAN || 2 * sys_elems<D>() >= D * LD, "the transforms' staging matrix must fit into Ms + Vs");
-        return sizeof(cplx) * ((LEAN ? 0 : D * LD) + 2 * sys_elems<D>() + d * LDs + 2 * d * d + d * LDs) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
+        return sizeof(cplx) * ((LEAN ? 0 : D * LD) + (LEAN && D != 16 ? sys_elems<D>() : 0) + 2 * sys_elems<D>() + d * LDs + 2 * d * d + d * LDs) + sizeof(double) * D + sizeof(JRec) * (D / 2 + 1);
     }
     __device__ void carve(char*& p) {
         if constexpr (!LEAN) { Mw = (cplx*)p; p += sizeof(cplx) * D * LD; }
         Ms = (cplx*)p; p += sizeof(cplx) * sys_elems<D>();
         Vs = (cplx*)p; p += sizeof(cplx) * sys_elems<D>();
         if constexpr (LEAN) { Mw = Ms; Mpt = Ms; } else { Mpt = Mw; }
+        if constexpr (LEAN && D != 16) { Ts = (cplx*)p; p += sizeof(cplx) * sys_elems<D>(); } else { Ts = Mw; }
         pt = (cplx*)p; p += sizeof(cplx) * d * LDs;
         pts = (cplx*)p; p += sizeof(cplx) * d * d;
         ptV = (cplx*)p; p += sizeof(cplx) * d * d;
@@ -95,8 +97,7 @@ __device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool wa
         else
 #endif
         {
-            static_assert(D == 16 || !LdsT::lean, "the lean layout has no scratch for the generic basis change");
-            jacobi_rotate_into_basis<D>(L.Ms, L.Vs, (cplx*)L.Mw, lane);
+            jacobi_rotate_into_basis<D>(L.Ms, L.Vs, L.Ts, lane);
         }
     }
     int sw;

@@ -38,7 +38,7 @@ int option_pgdb1_binned();                       // fbx_set_option("pgdb1_binned
 int option_pgdb_packed_1q();                     // fbx_set_option("pgdb_packed_1q"): single-qubit PGDB on the lane-per-item kernel: 0 never, 1 large batches (default), 2 always
 // Defaults of those options: the eigensolver of PGDB's CP projections stops at an off-diagonal norm of
 // <this> x the previous outer step (relative to ||H||_F), never tighter than 1e-13; 0 = always 1e-13.
-// Surveys against the oracle (DESIGN.md 2.1 / 2.2): 2 qubits, 704 items -- identical deviation histogram at 1e-8
+// Surveys against the oracle (DESIGN.md 4.0-4.2 / 2.2): 2 qubits, 704 items -- identical deviation histogram at 1e-8
 // and at 0; 3 qubits, 66 items -- 9e-11 at 1e-7 and at 0 alike (7e-10 at 3e-7, 4.5e-10 on 18 items at 1e-6, 1.3e-8 at 1e-5).
 #ifndef FBX_JTOL_REL
 #define FBX_JTOL_REL 1e-8

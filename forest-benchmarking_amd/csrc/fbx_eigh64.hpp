@@ -1,6 +1,6 @@
 // fbx_eigh64.hpp -- the 64 x 64 Hermitian eigensolver of the 3-qubit kernels (1024 threads, one 2 x 2 block per thread on a
 // 32 x 32 grid), round 4: the same cyclic two-sided Jacobi in the Brent-Luk systolic form as jacobi_eigh_simple<64, 1024>
-// (fbx_eigh.hpp) with the two things that bounded its round removed (DESIGN.md 2.2: LDS WRITES, 78 B/clk/CU, and two
+// (fbx_eigh.hpp) with the two things that bounded its round removed (DESIGN.md 4.4: LDS WRITES, 78 B/clk/CU, and two
 // workgroup barriers per round):
 //
 //   * the eigenvector block never touches LDS.  A wavefront owns two block rows (lanes 0-31 = row 2w, 32-63 = row 2w + 1),

@@ -78,17 +78,22 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     const bool ls_reference = (mode & FBX_MODE_LS_REFERENCE) != 0;      // per call: the line search taken literally (include/fbx.h)
     mode &= 0xff;
     // batches that put several reconstructions on a SIMD take the lean two-waves-per-SIMD kernel (2 qubits)
-    bool lean = NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH;
-    size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
-    if constexpr (NQ == 2) {
+    // MAXJ = 0: the STREAMED instantiation (fbx_pgdb_body.hpp) -- any number of settings, outcome slots read from HBM / L2
+    constexpr bool STREAM = MAXJ == 0;
+    const int slots = STREAM ? (des->dev.m + 63) / 64 : MAXJ;            // outcome slots per lane
+    bool lean = STREAM || (NQ == 2 && (ex.total_batch > B ? ex.total_batch : B) >= FBX_LEAN_MIN_BATCH);
+    size_t lds = STREAM ? pgdb_stream_lds(NQ, des->dev.S) : PgdbLds<NQ, false>::bytes(des->dev.S, 64 * MAXJ);      // Ln has one row pair per outcome slot of the kernel
+    if constexpr (NQ == 2 && !STREAM) {
         lean = lean && pgdb_lean_eligible(des->dev.S);
         if (lean) lds = pgdb_lean_lds(MAXJ, des->dev.S);
     }
     if (lds > 160 * 1024) {
-        set_error("fbx_pgdb_process: design too large for the LDS-resident kernel");
+        set_error("fbx_pgdb_process: too many distinct input states for the prediction tables of the LDS-resident kernel");
         return FBX_ERR_UNSUPPORTED;
     }
-    if (!lean) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_kernel<NQ, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if constexpr (!STREAM) {
+        if (!lean) FBX_HIP(hipFuncSetAttribute((const void*)pgdb_kernel<NQ, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     // per-item store of Dykstra eigenvector bases (BASIS_CAP x D x D complex each = 128 KiB per 2-qubit
     // item): a grow-only workspace of the calling thread (released by fbx_release_workspace).  A single
     // outer iteration has no previous iteration to take a basis from: no store then.
@@ -99,7 +104,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     // When the device cannot give that much, the launch size is halved until the store fits.
     const bool want_basis = !(mode == FBX_MODE_FIXED && max_iters <= 1) && !(mode == FBX_MODE_CONVERGE && max_iters == 1);
     const size_t basis_item = want_basis ? sizeof(cplx) * D * D * BASIS_CAP : 0;
-    const size_t counts_item = lean ? sizeof(double) * 2 * MAXJ * 64 : 0;      // normalised counts of the lean kernel (fbx_pgdb_body.hpp)
+    const size_t counts_item = lean ? sizeof(double) * 2 * (size_t)slots * 64 : 0;      // normalised counts of the lean kernel (fbx_pgdb_body.hpp)
     int64_t CHUNK = 65536;
     char* wsp = nullptr;
     int64_t ws_items = ex.ws_items > 0 ? ex.ws_items : (B < CHUNK ? B : CHUNK);
@@ -117,7 +122,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
     }
     const int64_t n_slots = ws_items;
     cplx* basis = basis_item ? (cplx*)wsp + (size_t)ex.ws_offset * D * D * BASIS_CAP : nullptr;
-    double* ncounts = counts_item ? (double*)(wsp + basis_item * (size_t)n_slots) + (size_t)ex.ws_offset * 2 * MAXJ * 64 : nullptr;
+    double* ncounts = counts_item ? (double*)(wsp + basis_item * (size_t)n_slots) + (size_t)ex.ws_offset * 2 * (size_t)slots * 64 : nullptr;
     const size_t m = des->dev.m;
     DesignDev dev = des->dev;
     dev.eig_rel_tol = ex.eig_rel_tol >= 0.0 ? ex.eig_rel_tol : option_pgdb_eig_rel_tol(NQ);     // per call, else the process default
@@ -135,6 +140,11 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
         // whose outer iterations last microseconds (a piece's set-up and hand-over then cost what the tail saves: 8000 Pauli
         // experiments 8.6 -> 10.3 ms, while 100 fixed iterations of the SIC design gain 25-35 %; scripts/pieces_time_1q.py)
         const bool fat_pieces = !lean && nb > 1024 && (NQ == 2 || mode == FBX_MODE_FIXED);
+        if constexpr (STREAM) {                             // whole reconstructions, one workgroup each
+            const int rc = pgdb_stream_launch(NQ, lds, st, a);
+            if (rc) return rc;
+            continue;
+        } else {
         {
             // the two-waves kernel runs its reconstructions in pieces (fbx_pgdb_lean.hip): fbx_set_option("pgdb_pieces"), 1 = whole
             // reconstructions.  FBX_LEAN_PIECES / FBX_LEAN_PIECE_ITERS (environment, experiments and tests) override it per call.
@@ -185,6 +195,7 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
         }
         hipLaunchKernelGGL((pgdb_kernel<NQ, MAXJ>), dim3((unsigned)nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
                            a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.trace, a.trace_iters);
+        }
     }
     FBX_HIP(hipGetLastError());
     return FBX_OK;
@@ -223,15 +234,18 @@ static int pgdb_dispatch(const fbx_design* des, int64_t B, const double* e, cons
         }
         if (m <= 64) return launch_pgdb<1, 1>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         if (m <= 256) return launch_pgdb<1, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+        // merged / repeated datasets (the reference takes any result list, tomography.py:494-539): outcome slots streamed from HBM
+        return launch_pgdb<1, 0>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     } else if (n == 2) {
         if (m <= 256) return launch_pgdb<2, 4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         if (m <= 576) return launch_pgdb<2, 9>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
         if (m <= 1024) return launch_pgdb<2, 16>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+        return launch_pgdb<2, 0>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     }
     else if (n == 3) {
         return pgdb3_dispatch(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     }
-    set_error("fbx_pgdb_process: design outside the supported sizes (1 qubit m <= 256, 2 qubits m <= 1024)");
+    set_error("fbx_pgdb_process: process designs of 1 to 3 qubits");
     return FBX_ERR_UNSUPPORTED;
 }
 

@@ -150,7 +150,7 @@ pgdb1_packed_kernel(DesignDev des, long long B, const double* __restrict__ expec
 //   * Once few reconstructions are left (they no longer fill the chip: grouping buys nothing and every launch costs a full
 //     iteration's latency) one last launch runs the remaining ones to completion out of registers, as the kernel above does.
 // The arithmetic of a reconstruction is per lane and in a fixed order either way: results are bit-identical to the persistent
-// kernel's (tests/test_pgdb1_gpu.py).  Measured (DESIGN.md 2.4): 2^20 experiments to convergence 64.6 -> 53 ms (Pauli),
+// kernel's (tests/test_pgdb1_gpu.py).  Measured (DESIGN.md 4.5): 2^20 experiments to convergence 64.6 -> 53 ms (Pauli),
 // 43.4 -> 34.5 ms (SIC); 30 fixed iterations 500 -> 217 ms / 131 -> 46 ms.
 constexpr int P1_NB = 8;                 // bins: Dykstra count of the last outer iteration 1 .. 7, 8+
 constexpr int P1_NF = 56;                // doubles per slot

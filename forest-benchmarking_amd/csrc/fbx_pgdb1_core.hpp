@@ -479,7 +479,7 @@ FBX_P1 H4 p1_gradient(const Des& des, const NT& nt, const double (&R)[16]) {
 // (up to 50) cost less than one evaluation.  Outcomes at the clip, or moving by more than their own size over a full step,
 // are kept out of the sums and evaluated exactly (two register slots per lane; a lane with more of them stays with full
 // evaluations).  The acceptance test is then made on the difference itself -- the rule of the 2-qubit kernel
-// (fbx_pgdb.hip `rejected()`, DESIGN.md 2.1): the noise-free limit of the reference's `new_cost > old_cost + change`.
+// (fbx_pgdb.hip `rejected()`, DESIGN.md 4.0-4.2): the noise-free limit of the reference's `new_cost > old_cost + change`.
 constexpr int P1_NS = 16;
 constexpr double P1_SMALL_STEP = 0x1p-3;
 struct P1Line {

@@ -151,7 +151,7 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
 // Both A operands are read TRANSPOSED so that the 16 lanes of a group walk along a row of the layout:
 // H[m][k] = conj(H[k][m]) (H is exactly Hermitian: it was just symmetrised) and (V^H)[m][k] = conj(V[k][m]).
 // 2 x 16 x 2 b128 loads and 8 stores per lane instead of 2 x 64 x 4 loads; the products themselves take
-// 128 x 32 cycles per wavefront (the VALU form: 68.7 k cycles per decomposition, this one: see DESIGN.md 2.2).
+// 128 x 32 cycles per wavefront (the VALU form: 68.7 k cycles per decomposition, this one: see DESIGN.md 4.4).
 #ifndef FBX3_ROTATE_VALU
 __device__ void rotate_into_basis_mfma(Lds& L, int t) {
     typedef double v4d __attribute__((ext_vector_type(4)));

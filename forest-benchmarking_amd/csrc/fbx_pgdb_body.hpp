@@ -2,7 +2,7 @@
 // translation units that instantiate it: fbx_pgdb.hip (the one-wavefront-per-SIMD kernel, the launchers and the C ABI) and
 // fbx_pgdb_lean.hip (the two-wavefronts-per-SIMD kernel).  Two units because they are COMPILED DIFFERENTLY: the instruction
 // scheduler's max-ILP strategy is worth 3 % on the lone wavefront of the first kernel and costs the register-starved second one
-// half its speed (build.py: per-file flags; DESIGN.md 2.1).
+// half its speed (build.py: per-file flags; DESIGN.md 4.0-4.2).
 #pragma once
 #include "fbx_choi.hpp"
 #include <cstdlib>
@@ -95,6 +95,13 @@ struct PgdbLds {
     }
 };
 
+// LEAN: the design's Bloch table [S][D] fits at the front of Ms + Vs, in front of Rb (2 qubits: up to 50 input states)
+template <int NQ>
+__host__ __device__ constexpr bool pgdb_ct_fits(int S) {
+    constexpr int D = 1 << (2 * NQ);
+    return sizeof(double) * D * (size_t)S + sizeof(double) * D * D <= 2 * sizeof(cplx) * sys_elems<D>();
+}
+
 // T[s][i] = sum_j R[i][j] * C[j][s].  Lane (i = lane % D, q = lane / D) keeps row i of R in registers
 // (Rb is transposed, so the D loads are conflict-free across i) and walks the states s = q, q + 64/D,
 // ...: per state D/2 broadcast 16-byte loads of the state's Bloch vector (Ct is [S][D]) and D FMAs, all
@@ -135,6 +142,15 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
           double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters,
           double* __restrict__ rec = nullptr, int piece_stop = 0x7fffffff, bool resume = false) {
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
+    // STREAM (LEAN with MAXJ = 0; round 5): designs of ANY number of settings -- merged or repeated datasets (the reference loops
+    // over whatever result list it is given, tomography.py:494-539).  No per-slot register arrays at all: the number of outcome
+    // slots per lane is a run-time value, the normalised counts and design words of slot j are read from HBM / L2 where they
+    // are used (the item's slice of the ncounts workspace, the design's table), the probabilities come from the two tables as
+    // in every LEAN instantiation.  Slow (every pass over the outcomes streams 20 bytes per setting through L2) and
+    // complete; designs that fit the register-resident instantiations never get here (pgdb_dispatch).
+    constexpr bool STREAM = LEAN && MAXJ == 0;
+    static_assert(!STREAM || !PIECES, "the streamed instantiation runs whole reconstructions");
+    constexpr int MJ = STREAM ? 1 : MAXJ;           // extent of the per-slot register arrays
     // The passes over a lane's MAXJ outcome slots (cost, gradient weights, clip detection, power sums) are straight-line code in
     // the one-wave kernel and LOOPS in the lean one (the slot index is wave-uniform: register arrays are indexed through
     // s_set_gpr_idx): unrolled they are 6.4 KB of code per slot -- 58 of the 91 KB of the 540-setting instantiation, against a
@@ -142,10 +158,11 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 #ifndef FBX_FAT_SLOT_UNROLL
 #define FBX_FAT_SLOT_UNROLL MAXJ     // (experiment: 1 = the one-wave kernel loops over its slots too)
 #endif
-    constexpr int SLOT_UNROLL = LEAN ? 1 : FBX_FAT_SLOT_UNROLL;
+    constexpr int SLOT_UNROLL = LEAN ? 1 : (FBX_FAT_SLOT_UNROLL);
     int lane = threadIdx.x & 63;            // (re-made opaque per phase in the lean kernel: FBX_LOCAL, fbx_common.hpp)
     const long long item = item_;
     const int m = des.m, S = des.S;
+    const int nslots = STREAM ? (m + 63) / 64 : MAXJ;       // outcome slots per lane (a compile-time constant unless STREAM)
     PgdbLds<NQ, LEAN> L;
     L.carve(smem, S, 64 * MAXJ);
 
@@ -156,13 +173,16 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     // spent 3.7 x the one-wave kernel's cycles in the transform / table phases, profiles/r04/phase_*.txt).  pgdb_lean_eligible()
     // keeps designs whose table does not fit beside Rb (more than 50 states) on the one-wave kernel.
     const double* Ct;
-    if constexpr (LEAN) Ct = (const double*)L.choi.Ms;
+    // (STREAM: a design whose Bloch table does not fit beside Rb -- more than 50 input states for two qubits -- reads it through L2)
+    const bool ct_staged = !STREAM || pgdb_ct_fits<NQ>(S);
+    if constexpr (STREAM) Ct = ct_staged ? (const double*)L.choi.Ms : des.Ct;
+    else if constexpr (LEAN) Ct = (const double*)L.choi.Ms;
     else {
         for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
         Ct = L.Cl;
     }
     auto stage_ct = [&]() __attribute__((always_inline)) {       // LEAN: des.Ct -> front of Ms + Vs (both sides 16-byte aligned)
-        if constexpr (LEAN) {
+        if (LEAN && ct_staged) {
             typedef __attribute__((address_space(1))) const fbx_v2d* gptr;
             const gptr src = (gptr)des.Ct;
             fbx_v2d* dst = (fbx_v2d*)L.choi.Ms;
@@ -176,11 +196,29 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     // gradient to the projection and from the projection to the end of the line search -- not across the projection, where the
     // Dykstra state and the eigensolver need the registers: load_slots() re-reads them (coalesced rows of the item's slice of
     // an L2-resident workspace; the design's own table) in front of the gradient pass and in front of the line search.
-    double nreg_p[LEAN ? MAXJ : 1], nreg_m[LEAN ? MAXJ : 1];
-    const __amdgpu_buffer_rsrc_t nc_rsrc = buf_rsrc(ncounts, LEAN ? 2 * MAXJ * 64 * 8 : 0);      // (raw buffer rows: fbx_common.hpp)
+    double nreg_p[LEAN ? MJ : 1], nreg_m[LEAN ? MJ : 1];
+    const __amdgpu_buffer_rsrc_t nc_rsrc = buf_rsrc(ncounts, LEAN ? 2u * (unsigned)nslots * 64u * 8u : 0u);      // (raw buffer rows: fbx_common.hpp)
     const __amdgpu_buffer_rsrc_t sp_rsrc = buf_rsrc(des.sp, 4u * (unsigned)m);                   // settings beyond m read as 0
-    {
-        double npl[MAXJ], nmi[MAXJ];
+    if constexpr (STREAM) {        // two passes: the grand total (same order of additions as below), then the normalised counts
+        for (int j = 0; j < nslots; ++j) {
+            const int g = lane + 64 * j;
+            if (g < m) tot += counts[item * m + des.order[g]];
+        }
+        tot = uniform(wave_sum(tot));
+        for (int j = 0; j < nslots; ++j) {
+            const int g = lane + 64 * j;
+            double np_ = 0.0, nm_ = 0.0;
+            if (g < m) {
+                const int k = des.order[g];
+                const double e = expect[item * m + k], c = counts[item * m + k];
+                const double plus = (1.0 + e) / 2.0;
+                np_ = c * plus; nm_ = c * (1.0 - plus);
+            }
+            buf_store_f64(nc_rsrc, 8u * lane, 512u * (2 * j), np_ / tot); buf_store_f64(nc_rsrc, 8u * lane, 512u * (2 * j + 1), nm_ / tot);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wavefront reads them back through the same L2)
+    } else {
+        double npl[MJ], nmi[MJ];
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int g = lane + 64 * j;
@@ -207,7 +245,8 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     FBX_WAVE_SYNC();
     // normalised counts of slot j
     auto counts_of = [&](int j, double& np_, double& nm_) __attribute__((always_inline)) {
-        if constexpr (LEAN) { np_ = nreg_p[j]; nm_ = nreg_m[j]; }
+        if constexpr (STREAM) { np_ = buf_load_f64(nc_rsrc, 8u * lane, 512u * (2 * j)); nm_ = buf_load_f64(nc_rsrc, 8u * lane, 512u * (2 * j + 1)); }
+        else if constexpr (LEAN) { np_ = nreg_p[j]; nm_ = nreg_m[j]; }
         else { np_ = L.Ln[(2 * j) * 64 + lane]; nm_ = L.Ln[(2 * j + 1) * 64 + lane]; }
     };
 
@@ -215,14 +254,19 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     const double inv_mu = (2.0 * d * d) / 3.0;          // 1 / mu, mu = 3 / (2 d^2)
 
     // per-setting design words: in registers for the whole reconstruction (LEAN: see load_slots)
-    uint32_t spw[MAXJ];
+    uint32_t spw[MJ];
+    if constexpr (!STREAM) {
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int g = lane + 64 * j;
-        spw[j] = g < m ? des.sp[g] : 0u;
+        for (int j = 0; j < MAXJ; ++j) {
+            const int g = lane + 64 * j;
+            spw[j] = g < m ? des.sp[g] : 0u;
+        }
     }
+    auto spw_of = [&](int j) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (STREAM) return buf_load_u32(sp_rsrc, 4u * lane, 256u * j); else return spw[j];
+    };
     auto load_slots = [&]() __attribute__((always_inline)) {
-        if constexpr (LEAN) {
+        if constexpr (LEAN && !STREAM) {
             // (the compiler must neither keep the previous copies alive across the projection nor hoist these loads above it)
             __asm__ volatile("" ::: "memory");
 #pragma unroll
@@ -238,7 +282,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         const int g = lane + 64 * j;
         a = missing; b = missing;
         if (g < m) {
-            const uint32_t dw = spw[j];
+            const uint32_t dw = spw_of(j);
             const int s = dw >> 16, p = dw & 0xffff;
             const double cf = unit_coefs ? 1.0 : des.coef[g];
             const double tr = T[s * D], ex = cf * T[s * D + p];
@@ -248,7 +292,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     // model probabilities of the current estimate (pe) and of the update direction (pu), per owned
     // setting and outcome: p(alpha) = pe + alpha * pu.  One-wave kernel: register arrays, so a line-search step
     // touches no memory.  LEAN: recomputed from the two tables at every use (same expressions, same bits).
-    double pep[LEAN ? 1 : MAXJ], pem[LEAN ? 1 : MAXJ], pup[LEAN ? 1 : MAXJ], pum[LEAN ? 1 : MAXJ];
+    double pep[LEAN ? 1 : MJ], pem[LEAN ? 1 : MJ], pup[LEAN ? 1 : MJ], pum[LEAN ? 1 : MJ];
     if constexpr (!LEAN) {
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) { pep[j] = pem[j] = 1.0; pup[j] = pum[j] = 0.0; }
@@ -271,7 +315,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     auto cost_at = [&](double alpha) __attribute__((always_inline)) -> double {
         double acc = 0.0;
 #pragma unroll SLOT_UNROLL
-        for (int j = 0; j < MAXJ; ++j) {
+        for (int j = 0; j < (STREAM ? nslots : MAXJ); ++j) {
             const int g = lane + 64 * j;
             if (g < m) {
                 double ep_, em_, up_, um_;
@@ -371,7 +415,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         for (int idx = lane; idx < D * S; idx += 64) Wt[idx] = 0.0;
         FBX_WAVE_SYNC();
 #pragma unroll SLOT_UNROLL
-        for (int j = 0; j < MAXJ; ++j) {
+        for (int j = 0; j < (STREAM ? nslots : MAXJ); ++j) {
             const int g = lane + 64 * j;
             if (g < m) {
                 double ep_, em_;
@@ -382,7 +426,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
                 counts_of(j, np_, nm_);
                 const double ep = np_ / pp, em = nm_ / pm;
                 const double cf = unit_coefs ? 1.0 : des.coef[g];
-                const uint32_t dw = spw[j];
+                const uint32_t dw = spw_of(j);
                 const int st = dw >> 16, p = dw & 0xffff;
                 atomicAdd(&Wt[st * D], 0.5 * (ep + em));
                 atomicAdd(&Wt[st * D + p], cf * 0.5 * (ep - em));
@@ -431,7 +475,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         // projections stops at an off-diagonal norm of des.eig_rel_tol (default FBX_JTOL_REL; fbx_set_option) x the previous outer step (relative to
         // ||H||_F), never looser than that and never tighter than the 1e-13 it uses everywhere else.  What the
         // reconstruction V diag(M)+ V^H drops is of the size of that off-diagonal part, i.e. 1e-8 of the
-        // distance the estimate still moves per iteration (DESIGN.md 2.1: -10 % time, parity survey unchanged).
+        // distance the estimate still moves per iteration (DESIGN.md 4.0-4.2: -10 % time, parity survey unchanged).
         { const double tr_ = des.eig_rel_tol * outer_step; L.choi.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }
         basis.write_all = outer_step < FBX_BASIS_WRITE_STEP;
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
@@ -486,12 +530,13 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         double rmax = 0.0;                   // max |pu / pe| over the outcomes that are not listed
         uint32_t near_clip = 0u;             // wave-uniform: bit 2j / 2j+1 = some lane's +/- outcome of slot j is near the clip
 #pragma unroll SLOT_UNROLL
-        for (int j = 0; j < MAXJ; ++j) {
+        for (int j = 0; j < (STREAM ? nslots : MAXJ); ++j) {
             double ep_, em_, up_, um_;
             pe_of(j, ep_, em_); pu_of(j, up_, um_);
             rmax = fmax(rmax, fmax(fabs(ratio(up_, ep_)), fabs(ratio(um_, em_))));
-            if (__ballot(exact(up_, ep_))) near_clip |= 1u << (2 * j);
-            if (__ballot(exact(um_, em_))) near_clip |= 2u << (2 * j);
+            // (STREAM: more slots than the mask has bit pairs -- one flag for all, every slot is searched below)
+            if (__ballot(exact(up_, ep_))) near_clip |= STREAM ? 1u : 1u << (2 * j);
+            if (__ballot(exact(um_, em_))) near_clip |= STREAM ? 1u : 2u << (2 * j);
         }
         rmax = uniform(wave_max(rmax));
         const bool small_ok = rmax == rmax;
@@ -510,10 +555,10 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
             const unsigned long long below = (1ull << lane) - 1ull;
             FBX_WAVE_SYNC();
 #pragma unroll SLOT_UNROLL
-            for (int j = 0; j < MAXJ; ++j) {
+            for (int j = 0; j < (STREAM ? nslots : MAXJ); ++j) {
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
-                    if (near_clip & ((1u + sg) << (2 * j))) {
+                    if (STREAM || (near_clip & ((1u + sg) << (2 * j)))) {
                         double np_, nm_, ep_, em_, up_, um_;
                         counts_of(j, np_, nm_);
                         pe_of(j, ep_, em_); pu_of(j, up_, um_);
@@ -560,7 +605,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         // stalled iterations past convergence, where the projection's inexactness makes the direction an
         // ASCENT direction (new - old = alpha <update, gradient> > change > 0 for every alpha): there the
         // reference's rounded test is decided by the noise of its cost sums (it ends up halving 47-50 times
-        // per iteration, DESIGN.md 2.1), the rounded test on an exact difference would accept as soon as both
+        // per iteration, DESIGN.md 4.0-4.2), the rounded test on an exact difference would accept as soon as both
         // sides vanish against the cost (~11 halvings, a 3e-8 step along an ascent direction, every stalled
         // iteration), and the exact test rejects down to alpha < 1e-15 like the reference's late iterations:
         // the estimate then stays where the reference's stays, to rounding.  -DFBX_LS_ROUNDED restores the
@@ -574,7 +619,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 #pragma unroll
                 for (int k = 0; k < NS; ++k) Sk[k] = 0.0;
 #pragma unroll SLOT_UNROLL
-                for (int j = 0; j < MAXJ; ++j) {
+                for (int j = 0; j < (STREAM ? nslots : MAXJ); ++j) {
                     double np_, nm_, ep_, em_, up_, um_;
                     counts_of(j, np_, nm_);
                     pe_of(j, ep_, em_); pu_of(j, up_, um_);
@@ -763,5 +808,8 @@ struct PgdbLaunch {
 size_t pgdb_lean_lds(int maxj, int S);
 bool pgdb_lean_eligible(int S);      // the design's Bloch table fits beside Rb in the Jacobi work area
 int pgdb_lean_launch(int maxj, size_t lds, hipStream_t st, const PgdbLaunch& a);
+// the streamed instantiations (any number of settings; 1 or 2 qubits): LDS bytes and launch
+size_t pgdb_stream_lds(int nq, int S);
+int pgdb_stream_launch(int nq, size_t lds, hipStream_t st, const PgdbLaunch& a);
 
 }  // namespace fbx

@@ -24,9 +24,11 @@ pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                  long long* __restrict__ phase_out, cplx* __restrict__ basis_scratch, int basis_cap,
                  double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (MAXJ = 0, the streamed instantiation: the number of outcome slots per lane comes from the design)
+    const size_t slots = MAXJ > 0 ? (size_t)MAXJ : (size_t)((des.m + 63) / 64);
     pgdb_body<NQ, MAXJ, true>(smem, blockIdx.x, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
                               dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
-                              ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64, trace_out, trace_iters);
+                              ncounts + (size_t)blockIdx.x * 2 * slots * 64, trace_out, trace_iters);
 }
 
 // The same, in PIECES (launches of 2048 .. 32 768 reconstructions, i.e. 1 .. 16 per wave slot).  A launch of whole reconstructions
@@ -73,6 +75,22 @@ static int lean_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {
     hipLaunchKernelGGL((pgdb_lean_kernel<2, MAXJ>), dim3((unsigned)a.nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
                        a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters);
     return FBX_OK;
+}
+
+// Designs beyond the register-resident instantiations (2 qubits: more than 1024 settings; 1 qubit: more than 1024): the same
+// kernel with MAXJ = 0 -- outcome slots streamed from HBM / L2 (fbx_pgdb_body.hpp, STREAM), whole reconstructions.
+template <int NQ>
+static int stream_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {
+    FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<NQ, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((pgdb_lean_kernel<NQ, 0>), dim3((unsigned)a.nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
+                       a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters);
+    return FBX_OK;
+}
+size_t pgdb_stream_lds(int nq, int S) {
+    return ((nq == 1 ? PgdbLds<1, true>::bytes(S, 0) : PgdbLds<2, true>::bytes(S, 0)) + 15) & ~(size_t)15;
+}
+int pgdb_stream_launch(int nq, size_t lds, hipStream_t st, const PgdbLaunch& a) {
+    return nq == 1 ? stream_launch<1>(lds, st, a) : stream_launch<2>(lds, st, a);
 }
 
 size_t pgdb_lean_lds(int maxj, int S) { return (PgdbLds<2, true>::bytes(S, 64 * maxj) + 15) & ~(size_t)15; }

@@ -28,9 +28,13 @@ struct StateLds {
     JRec* rec;                     // [d/2 + 1]
     double *w, *r, *lam;           // [D], [D], [d]
     double *hs, *hd;               // [m] per-setting scratch
-    static size_t bytes(int m) {
+    __host__ __device__ static constexpr size_t bytes(int m) {
         return sizeof(cplx) * 6 * D + sizeof(JRec) * (d / 2 + 1) + sizeof(double) * (2 * D + d + 2 * (size_t)m) + 64;
     }
+    // The per-setting scratch (16 bytes per setting) is staged in LDS up to 64 KiB; a design beyond that -- a state-tomography
+    // dataset repeated or merged some 60 times over -- takes the streamed form of r_operator_elem, which needs none.
+    __host__ __device__ static constexpr bool staged(int m) { return bytes(m) <= 64 * 1024; }
+    __host__ __device__ static constexpr size_t launch_bytes(int m) { return bytes(staged(m) ? m : 0); }
     __device__ void carve(char* p, int m) {
         rho = (cplx*)p; p += sizeof(cplx) * D;  U = (cplx*)p; p += sizeof(cplx) * D;
         tmp = (cplx*)p; p += sizeof(cplx) * D;  aux = (cplx*)p; p += sizeof(cplx) * D;
@@ -110,6 +114,30 @@ __device__ cplx r_operator_elem(const DesignDev& des, const double* __restrict__
             const double gm = ((1.0 - mine->e) * 0.5) / ((1.0 - pe) * 0.5 + DBL_MIN);
             s0 = 0.5 * (gp + gm);
             atomicAdd(&L.w[mine->p], mine->cf * 0.5 * (gp - gm));
+        }
+        s0 = wave_sum(s0);
+        FBX_WAVE_SYNC();
+        if (lane < D) L.w[lane] = L.w[lane] / m;
+        FBX_WAVE_SYNC();
+        cplx out; out.re = 0.0; out.im = 0.0;
+        if (lane < D) out = pauli_synthesis<NQ>(L.w, s0 / m + 0.0, lane / d, lane % d);
+        return out;
+    }
+    if (!StateLds<NQ>::staged(m)) {
+        // Streamed (any number of settings; the reference loops over whatever list it is given, tomography.py:326-336): every lane
+        // walks its settings straight from HBM and adds their weights to w[p] with LDS atomics (one wavefront: the same order
+        // in every run) -- no per-setting scratch.
+        if (lane < D) L.w[lane] = 0.0;
+        FBX_WAVE_SYNC();
+        double s0 = 0.0;
+        for (int g = lane; g < m; g += 64) {
+            const int p = des.sp[g] & 0xffff;
+            const double cf = des.unit_coefs ? 1.0 : des.coef[g];
+            const double me = e[des.order[g]], pe = cf * L.r[p];
+            const double gp = ((1.0 + me) * 0.5) / ((1.0 + pe) * 0.5 + DBL_MIN);
+            const double gm = ((1.0 - me) * 0.5) / ((1.0 - pe) * 0.5 + DBL_MIN);
+            s0 += 0.5 * (gp + gm);
+            atomicAdd(&L.w[p], cf * 0.5 * (gp - gm));
         }
         s0 = wave_sum(s0);
         FBX_WAVE_SYNC();
@@ -212,7 +240,7 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
                  double* __restrict__ rho_out, int* __restrict__ iters_out, int* __restrict__ hit_out) {
     constexpr int d = 1 << NQ, D = d * d;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    StateLds<NQ> L; L.carve(smem, des.m);
+    StateLds<NQ> L; L.carve(smem, StateLds<NQ>::staged(des.m) ? des.m : 0);
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
     const double* e = expect + item * des.m;
@@ -368,7 +396,7 @@ r_operator_kernel(DesignDev des, long long B, const double* __restrict__ rho_in,
                   double* __restrict__ r_out) {
     constexpr int d = 1 << NQ, D = d * d;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    StateLds<NQ> L; L.carve(smem, des.m);
+    StateLds<NQ> L; L.carve(smem, StateLds<NQ>::staged(des.m) ? des.m : 0);
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
     if (lane < D) { L.rho[lane].re = rho_in[(item * D + lane) * 2]; L.rho[lane].im = rho_in[(item * D + lane) * 2 + 1]; }
@@ -1179,7 +1207,7 @@ struct HostIO {
     } while (0)
 
 size_t state_lds(int n, int m) {
-    return n == 1 ? StateLds<1>::bytes(m) : n == 2 ? StateLds<2>::bytes(m) : StateLds<3>::bytes(m);
+    return n == 1 ? StateLds<1>::launch_bytes(m) : n == 2 ? StateLds<2>::launch_bytes(m) : StateLds<3>::launch_bytes(m);
 }
 int check_state_design(const fbx_design* des, const char* who) {
     { const int rc = check_design(des, who); if (rc) return rc; }
@@ -1264,8 +1292,7 @@ int fbx_mle_state_dev(const fbx_design* design, int64_t B, const double* d_expec
     const int n = design->dev.n; const size_t m = design->dev.m, D = design->dev.D;
     if (n == 4) return launch_mle_big<4>(design, B, d_expect, d_counts, epsilon, entropy_penalty, beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
     if (n == 5) return launch_mle_big<5>(design, B, d_expect, d_counts, epsilon, entropy_penalty, beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
-    const size_t lds = state_lds(n, (int)m);
-    if (lds > 64 * 1024) { set_error("fbx_mle_state: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
+    const size_t lds = state_lds(n, (int)m);           // (designs beyond 64 KiB of per-setting staging take the streamed form: StateLds::staged)
     const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !FBX_MLE_UNPACKED;
     if (packed && n == 1)
         hipLaunchKernelGGL(mle_state_packed_kernel<1>, dim3((unsigned)((B + 15) / 16)), dim3(64), 0, stream(), design->dev,
@@ -1307,7 +1334,6 @@ int fbx_r_operator_dev(const fbx_design* design, int64_t B, const double* d_rho,
     const int n = design->dev.n;
     if (n >= 4) return state_big(0, design, B, d_rho, d_expect, nullptr, d_r_out);
     const size_t lds = state_lds(n, (int)design->dev.m);
-    if (lds > 64 * 1024) { set_error("fbx_r_operator: too many settings for LDS staging"); return FBX_ERR_UNSUPPORTED; }
     FBX_DISPATCH_NQ(n, r_operator_kernel, lds, B, design->dev, (long long)B, d_rho, d_expect, d_r_out);
     FBX_HIP(hipGetLastError());
     return FBX_OK;

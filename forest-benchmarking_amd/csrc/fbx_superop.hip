@@ -464,13 +464,15 @@ convert_big_kernel(int from, int to, long long B, const double* __restrict__ in,
 }
 
 template <int NQ>
-static int launch_convert_big(int from, int to, int64_t B, const double* in, int K, double* out) {
+static int convert_into_chi_big(int from, int64_t B, const double* in, double* out);
+
+// psd_choi: the caller vouches that the Choi matrix on the way into chi is positive semidefinite (|C| = C): the kernel's
+// linear basis change then IS choi2chi (it is what kraus -> chi runs)
+template <int NQ>
+static int launch_convert_big(int from, int to, int64_t B, const double* in, int K, double* out, bool psd_choi = false) {
     constexpr size_t d = (size_t)1 << NQ, D = d * d;
-    if (to == FBX_REP_CHI && from != FBX_REP_KRAUS) {
-        set_error("fbx_convert: conversions into chi from a Choi / superoperator / Pauli-Liouville matrix go through a "
-                  "D x D eigendecomposition (choi2kraus) and are offered for 1..3 qubits only");
-        return FBX_ERR_UNSUPPORTED;
-    }
+    if (to == FBX_REP_CHI && from != FBX_REP_KRAUS && !(psd_choi && from == FBX_REP_CHOI))
+        return convert_into_chi_big<NQ>(from, B, in, out);
     const size_t lds = sizeof(cplx) * (size_t)(K > 0 ? K : 1) * D;
     if (lds > 160 * 1024) { set_error("fbx_convert: too many Kraus operators for LDS staging"); return FBX_ERR_UNSUPPORTED; }
     auto kern = convert_big_kernel<NQ>;
@@ -486,6 +488,34 @@ static int launch_convert_big(int from, int to, int64_t B, const double* in, int
                            out + b0 * D * D * 2, (cplx*)w);
     }
     FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
+// Into chi from a Choi / superoperator / Pauli-Liouville matrix for 4 and 5 qubits (round 5).  The reference goes through
+// choi2kraus -> kraus2chi (superoperator_transformations.py:241-250, 291-298, 339-348): chi of |C| = sum |lambda_i| v_i v_i^H
+// over the eigenpairs with |lambda_i| > 1e-9.  Composed from the library's own primitives, everything resident: the walk to
+// the Choi matrix, fbx_eigh_dev (the HBM-resident Jacobi: 25 ms per 256 x 256 matrix, 0.8 s per 1024 x 1024), |lambda| with
+// the reference's cut, fbx_matmul_dev for V diag(|lambda|) V^H, and the kernel's linear basis change on that PSD matrix.
+__global__ void __launch_bounds__(256) abs_cut_kernel(double* __restrict__ w, long long n, double tol) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const double a = fabs(w[i]); w[i] = a > tol ? a : 0.0; }
+}
+template <int NQ>
+static int convert_into_chi_big(int from, int64_t B, const double* in, double* out) {
+    constexpr size_t D = (size_t)1 << (2 * NQ);
+    const int64_t chunk = (int64_t)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)256 << 20) / (D * D * sizeof(cplx))));
+    DevBuf c, v, w;
+    { int rc; if ((rc = c.alloc(D * D * sizeof(cplx) * chunk)) || (rc = v.alloc(D * D * sizeof(cplx) * chunk)) || (rc = w.alloc(D * sizeof(double) * chunk))) return rc; }
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        const double* choi = in + (size_t)b0 * D * D * 2;
+        if (from != FBX_REP_CHOI) { const int rc = launch_convert_big<NQ>(from, FBX_REP_CHOI, nb, choi, 0, c.as<double>()); if (rc) return rc; choi = c.as<double>(); }
+        { const int rc = fbx_eigh_dev((int)D, nb, choi, w.as<double>(), v.as<double>()); if (rc) return rc; }
+        hipLaunchKernelGGL(abs_cut_kernel, dim3((unsigned)((nb * D + 255) / 256)), dim3(256), 0, stream(), w.as<double>(), (long long)(nb * D), 1e-9);
+        FBX_HIP(hipGetLastError());
+        { const int rc = fbx_matmul_dev((int)D, nb, v.as<double>(), 0, w.as<double>(), v.as<double>(), 1, c.as<double>()); if (rc) return rc; }
+        { const int rc = launch_convert_big<NQ>(FBX_REP_CHOI, FBX_REP_CHI, nb, c.as<double>(), 0, out + (size_t)b0 * D * D * 2, true); if (rc) return rc; }
+    }
     return FBX_OK;
 }
 
@@ -1782,11 +1812,24 @@ int fbx_convert_dev(int from_rep, int to_rep, int n_qubits, int64_t B, const dou
     FBX_TRY(convert_check(from_rep, to_rep, n_qubits, B, d_in, K, d_out));
     FBX_TRY(ensure_device());
     if (B == 0) return FBX_OK;
-    if (n_qubits == 5) return launch_convert_big<5>(from_rep, to_rep, B, d_in, K, d_out);
-    if (n_qubits == 4) return launch_convert_big<4>(from_rep, to_rep, B, d_in, K, d_out);
-    if (n_qubits == 3) return launch_convert3(from_rep, to_rep, B, d_in, K, d_out);
-    if (n_qubits == 1) return launch_convert<1>(from_rep, to_rep, B, d_in, K, d_out);
-    return launch_convert<2>(from_rep, to_rep, B, d_in, K, d_out);
+    auto dispatch = [&](int from, int to, const double* in, int k, double* out, bool psd) -> int {
+        if (n_qubits == 5) return launch_convert_big<5>(from, to, B, in, k, out, psd);
+        if (n_qubits == 4) return launch_convert_big<4>(from, to, B, in, k, out, psd);
+        if (n_qubits == 3) return launch_convert3(from, to, B, in, k, out);
+        if (n_qubits == 1) return launch_convert<1>(from, to, B, in, k, out);
+        return launch_convert<2>(from, to, B, in, k, out);
+    };
+    const int rc = dispatch(from_rep, to_rep, d_in, K, d_out, false);
+    if (rc != FBX_ERR_UNSUPPORTED || from_rep != FBX_REP_KRAUS) return rc;
+    // More Kraus operators than the fused kernels stage in LDS (K x D x 16 B against 160 KiB: 40 operators for 4 qubits, 10 for
+    // 5): the Choi matrix from the basis-free kernel, which takes any K (one thread per entry, operators read through L2),
+    // then on from there -- the Choi matrix of a Kraus set is PSD, so the way into chi is the linear one.
+    const size_t D = (size_t)1 << (2 * n_qubits);
+    if (to_rep == FBX_REP_CHOI) return fbx_convert_general_dev(FBX_REP_KRAUS, FBX_REP_CHOI, 1 << n_qubits, B, d_in, K, d_out);
+    DevBuf choi;
+    FBX_TRY(choi.alloc(D * D * sizeof(cplx) * (size_t)B));
+    FBX_TRY(fbx_convert_general_dev(FBX_REP_KRAUS, FBX_REP_CHOI, 1 << n_qubits, B, d_in, K, choi.as<double>()));
+    return dispatch(FBX_REP_CHOI, to_rep, choi.as<double>(), 0, d_out, true);
 }
 
 static int convert_general_check(int from_rep, int to_rep, int dim, int64_t B, const void* in, int K, const void* out) {

@@ -91,13 +91,7 @@ def _kraus_stack(kraus_ops):
 
 
 def _one(src, dst, x):
-    x = np.asarray(x)
-    if dst == "chi" and src != "kraus" and x.shape[-1] > 64:
-        # 4 and 5 qubits: the reference's own route (superoperator_transformations.py:195-204,339-348), step by step --
-        # Choi matrix, its Kraus operators through the HBM-resident eigensolver, kraus2chi
-        choi = x if src == "choi" else convert_batch(src, "choi", x[None])[0]
-        return kraus2chi(choi2kraus(choi))
-    return convert_batch(src, dst, x[None])[0]
+    return convert_batch(src, dst, np.asarray(x)[None])[0]
 
 
 def kraus2chi(kraus_ops):

@@ -63,7 +63,7 @@ extern "C" {
  * series in alpha) and tests that.  The two agree wherever the comparison is not decided by the rounding of the cost sums,
  * i.e. in every iteration up to the reference's own stopping point (tests hold the halving counts equal there); past it
  * (FBX_MODE_FIXED beyond convergence) the reference performs a rounding-driven walk that no other summation order
- * reproduces, and this flag yields ANOTHER such walk, not the reference's (DESIGN.md 3).  Slower: ~50 full cost
+ * reproduces, and this flag yields ANOTHER such walk, not the reference's (DESIGN.md 6).  Slower: ~50 full cost
  * evaluations per stalled iteration.  Ignored for 3 qubits, whose kernel always evaluates this way. */
 #define FBX_MODE_LS_REFERENCE 0x100
 
@@ -109,7 +109,7 @@ int         fbx_release_workspace(void);            /* free the calling thread's
  *   off-diagonal norm of <value> x the previous outer step (relative to ||H||_F) instead of always at 1e-13 --
  *   an inexact projection whose error is that fraction of the distance the estimate still moves per iteration.
  *   0 reproduces the reference's eigh-to-machine-precision trajectory iteration by iteration (tests use it);
- *   the defaults leave the converged estimates within 1e-9 of the reference's (DESIGN.md 2.1, 2.2).  Range [0, 1e-3].
+ *   the defaults leave the converged estimates within 1e-9 of the reference's (DESIGN.md 4.0, 4.4).  Range [0, 1e-3].
  *   "pgdb_host_chunk" (default 4096): items of the first and of the last stage of the pipelined host-pointer form of
  *   fbx_pgdb_process (see fbx_host_alloc); the bulk in between goes in one launch per 65 536 items.
  *   "eigh_cooperative" (default 1): fbx_eigh of a few matrices with N >= 128 spreads each matrix over the whole chip with a
@@ -279,7 +279,10 @@ int fbx_state_log_likelihood_dev(const fbx_design* design, int64_t B, const doub
  * are only defined up to phase, superoperator_transformations.py:325-336).  n_qubits 1..5; for
  * 4 and 5 qubits (256^2 / 1024^2 matrices, work matrices in HBM) the conversions INTO chi from a Choi /
  * superoperator / Pauli-Liouville matrix -- which the reference routes through a D x D eigendecomposition
- * (choi2kraus) -- return FBX_ERR_UNSUPPORTED; kraus -> chi and everything else is there. */
+ * (choi2kraus: chi of |C|, eigenvalues within 1e-9 dropped) -- are composed from fbx_eigh_dev, fbx_matmul_dev and the
+ * linear basis change (25 ms per 256 x 256 item, ~1 s per 1024 x 1024 item: complete, not fast).  Kraus sets with more
+ * operators than the fused kernels stage in LDS (K x D x 16 B against 160 KiB) go through the basis-free kernel
+ * (fbx_convert_general: any K) to the Choi matrix and on from there. */
 int fbx_convert(int from_rep, int to_rep, int n_qubits, int64_t B, const double* in, int K,
                 double* out);
 /* same with device pointers (buffers from fbx_malloc): the batch stays resident in HBM */

@@ -1,4 +1,4 @@
-"""Round-1 anomaly hunt: the diagnostics build (libfbx_prof.so: phase timers) once produced, on 3 of
+"""Round-1 anomaly hunt (docs/history/DESIGN_rounds1-4.md 5.7): the diagnostics build (libfbx_prof.so: phase timers) once produced, on 3 of
 11 boxes and only in the FIRST launch of a process, reconstructions with far too many Dykstra iterations.  This runs
 the first launch of a fresh process with each library and compares every counter and the Choi matrices.
 usage: python scripts/anomaly_check.py   (prints one line per library; exit code 1 on a mismatch)"""

@@ -452,6 +452,62 @@ def make_fixed_spread(n, basis, seeds=(1, 2, 3), workers=8):
           f"converge max {conv.max():.2e}")
 
 
+# Round 5: MERGED / REPEATED datasets.  The reference loops over whatever result list it is handed (tomography.py:494-539,
+# :273-338): the same design measured several times -- here with different shot counts per repetition -- is one experiment of
+# reps x m settings.  These lists exceed the register- / LDS-resident sizes of the kernels (2 qubits: 1024 settings, 1 qubit:
+# 256, state designs: 64 KiB of per-setting staging) and exercise their streamed forms.
+def _repeated(exact, reps, shots, first_item):
+    es, cs = [], []
+    for r in range(reps):
+        e, c = synthetic.sample_expectations(exact, shots[r % len(shots)], first_item, seed_base=2000 + 1000 * r)
+        es.append(e); cs.append(c)
+    return np.concatenate(es, axis=1), np.concatenate(cs, axis=1)
+
+
+def make_repeated():
+    out = {}
+    shots = (1000, 500, 2000)
+    for tag, n, basis, reps, batch in (("p2pauli", 2, "pauli", 3, 3), ("p2sic", 2, "sic", 5, 2), ("p1pauli", 1, "pauli", 15, 3)):
+        qubits = list(range(n))
+        design = synthetic.process_design(n, basis)
+        us = np.array([synthetic.haar_unitary(design.dim, np.random.RandomState(1000 + b)) for b in range(batch)])
+        e, c = _repeated(synthetic.exact_process_expectations(design, us), reps, shots, 0)
+        settings = process_settings(qubits, basis) * reps
+        pg, lv, tni = [], [], []
+        for b in range(batch):
+            res = ref_results(settings, e[b], c[b])
+            pg.append(T.pgdb_process_estimate(res, qubits))
+            lv.append(T.linear_inv_process_estimate(res, qubits))
+            if b == 0:
+                tni.append(T.pgdb_process_estimate(res, qubits, trace_preserving=False))
+        out.update({f"{tag}_in_labels": np.tile(design.in_labels, (reps, 1)), f"{tag}_paulis": np.tile(design.paulis, (reps, 1)),
+                    f"{tag}_e": e, f"{tag}_c": c, f"{tag}_u": us, f"{tag}_pgdb": np.array(pg), f"{tag}_linv": np.array(lv),
+                    f"{tag}_pgdb_tni": np.array(tni)})
+        print("repeated", tag, e.shape, flush=True)
+    for tag, n, reps, batch in (("s2", 2, 280, 2), ("s1", 1, 1400, 2)):
+        qubits = list(range(n))
+        design, rhos, _, _ = synthetic.state_batch(n, batch, mixed=0.1)
+        e, c = _repeated(synthetic.exact_state_expectations(design, rhos), reps, shots, 0)
+        settings = list(T._state_tomo_settings(qubits)) * reps
+        mle, lv, ll, rop, hed = [], [], [], [], []
+        for b in range(batch):
+            res = ref_results(settings, e[b], c[b])
+            lv.append(T.linear_inv_state_estimate(res, qubits))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m = T.iterative_mle_state_estimate(res, qubits, maxiter=40)
+                hed.append(T.iterative_mle_state_estimate(res, qubits, beta=0.5, epsilon=1e-4, maxiter=12))
+            mle.append(m)
+            ll.append(T.state_log_likelihood(m, res, qubits))
+            rop.append(T._R(m, res, qubits[::-1]))
+        out.update({f"{tag}_paulis": np.tile(design.paulis, (reps, 1)), f"{tag}_e": e, f"{tag}_c": c, f"{tag}_truth": rhos,
+                    f"{tag}_mle40": np.array(mle), f"{tag}_hedged12": np.array(hed), f"{tag}_linv": np.array(lv),
+                    f"{tag}_loglik": np.array(ll), f"{tag}_r_op": np.array(rop)})
+        print("repeated", tag, e.shape, flush=True)
+    np.savez_compressed(os.path.join(HERE, "repeated.npz"), **out)
+    print("repeated done")
+
+
 def make_sweep_3q(batch=6):
     """The 3-qubit leg of BASELINE configs[2]'s pipeline for `batch` random CPTP Kraus sets (K = 4, 8 x 8 operators): what the
     reference's kraus2choi / kraus2pauli_liouville / kraus2chi / choi2chi / process_fidelity return (round 4: the fused
@@ -478,6 +534,9 @@ if __name__ == "__main__":
     np.random.seed(0)
     if "--sweep3q" in sys.argv:
         make_sweep_3q()
+        sys.exit(0)
+    if "--repeated" in sys.argv:          # round 5: merged / repeated datasets beyond the kernels' resident sizes (a few minutes)
+        make_repeated()
         sys.exit(0)
     if "--fixed-spread" in sys.argv:      # round 5: the reference against its own re-ordered self (about a minute on 8 cores)
         make_fixed_spread(2, "pauli")

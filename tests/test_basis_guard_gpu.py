@@ -1,4 +1,4 @@
-"""The stored-basis guard of the PGDB kernels: a test-only build of the library
+"""The stored-basis guard of the PGDB kernels (docs/history/DESIGN_rounds1-4.md 5.7): a test-only build of the library
 (libfbx_cor.so: -DFBX_DBG_CORRUPT_BASIS -DFBX_DEBUG_REJECT -DFBX_DIAGNOSTICS) damages every eigenvector basis that is loaded
 from the HBM store for Dykstra iteration 1.  The damaged bases must be rejected by the Frobenius-norm test
 in front of the eigensolver, and the reconstruction must come out as with the product library."""

@@ -16,7 +16,11 @@ pytestmark = pytest.mark.gpu
 
 def _random_choi(n, B, K, seed):
     from fbx.operator_tools import random_operators as ro, convert_batch
-    ks = np.ascontiguousarray(ro.random_kraus_batch(2 ** n, K, B, seed=seed))      # [B, K, d, d] CPTP sets, generated on the device
+    if n <= 3:
+        ks = np.ascontiguousarray(ro.random_kraus_batch(2 ** n, K, B, seed=seed))      # [B, K, d, d] CPTP sets, generated on the device
+    else:
+        from fbx import synthetic
+        ks = np.ascontiguousarray(synthetic.kraus_batch(n, K, B, seed=seed))
     return ks, convert_batch("kraus", "choi", ks)
 
 
@@ -31,8 +35,8 @@ def test_choi2kraus_batch_round_trip_counts_and_order(gpu, n, B, K):
     assert (counts == K).all()                                         # rank K: the other D - K eigenvalues are below 1e-9
     for b in range(B):
         assert not kraus[b, counts[b]:].any()                          # unused slots are zero
-    # kraus2choi(choi2kraus(C)) = C -- on the device, all D slots (the zero operators add nothing)
-    back = convert_batch("kraus", "choi", kraus)
+    # kraus2choi(choi2kraus(C)) = C -- on the device, the kept slots
+    back = convert_batch("kraus", "choi", np.ascontiguousarray(kraus[:, :max(1, int(counts.max()))]))
     assert np.abs(back - choi).max() < 1e-12 * D
     # the reference's list: ascending eigenvalues, operator norms = the eigenvalues
     for b in range(0, B, max(1, B // 7)):

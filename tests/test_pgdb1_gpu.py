@@ -63,7 +63,7 @@ def test_oracle_parity_with_equal_counts(gpu, basis):
     for b in range(B):
         assert (st["iterations"][b], st["dykstra"][b]) == (wst[b]["iterations"], wst[b]["dykstra"])
         # per-iteration equality with the oracle: Dykstra iterations everywhere, halvings in every iteration before the last
-        # (small steps are tested on the exact cost difference, DESIGN.md 2.1: only the final, stalled iteration may differ)
+        # (small steps are tested on the exact cost difference, DESIGN.md 4.0-4.2: only the final, stalled iteration may differ)
         k = int(st["iterations"][b])
         wtr = np.array(wst[b]["trace"])
         assert np.array_equal(st["trace"][b, :k, 0], wtr[:, 0])

@@ -71,7 +71,7 @@ def test_pgdb_fixed_100_matches_oracle(gpu, n, basis):
     # The fixed mode keeps iterating past convergence (an extension: the reference stops there).  Those
     # iterations are *stalled*: the inexact Dykstra projection gives an ASCENT direction, the reference halves the
     # step until the rounding noise of its cost sums lets a step pass (3e-8, 4e-9, ... then < 1e-11), the kernel
-    # -- which knows the cost difference exactly -- rejects every step down to alpha < 1e-15 (DESIGN.md 2.1).  The
+    # -- which knows the cost difference exactly -- rejects every step down to alpha < 1e-15 (DESIGN.md 4.0-4.2).  The
     # two estimates differ by the reference's first few noise-accepted steps: <= 1.1e-7 over 256 bench items
     # (scripts/parity_survey.py), against <= 3e-9 between two summation orders of the reference itself.
     # Outer-iteration and Dykstra counts agree exactly, in EVERY iteration; halvings in every iteration before the
@@ -255,7 +255,7 @@ def test_config5_whole_batch_on_one_gpu(gpu):
 @pytest.mark.parametrize("basis", ["pauli", "sic"])
 def test_lean_two_waves_per_simd_kernel_agrees_with_the_one_wave_kernel(gpu, basis):
     """Batches of > 1024 two-qubit reconstructions (2048 here) run pgdb_lean_kernel (16.5 KB of LDS, <= 256 registers, two
-    wavefronts per SIMD; DESIGN.md 2.1).  Since round 3 it carries Dykstra's state as two matrices + an 8-number
+    wavefronts per SIMD; DESIGN.md 4.0-4.2).  Since round 3 it carries Dykstra's state as two matrices + an 8-number
     summary instead of four matrices (fbx_choi.hpp proj_physical_blk_compact: same projections and stopping rule, the
     stopping functional assembled from algebraically equal terms), so its trajectory equals the one-wave kernel's to
     rounding, not bit for bit: every COUNT must be equal, the estimates within 1e-10 (the kernels agree with the
@@ -323,7 +323,7 @@ def test_two_waves_kernel_in_pieces_is_bit_identical_to_whole_reconstructions(gp
 
 
 def test_survey_outliers_stay_within_the_reference_own_spread(gpu):
-    """The four items of the 704-item survey (DESIGN.md 2.1) beyond 1e-9 in converge mode: the kernel must keep the
+    """The four items of the 704-item survey (DESIGN.md 4.0-4.2) beyond 1e-9 in converge mode: the kernel must keep the
     oracle's outer-iteration and Dykstra counts and stay within twice the distance the oracle itself moves when the
     same experiment is presented with its settings in another order (the reference's reproducibility on that item;
     tests/test_oracle_goldens.py::test_survey_outliers_are_rounding_defined_in_the_reference_too)."""

@@ -327,12 +327,21 @@ def test_four_qubit_conversions_match_the_oracle(gpu):
                 got = st.convert_batch(src, dst, reps[src])
                 assert np.abs(got - reps[dst]).max() < 1e-11, (src, dst)
     assert np.abs(reps["pauli_liouville"].imag).max() < 1e-12                            # a PTM is real
-    for src in ("choi", "superop", "pauli_liouville"):                                   # routed through eigh in the reference:
-        with pytest.raises(Exception):                                                   # not in the batched kernel ...
-            st.convert_batch(src, "chi", reps[src])
-    # ... but the reference-named functions take the reference's route (choi2kraus on the 256 x 256 eigensolver)
+    # into chi from a Choi / superoperator / Pauli-Liouville matrix: the reference goes through choi2kraus (a 256 x 256
+    # eigendecomposition); batched since round 5 (fbx_eigh_dev + V |lambda| V^H + the linear basis change, all resident)
+    for src in ("choi", "superop", "pauli_liouville"):
+        got = st.convert_batch(src, "chi", reps[src])
+        assert np.abs(got - reps["chi"]).max() < 1e-9, (src, "chi")
     assert np.abs(st.choi2chi(reps["choi"][0]) - reps["chi"][0]).max() < 1e-9
     assert np.abs(st.pauli_liouville2chi(reps["pauli_liouville"][1]) - reps["chi"][1]).max() < 1e-9
+    # a Hermitian, NON-CP "Choi" matrix: the reference's quirk (chi of |C|, eigenvalues within 1e-9 dropped) -- against the oracle
+    h = rs.randn(256, 256) + 1j * rs.randn(256, 256)
+    h = (h + h.conj().T) / 32
+    assert np.abs(st.convert_batch("choi", "chi", h[None])[0] - so.choi2chi(h)).max() < 1e-9
+    # more Kraus operators than the fused kernel stages in LDS (40 for 4 qubits): the basis-free kernel takes over
+    many = (rs.randn(1, 50, 16, 16) + 1j * rs.randn(1, 50, 16, 16)) / 30
+    for dst, f in (("choi", so.kraus2choi), ("pauli_liouville", so.kraus2pauli_liouville), ("chi", so.kraus2chi)):
+        assert np.abs(st.convert_batch("kraus", dst, many)[0] - f(list(many[0]))).max() < 1e-10, ("50 operators", dst)
 
 
 def test_five_qubit_conversions(gpu):
