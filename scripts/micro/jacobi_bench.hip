@@ -4,6 +4,12 @@
 #ifdef FBX_JACOBI_CHAIN_FIRST
 #include "jacobi_chain_first.hpp"      // round-3 experiment (measured, not adopted)
 #endif
+#ifdef FBX_JACOBI_ALLREG
+#include "jacobi_allreg.hpp"           // round-5 experiment: matrix AND eigenvector blocks in registers, exchange through DPP + ds_bpermute
+#endif
+#ifdef FBX_JACOBI_VDPP
+#include "jacobi_vdpp.hpp"             // round-5 experiment: eigenvector exchange through DPP instead of LDS
+#endif
 #ifdef FBX_JACOBI_REGPIVOT
 #include "jacobi_regpivot.hpp"         // round-5 experiment: next-round pivots through registers (measured, not adopted)
 #endif
@@ -33,6 +39,10 @@ __global__ void __launch_bounds__(64) k_eigh(const double* A, double* W, double*
         sweeps += jacobi_eigh_wave_chain_first<N>(M, V, lane, true);
 #elif defined(FBX_JACOBI_REGPIVOT)
         sweeps += jacobi_eigh_wave_regpivot<N>(M, V, lane, true);
+#elif defined(FBX_JACOBI_ALLREG)
+        sweeps += jacobi_eigh_wave_allreg<N>(M, V, lane, true);
+#elif defined(FBX_JACOBI_VDPP)
+        sweeps += jacobi_eigh_wave_vdpp<N>(M, V, lane, true);
 #else
         sweeps += jacobi_eigh_lds<N>(M, V, rot, lane);
 #endif

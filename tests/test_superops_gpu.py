@@ -293,6 +293,15 @@ def test_full_size_sweep_properties(gpu):
         sample = np.r_[0, 1, 4095, 4096, 123457, B - 2, B - 1]
         want = convert_batch("kraus", name, ks[sample])
         assert np.abs(out[sample] - want).max() < 1e-13, name
+        # ... and the ORACLE (the reference's functions restated, pinned to the reference in tests/test_oracle_vs_reference.py)
+        # on the same sample: the fused kernel itself against the reference's arithmetic, not against another kernel
+        from fbx_oracle import superops as so
+        f = {"choi": so.kraus2choi, "pauli_liouville": so.kraus2pauli_liouville, "chi": so.kraus2chi}[name]
+        for k, b in enumerate(sample):
+            assert np.abs(out[b] - f(list(ks[b]))).max() < 1e-13, (name, b)
+            if name == "pauli_liouville":
+                from fbx_oracle import measures as om
+                assert abs(fid[b] - om.process_fidelity(ref[0], out[b])) < 1e-13
         tr = np.trace(out[::997], axis1=1, axis2=2)
         if name == "choi":
             assert np.abs(tr - 4).max() < 1e-12
