@@ -21,8 +21,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #                      540-setting instantiation is larger than the 64 KB instruction cache eight wavefronts share) and no machine
 #                      LICM: loop-invariant per-lane addresses and masks hoisted out of the outer loop were what still spilled
 #                      (70 -> 38 spilled registers, 62.0 -> 61.5 ms per 8192 reconstructions).
+#   fbx_pgdb.hip       also -DFBX_JACOBI_TWO_WORKERS: the 16 x 16 Jacobi with two workers per upper block (csrc/fbx_eigh.hpp): B = 1024
+#                      12.38 -> 12.10 ms, to convergence 10.25 -> 9.75 ms; the two-waves kernel is 5 % SLOWER with it (spills) and keeps
+#                      the full-block form, as does every other unit.
 _MAX_ILP = "-mllvm -amdgpu-sched-strategy=max-ilp"
-FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", _MAX_ILP).split(),
+FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", _MAX_ILP + " -DFBX_JACOBI_TWO_WORKERS").split(),
               "fbx_pgdb3.hip": os.environ.get("FBX_PGDB3_FLAGS", _MAX_ILP).split(),
               "fbx_pgdb_lean.hip": os.environ.get("FBX_PGDB_LEAN_FLAGS", "-Os -mllvm -disable-machine-licm").split()}
 

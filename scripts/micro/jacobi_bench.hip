@@ -4,6 +4,9 @@
 #ifdef FBX_JACOBI_CHAIN_FIRST
 #include "jacobi_chain_first.hpp"      // round-3 experiment (measured, not adopted)
 #endif
+#ifdef FBX_JACOBI_H2
+#include "jacobi_h2.hpp"               // round-5 experiment: Hermitian symmetry with two workers per upper block
+#endif
 #ifdef FBX_JACOBI_ALLREG
 #include "jacobi_allreg.hpp"           // round-5 experiment: matrix AND eigenvector blocks in registers, exchange through DPP + ds_bpermute
 #endif
@@ -39,6 +42,8 @@ __global__ void __launch_bounds__(64) k_eigh(const double* A, double* W, double*
         sweeps += jacobi_eigh_wave_chain_first<N>(M, V, lane, true);
 #elif defined(FBX_JACOBI_REGPIVOT)
         sweeps += jacobi_eigh_wave_regpivot<N>(M, V, lane, true);
+#elif defined(FBX_JACOBI_H2)
+        sweeps += jacobi_eigh_wave_h2<N>(M, V, lane, true);
 #elif defined(FBX_JACOBI_ALLREG)
         sweeps += jacobi_eigh_wave_allreg<N>(M, V, lane, true);
 #elif defined(FBX_JACOBI_VDPP)
