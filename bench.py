@@ -154,7 +154,7 @@ def _measured_flop(kernel, items):
 
 
 # ================================================================================== flop accounting
-def pgdb2q_executed_flop(m, S, iters, dyk, backtracks, work):
+def pgdb2q_executed_flop(m, S, iters, dyk, backtracks, work, two_workers=False):
     """Floating-point operations the 2-qubit kernel EXECUTES for one reconstruction (mean over the
     batch), counted from the source (csrc/fbx_pgdb.hip, fbx_choi.hpp, fbx_eigh.hpp; fma = 2, DESIGN.md
     2.1) and the per-item work counters the kernel returns.  Kronecker formulation: the dense design
@@ -163,7 +163,9 @@ def pgdb2q_executed_flop(m, S, iters, dyk, backtracks, work):
     sweeps, terms, cost_evals, sum_passes = (float(np.mean(work[:, k])) for k in range(4))
     it, dy, bt = float(np.mean(iters)), float(np.mean(dyk)), float(np.mean(backtracks))
     f = {}
-    f["jacobi_sweeps"] = sweeps * 15 * lanes * 162                 # rotation 42 + 2x2 block update 80 + eigenvector update 40 per lane and round
+    # rotation 42 + 2x2 block update 80 + eigenvector update 40 per lane and round; the one-wave kernels (B <= 1024) update the
+    # Hermitian work matrix with two workers per upper block since round 5 (csrc/fbx_eigh.hpp): half a block update per lane
+    f["jacobi_sweeps"] = sweeps * 15 * lanes * (122 if two_workers else 162)
     f["jacobi_offnorm_tests"] = (sweeps + dy) * lanes * 20
     f["basis_change_mfma"] = max(dy - np.ceil(it / 16.0), 0.0) * 32 * 2 * 16 * 16 * 4   # 32 v_mfma_f64_16x16x4 per warm decomposition
     f["reconstruct"] = terms * lanes * 28                          # V diag(lam+) V^H, one rank-1 term per kept eigenvalue
@@ -588,7 +590,7 @@ def pgdb_roofline(batch, st, kernel_s, iters):
     kernel never performs and exceeds the peak at large batches, so it is not a utilisation figure."""
     B, m, S = batch.B, batch.design.m, batch.design.n_states
     dense = B * ALGO_FLOP_PER_RECON * (iters / 100.0) / kernel_s / 1e12
-    ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"])
+    ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"], two_workers=B <= 1024)
     algo_bytes = 2 * m * 8 + 4096
     kernel = ("pgdb_lean_pieces_kernel" if B > 1024 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
     measured = _measured_flop(kernel, B)

@@ -345,7 +345,11 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
                                    double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(N == 16 && LS == 64, "every lane of the wavefront owns one eigenvector block");
+    #ifdef FBX_JACOBI_LOCAL_CONSTANTS      // (experiment for the register-capped kernels: the per-lane constants below recomputed per call, not hoisted)
+    lane = opaque(lane);
+#else
     lane = FBX_LOCAL(lane);
+#endif
     const int Ir = lane / NB, Jc = lane % NB;
     const int me = lane;
     const bool diag = Ir == Jc, wb = Ir > Jc;                  // wb: second worker of the upper block (Jc, Ir)
