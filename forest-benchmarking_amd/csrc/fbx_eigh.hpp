@@ -340,6 +340,10 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 // max-ILP scheduling of fbx_pgdb.hip, 1429 -> 1396 at two with the default scheduling of fbx_pgdb_lean.hip.  In the kernels (same-box
 // A/B): B = 1024 fixed-100 12.38 -> 12.10 ms, to convergence 10.25 -> 9.75 ms -- and 8192 items on the register-capped two-waves
 // kernel 51.2 -> 53.7 ms (its dozen extra per-lane constants are spilled), which is why only fbx_pgdb.hip uses it.
+// (Measured and dropped: an annealed slot assignment for the entries between rounds -- scripts/micro/h2_layout_anneal.py: 21 / 25
+// LDS-array cycles per round for the two stores / four loads instead of the 60 / 45 the mirrored seats cost in the plane layout built
+// for full blocks, i.e. the 49.8 % bank conflicts of profiles/r05 gone -- changes nothing in isolation (940 vs 941 cycles per round:
+// the conflicts are not on the dependent chain) and costs the kernel its table look-ups: B = 1024 fixed-100 12.17 -> 12.52 ms.)
 template <int N>
 __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
                                    double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
