@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -185,3 +186,28 @@ def test_shard_bounds_cover_the_batch_exactly():
             assert blocks[0][0] == 0 and blocks[-1][1] == n
             assert all(b[1] == nb[0] for b, nb in zip(blocks, blocks[1:]))
             assert max(hi - lo for lo, hi in blocks) == -(-n // world)
+
+
+def test_file_rendezvous_reports_a_persistent_file_system_error_at_the_deadline(tmp_path, monkeypatch):
+    """Round-5 advisor finding: an OSError from the join / ack files (ENOSPC, EACCES, a stale NFS handle) sent a rank back to
+    re-read ``gen`` without looking at the clock -- 100 % CPU for ever.  Now the loop backs off and re-raises the error once the
+    deadline has passed."""
+    import time
+    from fbx import parallel
+    d = str(tmp_path / "rdzv")
+    os.makedirs(d, mode=0o700)
+    with open(os.path.join(d, "gen"), "w") as f:             # a generation somebody opened: rank 1 will try to join it
+        f.write("deadbeef")
+    calls = {"n": 0}
+
+    def broken_publish(self, payload, tag):
+        calls["n"] += 1
+        raise OSError(28, "No space left on device")
+
+    monkeypatch.setattr(parallel.FileRendezvous, "_publish", broken_publish)
+    t0 = time.monotonic()
+    with pytest.raises(OSError) as err:
+        parallel.FileRendezvous(1, 2, directory=d, timeout=1.5, join_timeout=0.2)
+    dt = time.monotonic() - t0
+    assert err.value.errno == 28 and 1.0 < dt < 10.0
+    assert calls["n"] < 200                                   # backed off between attempts instead of spinning

@@ -88,3 +88,31 @@ def test_bad_device_lists_are_refused(device_list):
     with pytest.raises(ValueError):
         _lib.set_devices([])
     assert _lib.set_devices([0]) == (0,)
+
+
+def test_alternating_device_lists_reuse_their_workers(device_list):
+    """Round-5 advisor finding: a list change used to drop its surplus worker threads -- parked for ever with their streams,
+    staging pools and multi-GB workspaces.  Now workers that leave the list release their device memory and are kept in a pool
+    keyed by device; later lists reuse them.  Forty changes of the list must not grow the process's thread count, and results
+    stay bit-identical throughout."""
+    import os
+    from fbx import synthetic, tomography
+    _lib = device_list
+
+    def threads():
+        with open(f"/proc/{os.getpid()}/status") as f:
+            return int([ln for ln in f if ln.startswith("Threads:")][0].split()[1])
+
+    design, _, e, c = synthetic.process_batch(2, "sic", 40)
+    _lib.set_devices([0])
+    want = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=5)
+    for ids in ([0, 0, 0], [0], [0, 0]):                     # warm: the pool now holds three workers of device 0
+        assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=5, devices=ids), want)
+    before = threads()
+    for k in range(40):
+        ids = ([0], [0, 0], [0, 0, 0], [0, 0])[k % 4]
+        got = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=5, devices=ids)
+        assert np.array_equal(got, want), (k, ids)
+    assert threads() <= before, (before, threads())
+    _lib.release_workspace()                                  # fans out to the workers of the current list
+    assert np.array_equal(tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=5, devices=[0, 0]), want)

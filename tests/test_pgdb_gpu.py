@@ -404,3 +404,33 @@ def test_pipelined_host_entry_point_across_kernels(gpu):
         assert np.array_equal(got.reshape(100, 3, 64, 64), np.broadcast_to(want, (100, 3, 64, 64)))
     finally:
         gpu.set_option("pgdb_host_chunk", old)
+
+
+def test_long_fixed_runs_keep_their_pieces_short(gpu):
+    """Round-5 advisor finding: a consumer waits for its predecessor piece with a bounded spin, and a piece lasted
+    max_iters / pieces outer iterations whatever max_iters was.  The launcher now raises the number of pieces so that one stays at
+    <= 64 iterations (whole reconstructions beyond 512 per piece) and the bound scales with the piece length: 1500 fixed
+    iterations on the two-waves kernel complete, and equal whole reconstructions bit for bit."""
+    from fbx import synthetic, tomography
+    B = 1100
+    design, _, e, c = synthetic.process_batch(2, "sic", B)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in ("FBX_LEAN_PIECES", "FBX_LEAN_PIECE_ITERS")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            return tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=1500, return_stats=True)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+
+    got, st = run({})
+    whole, sw = run({"FBX_LEAN_PIECES": "1"})
+    assert (st["iterations"] == 1500).all()
+    assert np.array_equal(got, whole)
+    for k in ("dykstra", "backtracks"):
+        assert np.array_equal(st[k], sw[k]), k
