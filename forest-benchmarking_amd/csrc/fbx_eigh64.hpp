@@ -77,6 +77,25 @@ __device__ __forceinline__ int herm_store_pos(int r, int c, bool& conj) {
 namespace eigh64 {
 constexpr int N = 64, NB = 32, PS = sys_plane<N>(), NUP = NB * (NB - 1) / 2, NT = 1024;
 
+#ifdef FBX_EIGH64_PUBLISHED
+// PUBLISHED ROTATIONS (round 5).  The rotation of a pair is computed ONCE per round instead of by every thread that applies it
+// (496 x 2 + 512 evaluations of two reciprocal-square-root chains per round: 80 of the ~140 vector instructions of a
+// matrix-role thread, 40 of the ~175 of an eigenvector-role thread -- the round is bound by vector issue, four wavefronts per
+// SIMD).  No second barrier: the pivot of NEXT round's pair K' is made of two diagonal entries and one off-diagonal entry that
+// all exist in ONE matrix-role thread at the end of this round -- the tournament permutation (jacobi_seat) forms
+//   pair 0 = {top 0, bottom 1}, pair 1 = {bottom 0, bottom 2}, pair K = {top K-1, bottom K+1} (2 <= K <= 30), pair 31 = {top 30, top 31},
+// so the thread of block (0,1), (0,2), (K-1,K+1), (30,31) holds the updated entry b' in its registers and the rotated diagonals
+// a' (of its row pair) and d' (of its column pair) in the two records it has just applied.  That thread evaluates the next
+// rotation and publishes the record {c, s, a'', d''} in the buffer the round writes -- in seats of the LOWER block triangle,
+// which the upper-triangle storage leaves unused: block (31, K) for K < 31, block (30, 23) for K = 31 (its bank group completes
+// those of pairs 24..30), entries 0 / 1 / 2 = (c, Re s) / (Im s, a'') / (d'', -).  Everybody reads two records instead of two pivot
+// blocks.  Same inputs, same function: BIT-IDENTICAL to the locally computed rotations.
+__device__ __forceinline__ int rec_pos(int K, int e) {
+    const int R = K < NB - 1 ? NB - 1 : NB - 2, C = K < NB - 1 ? K : 23;
+    return e * PS + sys_pos<N>(R, C, e);
+}
+#endif
+
 // the loop nest both roles run: `test(o2, n2)` adds the role's share of the off-diagonal / total norm, `round(rd, wr)` is one
 // round reading the buffer described by the first address set and writing the one described by the second (barrier NOT included)
 template <int NR, int NW, class Test, class Round>
@@ -111,6 +130,148 @@ __device__ __forceinline__ double flip_sign(double x, unsigned mask) {
     return __hiloint2double(__double2hiint(x) ^ (int)mask, __double2loint(x));
 }
 
+#ifdef FBX_EIGH64_PUBLISHED
+__device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* red, double tol2) {
+    // rows i and 30 - i have 32 strictly-upper blocks between them: half-wavefront r = t / 32 takes those two rows (r < 15),
+    // the last one the 16 blocks of row 15 -- runs of consecutive column pairs, as the conflict-free layout wants them
+    const int r = t / NB, c = t % NB;
+    const bool mrole = r < 15 || c < 16;
+    const bool lower_row = c >= NB - 1 - r;                // the second row of the pair (r < 15 only)
+    const int Iu = mrole ? (lower_row ? 30 - r : r) : 0;
+    const int Ju = mrole ? (lower_row ? Iu + 1 + (c - (NB - 1 - r)) : r + 1 + c) : 1;
+    static_assert(NUP == 15 * NB + 16, "496 strictly-upper blocks");
+    // which of next round's pairs this block holds the pivot entry of (see the head of the namespace), and where in the block
+    const bool k_first = Iu == 0 && Ju == 1, k_second = Iu == 0 && Ju == 2, k_last = Iu == NB - 2 && Ju == NB - 1;
+    const bool owner = mrole && (k_first || k_second || k_last || (Ju == Iu + 2 && Iu >= 1));
+    const int Kn = k_first ? 0 : k_second ? 1 : k_last ? NB - 1 : Iu + 1;
+    // own block (planes b = 0 / 1), record of the row pair, record of the column pair (entries 0 / 1; entry 2 = entry 0 + 2 planes);
+    // the four seats and the record this thread publishes
+    int ra[6], wa[6];
+    unsigned sgm[4];                                        // sign bit to flip on the imaginary part of an entry stored mirrored
+    ra[0] = sys_pos<N>(Iu, Ju, 0); ra[1] = sys_pos<N>(Iu, Ju, 1);
+    ra[2] = rec_pos(Iu, 0); ra[3] = rec_pos(Iu, 1);
+    ra[4] = rec_pos(Ju, 0); ra[5] = rec_pos(Ju, 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        bool cj;
+        wa[e] = herm_store_pos(jacobi_seat<N>(2 * Iu + (e >> 1)), jacobi_seat<N>(2 * Ju + (e & 1)), cj);
+        sgm[e] = cj ? 0x80000000u : 0u;
+    }
+    wa[4] = rec_pos(Kn, 0); wa[5] = rec_pos(Kn, 1);
+    auto test = [&](const int (&rd)[6], double& o2, double& n2) __attribute__((always_inline)) {
+        if (mrole) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const cplx v = Ms[e * PS + rd[e & 1]];
+                o2 += 2.0 * (v.re * v.re + v.im * v.im);
+            }
+            n2 = o2;
+        }
+    };
+    auto round = [&](const int (&rd)[6], const int (&wr)[6]) __attribute__((always_inline)) {
+        if (mrole) {
+            const cplx i0 = Ms[rd[2]], i1 = Ms[rd[3]];      // (c, Re s), (Im s, a') of the row pair
+            const cplx j0 = Ms[rd[4]], j1 = Ms[rd[5]];      // ... of the column pair
+            cplx m00 = Ms[0 * PS + rd[0]], m01 = Ms[1 * PS + rd[1]];
+            cplx m10 = Ms[2 * PS + rd[0]], m11 = Ms[3 * PS + rd[1]];
+            jacobi_apply_m(i0.re, i0.im, i1.re, j0.re, j0.im, j1.re, m00, m01, m10, m11);
+            if (owner) {
+                const double dI = Ms[2 * PS + rd[2]].re, dJ = Ms[2 * PS + rd[4]].re;
+                const double a = k_second ? dI : i1.im;     // pair 1 takes the BOTTOM of pair 0
+                const double d = k_last ? j1.im : dJ;       // pair 31 takes the TOP of pair 31
+                const cplx b = k_second ? m11 : k_last ? m00 : m01;
+                const JRot n = jacobi_rotation(a, d, b.re, b.im);
+                cplx e0, e1, e2;
+                e0.re = n.c; e0.im = n.sr; e1.re = n.si; e1.im = n.an; e2.re = n.dn; e2.im = 0.0;
+                Ms[wr[4]] = e0; Ms[wr[5]] = e1; Ms[2 * PS + wr[4]] = e2;
+            }
+            m00.im = flip_sign(m00.im, sgm[0]); m01.im = flip_sign(m01.im, sgm[1]);
+            m10.im = flip_sign(m10.im, sgm[2]); m11.im = flip_sign(m11.im, sgm[3]);
+            Ms[wr[0]] = m00; Ms[wr[1]] = m01; Ms[wr[2]] = m10; Ms[wr[3]] = m11;
+        }
+    };
+    return sweeps<6, 6>(ra, wa, delta, red, tol2, test, round);
+}
+
+__device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv, bool init_identity, double* red, double tol2) {
+    const int I = tv / NB, J = tv % NB;
+    const bool first = J == 0, last = J == NB - 1;
+    const bool diag = I == (J & 15);                       // row pair I (J < 16) or I + 16 (J >= 16) is the column pair
+    // pivot block of the column pair (convergence test only), its record; seats of the rotated diagonal and of the annihilated entry
+    int ra[4], wa[3];
+    {
+        const int sa = jacobi_seat<N>(2 * J), sd = jacobi_seat<N>(2 * J + 1);
+        bool cj;
+        ra[0] = sys_pos<N>(J, J, 0); ra[1] = sys_pos<N>(J, J, 1);
+        ra[2] = rec_pos(J, 0); ra[3] = rec_pos(J, 1);
+        wa[0] = 3 * (sa & 1) * PS + sys_pos<N>(sa >> 1, sa >> 1, sa & 1);
+        wa[1] = 3 * (sd & 1) * PS + sys_pos<N>(sd >> 1, sd >> 1, sd & 1);
+        wa[2] = herm_store_pos(sa, sd, cj);
+    }
+    // eigenvector blocks in registers: rows 2I, 2I + 1 (block 0) and 2I + 32, 2I + 33 (block 1); columns = slots 2J (p), 2J + 1 (q)
+    cplx v0p[2], v0q[2], v1p[2], v1q[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int Ik = I + 16 * k;
+        if (init_identity) {
+            v0p[k].re = (Ik == J) ? 1.0 : 0.0; v0p[k].im = 0.0; v1q[k] = v0p[k];
+            v0q[k].re = 0.0; v0q[k].im = 0.0; v1p[k] = v0q[k];
+        } else {
+            v0p[k] = Vs[0 * PS + sys_pos<N>(Ik, J, 0)]; v0q[k] = Vs[1 * PS + sys_pos<N>(Ik, J, 1)];
+            v1p[k] = Vs[2 * PS + sys_pos<N>(Ik, J, 0)]; v1q[k] = Vs[3 * PS + sys_pos<N>(Ik, J, 1)];
+        }
+    }
+    // the records of the first round, from the pivots as they stand (visible behind the barriers of the first convergence test;
+    // the seats lie in the lower block triangle of Ms, which nobody reads)
+    if (diag) {
+        const double a0 = Ms[0 * PS + ra[0]].re, d0 = Ms[3 * PS + ra[1]].re;
+        const cplx b0 = Ms[1 * PS + ra[1]];
+        const JRot n = jacobi_rotation(a0, d0, b0.re, b0.im);
+        cplx e0, e1, e2;
+        e0.re = n.c; e0.im = n.sr; e1.re = n.si; e1.im = n.an; e2.re = n.dn; e2.im = 0.0;
+        Ms[ra[2]] = e0; Ms[ra[3]] = e1; Ms[2 * PS + ra[2]] = e2;
+    }
+    FBX_BLOCK_SYNC();                                       // Vs is the second matrix buffer from here on
+    double ev_a = 0.0, ev_d = 0.0;                          // (diag threads) the pair's diagonal at the last convergence test
+    auto test = [&](const int (&rd)[4], double& o2, double& n2) __attribute__((always_inline)) {
+        if (diag) {
+            ev_a = Ms[0 * PS + rd[0]].re; ev_d = Ms[3 * PS + rd[1]].re;
+            const cplx b = Ms[1 * PS + rd[1]];
+            o2 = 2.0 * (b.re * b.re + b.im * b.im);
+            n2 = o2 + ev_a * ev_a + ev_d * ev_d;
+        }
+    };
+    auto round = [&](const int (&rd)[4], const int (&wr)[3]) __attribute__((always_inline)) {
+        const cplx r0 = Ms[rd[2]], r1 = Ms[rd[3]];         // (c, Re s), (Im s, a')
+        if (diag) {
+            cplx a; a.re = r1.im; a.im = 0.0; cplx d; d.re = Ms[2 * PS + rd[2]].re; d.im = 0.0; cplx z; z.re = 0.0; z.im = 0.0;
+            Ms[wr[0]] = a; Ms[wr[1]] = d; Ms[wr[2]] = z;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            jacobi_apply_v(r0.re, r0.im, r1.re, v0p[k], v0q[k], v1p[k], v1q[k]);
+            seat_shift(v0p[k].re, v0q[k].re, first, last); seat_shift(v0p[k].im, v0q[k].im, first, last);
+            seat_shift(v1p[k].re, v1q[k].re, first, last); seat_shift(v1p[k].im, v1q[k].im, first, last);
+        }
+    };
+    const int sweep = sweeps<4, 3>(ra, wa, delta, red, tol2, test, round);
+    if (sweep == FBX_JACOBI_MAX_SWEEPS && diag) { ev_a = Ms[0 * PS + ra[0]].re; ev_d = Ms[3 * PS + ra[1]].re; }
+    FBX_BLOCK_SYNC();
+    // results where the callers expect them: the eigenvalues on the diagonal of Ms, the eigenvectors in Vs (both buffers are
+    // free: every thread's last read lies behind a barrier)
+    if (diag) {
+        cplx a; a.re = ev_a; a.im = 0.0; cplx d; d.re = ev_d; d.im = 0.0;
+        Ms[0 * PS + sys_pos<N>(J, J, 0)] = a; Ms[3 * PS + sys_pos<N>(J, J, 1)] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int Ik = I + 16 * k;
+        Vs[0 * PS + sys_pos<N>(Ik, J, 0)] = v0p[k]; Vs[1 * PS + sys_pos<N>(Ik, J, 1)] = v0q[k];
+        Vs[2 * PS + sys_pos<N>(Ik, J, 0)] = v1p[k]; Vs[3 * PS + sys_pos<N>(Ik, J, 1)] = v1q[k];
+    }
+    return sweep;
+}
+#else
 __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* red, double tol2) {
     // rows i and 30 - i have 32 strictly-upper blocks between them: half-wavefront r = t / 32 takes those two rows (r < 15),
     // the last one the 16 blocks of row 15 -- runs of consecutive column pairs, as the conflict-free layout wants them
@@ -228,6 +389,7 @@ __device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv
     }
     return sweep;
 }
+#endif
 }  // namespace eigh64
 
 template <int NT = 1024>

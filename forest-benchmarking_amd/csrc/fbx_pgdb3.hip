@@ -996,7 +996,12 @@ int pgdb3_dispatch(const fbx_design* des, int64_t B, const double* e, const doub
     mode &= 0xff;          // FBX_MODE_LS_REFERENCE: this kernel's line search always evaluates the full cost with the rounded test
     if (m <= 4096) return launch3<4>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
     if (m <= 14336) return launch3<14>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
-    set_error("fbx_pgdb_process: 3-qubit designs are limited to 14336 settings");
+    // Merged / repeated datasets (the reference takes any result list, tomography.py:494-539): the same kernel with 32 / 64 outcome
+    // slots per thread.  Their per-slot arrays no longer fit 128 registers and live in scratch: slow (a few times the resident
+    // instantiations per outer iteration outside the projection) and complete up to 65 536 settings.
+    if (m <= 32768) return launch3<32>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+    if (m <= 65536) return launch3<64>(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex);
+    set_error("fbx_pgdb_process: 3-qubit designs are limited to 65536 settings");
     return FBX_ERR_UNSUPPORTED;
 }
 

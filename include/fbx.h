@@ -205,7 +205,10 @@ int fbx_design_info(const fbx_design* design, int* n_qubits, int* kind, int* m,
  *   NULL): final negative log-likelihood; work_out[B][4] (may be NULL): work accounting --
  *   Jacobi sweeps of the eigensolver, eigenvalue terms rebuilt by the CP projections, cost
  *   evaluations over all outcomes, power-sum reductions of the small-step line search
- *   (bench.py derives the executed flops from these counters). */
+ *   (bench.py derives the executed flops from these counters).
+ * Design sizes: 1 and 2 qubits any number of settings (above 256 / 1024 the outcome slots are streamed from HBM, slower);
+ * 3 qubits up to 65 536 settings (FBX_ERR_UNSUPPORTED beyond); process designs above 3 qubits are refused by
+ * fbx_design_create. */
 int fbx_pgdb_process(const fbx_design* design, int64_t B, const double* expect,
                      const double* counts, int trace_preserving, int mode, int max_iters,
                      double* choi_out, int32_t* iters_out, int32_t* dykstra_out,

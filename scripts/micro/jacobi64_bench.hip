@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <cstring>
 namespace fbx { void set_error(const std::string&) {} int hip_fail(hipError_t, const char*, const char*, int) { return 2; } hipStream_t stream() { return 0; } int ensure_device() { return 0; } int device_epoch() { return 0; } }
 using namespace fbx;
 #ifndef NT_VALUE
@@ -427,7 +428,10 @@ int main(int argc, char** argv) {
         for (int w : {0, 3, 7, 8, 12, 15}) printf("  wave %2d: work A %.0f  wait B1 %.0f  work B %.0f  wait B2 %.0f cycles per round\n", w,
             h[w * 4] / rounds, h[w * 4 + 1] / rounds, h[w * 4 + 2] / rounds, h[w * 4 + 3] / rounds);
     }
-    printf("mode %d: kernel %.3f ms; per eigh %.0f cycles, %.2f sweeps, %.0f cycles/round; residual %.2e, orthogonality %.2e\n",
-           mode, ms, csum / B / reps, ssum / B / reps, csum / ssum / (N - 1), res, orth);
+    unsigned long long hash = 1469598103934665603ull;           // FNV-1a over the bits of every eigenvalue and eigenvector entry (A/B builds: bit-identity)
+    auto mix = [&](const std::vector<double>& x) { for (double v : x) { unsigned long long u; memcpy(&u, &v, 8); hash = (hash ^ u) * 1099511628211ull; } };
+    mix(W); mix(V);
+    printf("mode %d: kernel %.3f ms; per eigh %.0f cycles, %.2f sweeps, %.0f cycles/round; residual %.2e, orthogonality %.2e; bits %016llx\n",
+           mode, ms, csum / B / reps, ssum / B / reps, csum / ssum / (N - 1), res, orth, hash);
     return 0;
 }

@@ -508,6 +508,21 @@ def make_repeated():
     print("repeated done")
 
 
+def make_repeated_3q():
+    """One 3-qubit experiment with the SIC design measured four times (16 128 settings; 500 / 1000 / 2000 / 1000 shots): beyond the
+    14 336 settings of the resident 3-qubit instantiations.  The reference's dense A is 32 256 x 4096 complex = 2.1 GB."""
+    n, basis, reps = 3, "sic", 4
+    qubits = list(range(n))
+    design = synthetic.process_design(n, basis)
+    us = np.array([synthetic.haar_unitary(design.dim, np.random.RandomState(1000))])
+    e, c = _repeated(synthetic.exact_process_expectations(design, us), reps, (500, 1000, 2000, 1000), 0)
+    res = ref_results(process_settings(qubits, basis) * reps, e[0], c[0])
+    est = T.pgdb_process_estimate(res, qubits)
+    np.savez_compressed(os.path.join(HERE, "repeated_3q.npz"), in_labels=np.tile(design.in_labels, (reps, 1)),
+                        paulis=np.tile(design.paulis, (reps, 1)), e=e, c=c, u=us, pgdb=np.array([est]))
+    print("repeated 3q done", e.shape)
+
+
 def make_sweep_3q(batch=6):
     """The 3-qubit leg of BASELINE configs[2]'s pipeline for `batch` random CPTP Kraus sets (K = 4, 8 x 8 operators): what the
     reference's kraus2choi / kraus2pauli_liouville / kraus2chi / choi2chi / process_fidelity return (round 4: the fused
@@ -534,6 +549,9 @@ if __name__ == "__main__":
     np.random.seed(0)
     if "--sweep3q" in sys.argv:
         make_sweep_3q()
+        sys.exit(0)
+    if "--repeated3q" in sys.argv:        # round 5: a 3-qubit list of 16 128 settings (several minutes, ~6 GB)
+        make_repeated_3q()
         sys.exit(0)
     if "--repeated" in sys.argv:          # round 5: merged / repeated datasets beyond the kernels' resident sizes (a few minutes)
         make_repeated()

@@ -3,7 +3,7 @@ same design measured several times -- with different shot counts per repetition 
 tests/golden/repeated.npz (make_goldens.py --repeated, produced by the reference itself) holds such lists beyond the resident
 sizes of the kernels: 2-qubit process designs of 1620 (Pauli x 3) and 1200 (SIC x 5) settings (register-resident kernels:
 1024), a 1-qubit one of 270 (256), state designs of 4200 settings (64 KiB of per-setting LDS staging = 3970).  Until round 5
-those calls returned FBX_ERR_UNSUPPORTED; now they take the streamed forms (csrc/fbx_pgdb_body.hpp STREAM: outcome slots read
+those calls returned FBX_ERR_UNSUPPORTED (3 qubits: beyond 14 336 settings, tests at the end); now they take the streamed forms (csrc/fbx_pgdb_body.hpp STREAM: outcome slots read
 from HBM / L2; csrc/fbx_state.hip r_operator_elem: no per-setting staging) and must give the reference's answer for that list.
 
 CPU: the oracle against the fixture.  GPU: the kernels against the fixture, and the streamed kernels against the resident ones
@@ -113,3 +113,35 @@ def test_state_tomography_of_a_repeated_dataset(gpu, tag, n):
     assert np.abs(tomography._R_batch(g[f"{tag}_mle40"], d, e) - g[f"{tag}_r_op"]).max() < 1e-10
     ll = tomography.state_log_likelihood_batch(g[f"{tag}_mle40"], d, e, c)
     assert np.abs(ll - g[f"{tag}_loglik"]).max() < 1e-9 * np.abs(g[f"{tag}_loglik"]).max()
+
+
+@pytest.mark.gpu
+def test_three_qubit_repeated_dataset(gpu):
+    """16 128 settings (the 3-qubit SIC design measured four times): beyond the 14 336 of the resident 3-qubit instantiations; the
+    kernel's 32-slot instantiation keeps its per-slot arrays in scratch.  tests/golden/repeated_3q.npz holds the reference's
+    answer for that list (make_goldens.py --repeated3q: a 2.1 GB dense design matrix)."""
+    from fbx import design as fd, tomography
+    g = np.load(os.path.join(GOLD, "repeated_3q.npz"))
+    p = g["paulis"]
+    d = fd.Design(3, "process", g["in_labels"], p, np.ones(len(p)))
+    assert d.m == 16128
+    got, st = tomography.pgdb_process_estimate_batch(d, g["e"], g["c"], return_stats=True)
+    assert np.abs(got - g["pgdb"]).max() < 1e-9
+    assert st["iterations"][0] > 20
+
+
+@pytest.mark.gpu
+def test_three_qubit_large_instantiations_agree_with_the_resident_ones(gpu):
+    """The SIC design padded with zero-count repetitions of itself is the same likelihood: 4 x 4032 = 16 128 settings take the 32-slot
+    instantiation, 9 x 4032 = 36 288 the 64-slot one; both must reproduce the resident kernel's estimate with every count equal."""
+    from fbx import design as fd, synthetic, tomography
+    base, _, e, c = synthetic.process_batch(3, "sic", 3)
+    want, sw = tomography.pgdb_process_estimate_batch(base, e, c, return_stats=True)
+    for reps in (4, 9):
+        big = fd.Design(3, "process", np.tile(base.in_labels, (reps, 1)), np.tile(base.paulis, (reps, 1)))
+        e2 = np.concatenate([e] + [np.zeros_like(e)] * (reps - 1), axis=1)
+        c2 = np.concatenate([c] + [np.zeros_like(c)] * (reps - 1), axis=1)
+        got, sg = tomography.pgdb_process_estimate_batch(big, e2, c2, return_stats=True)
+        assert np.abs(got - want).max() < 1e-10, reps
+        for k in ("iterations", "dykstra"):
+            assert np.array_equal(sg[k], sw[k]), (reps, k)
