@@ -184,9 +184,10 @@ def pgdb3q_executed_flop(m, S, iters, dyk, work):
     sweeps, terms, cost_evals = (float(np.mean(work[:, k])) for k in range(3))
     it, dy = float(np.mean(iters)), float(np.mean(dyk))
     f = {}
-    # a round of the role-split solver (csrc/fbx_eigh64.hpp): 496 matrix threads x (two rotations 2 x 42 + 2x2 block update 80)
-    # + 512 eigenvector threads x (one rotation 42 + two block updates 2 x 40); rounds 1-3: 1024 threads x 162
-    f["jacobi_sweeps"] = sweeps * 63 * (496 * 164 + 512 * 122)
+    # a round of the role-split solver with published rotations (csrc/fbx_eigh64.hpp, round 5): 496 matrix threads x (2x2 block
+    # update 80) + 32 of them x (next round's rotation 42) + 512 eigenvector threads x (two block updates 2 x 40).  Round 4, every
+    # thread evaluating the rotations it applies: 496 x 164 + 512 x 122; rounds 1-3: 1024 threads x 162
+    f["jacobi_sweeps"] = sweeps * 63 * (496 * 80 + 32 * 42 + 512 * 80)
     f["basis_change_mfma"] = dy * 2 * 64 ** 3 * 8                  # V^H H V as two dense complex 64^3 products on the fp64 matrix cores
     f["reconstruct"] = terms * 1024 * 28
     f["dykstra_rest"] = dy * 1024 * 240

@@ -62,34 +62,44 @@ __device__ __forceinline__ int herm_store_pos(int r, int c, bool& conj) {
 
 // jacobi_eigh64: roles.  The Hermitian symmetry halves the matrix work and the eigenvector work has none to offer, so the two
 // are given to different wavefronts (two of each per SIMD):
-//   * wavefronts 0-7, MATRIX role: 496 threads own one strictly-upper block (Iu, Ju) each.  Both
-//     rotations of the block are computed locally from the two pivot blocks (two independent reciprocal-square-root chains:
-//     no exchange between lanes, no second barrier); every entry is written once, to the seat the tournament permutation
+//   * wavefronts 0-7, MATRIX role: 496 threads own one strictly-upper block (Iu, Ju) each and apply the rotations of its row
+//     pair and of its column pair; every entry is written once, to the seat the tournament permutation
 //     assigns it or to the mirrored seat (conjugated), whichever lies in the stored triangle.
 //   * wavefronts 8-15, EIGENVECTOR role: thread (I, J), I < 16, owns the eigenvector blocks (I, J) and (I + 16, J) -- same
-//     column pair, one rotation for both -- in registers, exchanged with the neighbouring lanes as above.  The thread whose
-//     row pair equals its column pair (I == J or I + 16 == J) also places the pair's rotated diagonal and the annihilated entry.
+//     column pair, one rotation for both -- in registers, exchanged with the neighbouring lanes as above.
 // Two sets of LDS addresses (one per buffer) alternate between consecutive rounds, so a round contains no address arithmetic.
 // The two roles are two separate loop nests behind a SCALAR branch (the wavefront index is wave-uniform), with the same sequence
 // of workgroup barriers -- two per convergence test, one per round: their registers overlap instead of adding up (as one loop
 // body with both roles the solver needed all 128 registers of a 1024-thread workgroup and, behind its call boundary in the
 // 3-qubit kernels, saved 49 callee-saved registers to scratch per decomposition).
+// Rounds 1-4 (-DFBX_EIGH64_LOCAL_ROTATIONS keeps that form for A/B builds): every thread evaluated the rotations it applies from
+// the pivot blocks -- no exchange, no second barrier, and 2 x 496 + 512 evaluations of 32 rotations per round.
 namespace eigh64 {
 constexpr int N = 64, NB = 32, PS = sys_plane<N>(), NUP = NB * (NB - 1) / 2, NT = 1024;
 
-#ifdef FBX_EIGH64_PUBLISHED
-// PUBLISHED ROTATIONS (round 5).  The rotation of a pair is computed ONCE per round instead of by every thread that applies it
-// (496 x 2 + 512 evaluations of two reciprocal-square-root chains per round: 80 of the ~140 vector instructions of a
-// matrix-role thread, 40 of the ~175 of an eigenvector-role thread -- the round is bound by vector issue, four wavefronts per
-// SIMD).  No second barrier: the pivot of NEXT round's pair K' is made of two diagonal entries and one off-diagonal entry that
-// all exist in ONE matrix-role thread at the end of this round -- the tournament permutation (jacobi_seat) forms
+#ifndef FBX_EIGH64_LOCAL_ROTATIONS
+// PUBLISHED ROTATIONS (round 5).  The rotation of a pair is evaluated ONCE per round instead of by every thread that applies it
+// (an evaluation is ~30 vector instructions with two reciprocal-square-root chains: 60 of the 106 instructions of a
+// matrix-role thread's round and 30 of the 160 of an eigenvector-role thread's).  No second barrier: the pivot of NEXT round's
+// pair K' is made of two diagonal entries and one off-diagonal entry that all exist in ONE matrix-role thread at the end of
+// this round -- the tournament permutation (jacobi_seat) forms
 //   pair 0 = {top 0, bottom 1}, pair 1 = {bottom 0, bottom 2}, pair K = {top K-1, bottom K+1} (2 <= K <= 30), pair 31 = {top 30, top 31},
 // so the thread of block (0,1), (0,2), (K-1,K+1), (30,31) holds the updated entry b' in its registers and the rotated diagonals
 // a' (of its row pair) and d' (of its column pair) in the two records it has just applied.  That thread evaluates the next
 // rotation and publishes the record {c, s, a'', d''} in the buffer the round writes -- in seats of the LOWER block triangle,
 // which the upper-triangle storage leaves unused: block (31, K) for K < 31, block (30, 23) for K = 31 (its bank group completes
 // those of pairs 24..30), entries 0 / 1 / 2 = (c, Re s) / (Im s, a'') / (d'', -).  Everybody reads two records instead of two pivot
-// blocks.  Same inputs, same function: BIT-IDENTICAL to the locally computed rotations.
+// blocks.  Same inputs, same function: BIT-IDENTICAL to the locally computed rotations (micro/jacobi64_bench prints a hash).
+// What is sparse goes to ONE wavefront per role: a branch that a few lanes of EVERY wavefront take costs every wavefront its
+// whole instruction stream, and an LDS instruction with four active lanes a full issue.  The 32 publishing blocks are threads
+// 0-31 (wavefront 0 evaluates rotations, wavefronts 1-7 never enter that branch); the 32 threads of eigenvector row I = 0
+// (wavefront 8) place the rotated diagonals and the annihilated entries of all pairs.  Measured, cycles per round in isolation
+// (256 workgroups, profiles/r05/jacobi64_published.txt): 2615 local rotations; 2570 published; 2165 + publishing blocks in one
+// wavefront; 1938 + diagonals placed by one wavefront.  Without the eigenvector role's arithmetic the matrix chain alone takes
+// 1252.  Measured and dropped on top: the eigenvector role one round BEHIND (applies round r - 1 while the loads of round r are
+// in flight: 2474 against 2568 before the two concentrations, 2019 against 1938 after); s_setprio for the publishing wavefront
+// or for the whole matrix role (1944 / 1915: noise); DPP shifts without an `old` operand (the compiler does not fold them
+// into the selects).
 __device__ __forceinline__ int rec_pos(int K, int e) {
     const int R = K < NB - 1 ? NB - 1 : NB - 2, C = K < NB - 1 ? K : 23;
     return e * PS + sys_pos<N>(R, C, e);
@@ -130,15 +140,30 @@ __device__ __forceinline__ double flip_sign(double x, unsigned mask) {
     return __hiloint2double(__double2hiint(x) ^ (int)mask, __double2loint(x));
 }
 
-#ifdef FBX_EIGH64_PUBLISHED
+#ifndef FBX_EIGH64_LOCAL_ROTATIONS
 __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* red, double tol2) {
-    // rows i and 30 - i have 32 strictly-upper blocks between them: half-wavefront r = t / 32 takes those two rows (r < 15),
-    // the last one the 16 blocks of row 15 -- runs of consecutive column pairs, as the conflict-free layout wants them
-    const int r = t / NB, c = t % NB;
-    const bool mrole = r < 15 || c < 16;
-    const bool lower_row = c >= NB - 1 - r;                // the second row of the pair (r < 15 only)
-    const int Iu = mrole ? (lower_row ? 30 - r : r) : 0;
-    const int Ju = mrole ? (lower_row ? Iu + 1 + (c - (NB - 1 - r)) : r + 1 + c) : 1;
+    // the 32 blocks that publish a record are threads 0-31 (thread K' publishes pair K'); the others follow in this order with
+    // those 32 left out: rows i and 30 - i have 32 strictly-upper blocks between them, a run of 32 indices takes those two rows
+    // (i < 15), the last one the 16 blocks of row 15 -- runs of consecutive column pairs, as the conflict-free layout wants them
+    int Iu, Ju;
+    const bool mrole = t < NUP;
+    if (t < NB) {
+        Iu = t == 0 ? 0 : t == 1 ? 0 : t == NB - 1 ? NB - 2 : t - 1;
+        Ju = t == 0 ? 1 : t == 1 ? 2 : t == NB - 1 ? NB - 1 : t + 1;
+    } else {
+        int u = t - NB;                                     // index among the non-publishing blocks -> index in the full enumeration
+        // (publishing blocks in the full enumeration, ascending: (0,1), (0,2), (30,31); rows r and 30 - r: c = 1 and c = 32 - r; row 15: c = 1)
+        if (0 <= u) ++u;
+        if (1 <= u) ++u;
+        if (31 <= u) ++u;
+#pragma unroll
+        for (int rr = 1; rr < 15; ++rr) { if (32 * rr + 1 <= u) ++u; if (32 * rr + 32 - rr <= u) ++u; }
+        if (32 * 15 + 1 <= u) ++u;
+        const int r = u / NB, c = u % NB;
+        const bool lower_row = c >= NB - 1 - r;
+        Iu = mrole ? (lower_row ? 30 - r : r) : 0;
+        Ju = mrole ? (lower_row ? Iu + 1 + (c - (NB - 1 - r)) : r + 1 + c) : 1;
+    }
     static_assert(NUP == 15 * NB + 16, "496 strictly-upper blocks");
     // which of next round's pairs this block holds the pivot entry of (see the head of the namespace), and where in the block
     const bool k_first = Iu == 0 && Ju == 1, k_second = Iu == 0 && Ju == 2, k_last = Iu == NB - 2 && Ju == NB - 1;
@@ -196,7 +221,7 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
 __device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv, bool init_identity, double* red, double tol2) {
     const int I = tv / NB, J = tv % NB;
     const bool first = J == 0, last = J == NB - 1;
-    const bool diag = I == (J & 15);                       // row pair I (J < 16) or I + 16 (J >= 16) is the column pair
+    const bool diag = I == 0;                              // thread J of the first wavefront places pair J's rotated diagonal and annihilated entry
     // pivot block of the column pair (convergence test only), its record; seats of the rotated diagonal and of the annihilated entry
     int ra[4], wa[3];
     {
