@@ -79,24 +79,25 @@ struct Lds {
 };
 
 __device__ __forceinline__ double bsum(double v, Lds& L) { return block_sum<NT>(v, L.red); }
-// K sums over the workgroup with ONE barrier pair instead of K (every thread gets all totals)
+// K <= 8 sums over the workgroup with ONE barrier pair instead of K (every thread gets all totals).  Second stage (round 5): lane
+// 16 k + w of every wavefront reads the partial sum of wavefront w for value k (two loads per lane for K > 4) and the sixteen
+// partials are added by four DPP steps inside the row -- instead of 16 K broadcast loads and additions per thread (128 LDS
+// loads per thread and call for the Dykstra stopping functional: 17 k cycles of the ~420 k of a Dykstra iteration).
 template <int K>
 __device__ __forceinline__ void bsum_multi(double (&v)[K], Lds& L) {
+    static_assert(K <= 8 && NT / 64 == 16, "sixteen wavefronts, at most two values per row of lanes");
+    const int lane = threadIdx.x & 63;
+    double mine = 0.0;                                  // lane k < K publishes value k of this wavefront
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    for (int k = 0; k < K; ++k) { const double w = wave_sum(v[k]); mine = lane == k ? w : mine; }
     FBX_BLOCK_SYNC();                                   // earlier readers of `red` are done
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) L.red[k * (NT / 64) + (threadIdx.x >> 6)] = v[k];
-    }
+    if (lane < K) L.red[lane * (NT / 64) + (threadIdx.x >> 6)] = mine;
     FBX_BLOCK_SYNC();
+    double a = L.red[lane], b = K > 4 ? L.red[(64 + lane) & (K * (NT / 64) - 1)] : 0.0;
+    a += dpp_permute<0xB1>(a); a += dpp_permute<0x4E>(a); a += dpp_permute<0x141>(a); a += dpp_permute<0x140>(a);
+    if constexpr (K > 4) { b += dpp_permute<0xB1>(b); b += dpp_permute<0x4E>(b); b += dpp_permute<0x141>(b); b += dpp_permute<0x140>(b); }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) s += L.red[k * (NT / 64) + w];
-        v[k] = s;
-    }
+    for (int k = 0; k < K; ++k) v[k] = k < 4 ? readlane_f64(a, 16 * k) : readlane_f64(b, 16 * (k - 4));
 }
 
 // ---- warm start: Ms <- V^H Ms V for the eigenvectors V of the previous projection (still in Vs).
@@ -263,9 +264,23 @@ __device__ Blk reconstruct64(Lds& L, int t) {
 __device__ __forceinline__ double hermitise_into_ms(const Blk& x, Lds& L, int t, bool want_norm) {
     t = opaque(t);
     FBX_BLOCK_SYNC();
-    sys_store<D>(L.Ms, t, x);
-    FBX_BLOCK_SYNC();
-    const Blk xa = sys_load_adjoint<D>(L.Ms, t);
+    // the transposed copy goes through a layout of its own: block (I, J) of plane e at e * PS + I * 32 + (I ^ J), so that the
+    // eight blocks a lane group writes (eight column pairs of one row) AND the eight it reads back (eight ROW pairs of one column:
+    // a stride of 32 entries in the solver's layout, 8-way bank conflicts on every b128 read) fall on eight different bank groups
+    Blk xa;
+    {
+        constexpr int PS = sys_plane<D>();
+        const int I = t / NB, J = t % NB, sw = I ^ J;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cplx c; c.re = x.re[e]; c.im = x.im[e]; L.Ms[e * PS + I * NB + sw] = c; }
+        FBX_BLOCK_SYNC();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int et = (e & 1) * 2 + (e >> 1);
+            const cplx c = L.Ms[et * PS + J * NB + sw];
+            xa.re[e] = c.re; xa.im[e] = -c.im;
+        }
+    }
     Blk h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { h.re[e] = 0.5 * (x.re[e] + xa.re[e]); h.im[e] = 0.5 * (x.im[e] + xa.im[e]); }
@@ -492,6 +507,9 @@ __device__ __forceinline__ Blk proj_physical(const Blk& x, bool tp, Lds& L, int 
         const Blk new_tp = blk_axpy(blk_zero(), -1.0 / d, kron_id_blk(L.pt, t));
         red8[1] = blk_norm2(blk_sub(new_tp, old_tp));                      // ||new_TP_change - old_TP_change||^2
         blk_dotc(old_tp, blk_sub(new_state, last_state), red8[2], red8[3]); // <old_TP_change, state_change>
+        // (measured and dropped, round 5: contracting the state change in two halves -- (new_CP_change - old_CP_change) in front
+        //  of the TP projection, the Kronecker-structured TP half behind it -- so that only new_CP_change crosses the projection:
+        //  200.5 against 197.4 ms per 256 reconstructions)
         bsum_multi<8>(red8, L);
         PH3(5);
         const double i2r = red8[4] - c0r, i2i = red8[5] - c0i;

@@ -7,7 +7,7 @@ import numpy as np
 from fbx import synthetic, tomography, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 mode = sys.argv[2] if len(sys.argv) > 2 else 'fixed'
-design, us, e, c = synthetic.process_batch(2, 'pauli', B)
+design, us, e, c = synthetic.process_batch(int(os.environ.get('AB_NQ', '2')), os.environ.get('AB_BASIS', 'pauli'), B)     # AB_NQ=3 AB_BASIS=sic: the 3-qubit kernel
 _lib.set_device(0)
 lib = _lib.lib()
 buf = _lib.DeviceBuffer(B * 8 * 8)
