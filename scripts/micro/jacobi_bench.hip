@@ -13,6 +13,9 @@
 #ifdef FBX_JACOBI_VDPP
 #include "jacobi_vdpp.hpp"             // round-5 experiment: eigenvector exchange through DPP instead of LDS
 #endif
+#ifdef FBX_JACOBI_PUB16
+#include "jacobi_pub16.hpp"            // round-5 experiment: rotations published through LDS by the lanes that hold next round's pivots
+#endif
 #ifdef FBX_JACOBI_REGPIVOT
 #include "jacobi_regpivot.hpp"         // round-5 experiment: next-round pivots through registers (measured, not adopted)
 #endif
@@ -42,6 +45,8 @@ __global__ void __launch_bounds__(64) k_eigh(const double* A, double* W, double*
         sweeps += jacobi_eigh_wave_chain_first<N>(M, V, lane, true);
 #elif defined(FBX_JACOBI_REGPIVOT)
         sweeps += jacobi_eigh_wave_regpivot<N>(M, V, lane, true);
+#elif defined(FBX_JACOBI_PUB16)
+        sweeps += jacobi_eigh_wave_pub16<N>(M, V, lane, true);
 #elif defined(FBX_JACOBI_H2)
         sweeps += jacobi_eigh_wave_h2<N>(M, V, lane, true);
 #elif defined(FBX_JACOBI_ALLREG)
