@@ -38,7 +38,10 @@ __device__ __forceinline__ double dpp_next_lane(double x) {
 //   new bottom[J] = old bottom[J + 1] (J <= 30), old top[31] (J = 31)
 // (Measured and dropped: the shift and the end-of-ring select fused into one v_cndmask_b32_dpp per register through inline
 // assembly -- 48 instead of 80 instructions per round for the two blocks, and 6 % SLOWER: the assembly blocks pin the order of
-// 16 instructions and need their own s_nop for the DPP read hazard, which the scheduler otherwise hides.)
+// 16 instructions and need their own s_nop for the DPP read hazard, which the scheduler otherwise hides.  Round 5, on the
+// published-rotation solver whose round is bound by vector issue: all sixteen register halves of a thread in ONE block, VCC = the
+// lane mask of the ring ends, 48 instructions instead of 80 -- 2222-2272 against 1865 cycles per round: the block's 48 operands live
+// at once cost the 128-register thread 244 B of scratch.)
 __device__ __forceinline__ void seat_shift(double& top, double& bot, bool first, bool last) {
     const double send = first ? bot : top;             // pair 0 hands its BOTTOM column to pair 1 and keeps its top one
     const double from_prev = dpp_prev_lane(send);
