@@ -473,4 +473,12 @@ __device__ int jacobi_eigh64(cplx* Ms, cplx* Vs, int t, bool init_identity, doub
     return sweep;
 }
 
+// the workgroup solver of the generic kernels (fbx_eigh, the into-chi conversions): the role-split solver above for 64 x 64 on sixteen
+// wavefronts, jacobi_eigh_simple otherwise
+template <int N, int NT>
+__device__ __forceinline__ int jacobi_eigh_block(cplx* Ms, cplx* Vs, int t, bool init_identity, double* red) {
+    if constexpr (N == 64 && NT == 1024) return jacobi_eigh64<1024>(Ms, Vs, t, init_identity, red);
+    else return jacobi_eigh_simple<N, NT>(Ms, Vs, t, init_identity, red);
+}
+
 }  // namespace fbx

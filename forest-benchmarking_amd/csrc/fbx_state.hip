@@ -10,7 +10,7 @@
 //   project_state_matrix_to_physical operator_tools/project_state_matrix.py:6-52
 //   purity / fidelity / trace_distance / hilbert_schmidt_ip   distance_measures.py:14-114,198-216
 //   sqrtm_psd                        operator_tools/calculational.py:77-91
-#include "fbx_eigh.hpp"
+#include "fbx_eigh64.hpp"
 #include <hip/hip_cooperative_groups.h>
 #include <cfloat>
 #include <cstdlib>
@@ -599,7 +599,7 @@ eigh_kernel(long long B, const double* __restrict__ a, double* __restrict__ w_ou
     }
     sys_store<N>(Ms, lane, h);
     __syncthreads();
-    jacobi_eigh_simple<N, NT>(Ms, Vs, lane, true, red);
+    jacobi_eigh_block<N, NT>(Ms, Vs, lane, true, red);
     if (lane < N) lam[lane] = Ms[sys_index<N>(lane, lane)].re;
     __syncthreads();
     if (lane < N) {                     // rank of eigenvalue `lane` in ascending order (stable)

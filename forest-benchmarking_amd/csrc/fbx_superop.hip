@@ -9,6 +9,7 @@
 //   operator_tools/apply_superoperator.py:60-90              (apply_choi_matrix_2_state)
 //   distance_measures.py:271-359                             (entanglement / process fidelity)
 #include "fbx_choi.hpp"
+#include "fbx_eigh64.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -346,7 +347,7 @@ convert3_kernel(int from, int to, long long B, const double* __restrict__ in, in
                     __syncthreads();
                     sys_store<D>(A, t, h);
                     __syncthreads();
-                    jacobi_eigh_simple<D, NT>(A, Bm, t, true, red);
+                    jacobi_eigh_block<D, NT>(A, Bm, t, true, red);
                     if (t < D) {
                         const double l = fabs(A[sys_index<D>(t, t)].re);
                         lam[t] = l > 1e-9 ? l : 0.0;
