@@ -51,6 +51,30 @@ __device__ __forceinline__ void seat_shift(double& top, double& bot, bool first,
     bot = last ? t_old : from_next;
 }
 
+// Round 5: the same permutation for a thread that holds TWO neighbouring column pairs (2 tau, 2 tau + 1) of a ring whose 32 pairs
+// are the sixteen lanes of ONE DPP row.  Of the four columns (A, B) = (top, bottom) of pair 2 tau and (C, D) of pair 2 tau + 1, two
+// stay in the thread (A -> top of 2 tau + 1, D -> bottom of 2 tau: register renaming) and two travel (C to the right neighbour's
+// pair 2 tau + 2, B to the left neighbour's pair 2 tau - 1) -- and a DPP ROW shift has the ring's two ends built in: the lane
+// without a source keeps its `old` operand, which is exactly what the ends do (lane 0: the top of pair 0 stays; lane 15: the top of
+// pair 31 becomes its bottom).  4 DPP moves + 2 selects (the bottom of pair 0 becomes the top of pair 1) per FOUR doubles, against
+// 2 x (4 + 6) with seat_shift: 24 instead of 80 instructions per thread and round.
+__device__ __forceinline__ double dpp_row_shr_old(double old, double src) {        // lane i <- src of lane i - 1 of its row of 16; lane 0 <- old
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_row_shl_old(double old, double src) {        // lane i <- src of lane i + 1; lane 15 <- old
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x101, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x101, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void ring_shift(double& A, double& B, double& C, double& D, bool first) {
+    const double nA = dpp_row_shr_old(A, C);           // top of pair 2 tau <- top of pair 2 tau - 1 (left neighbour's C); pair 0 keeps its top
+    const double nD = dpp_row_shl_old(C, B);           // bottom of pair 2 tau + 1 <- bottom of pair 2 tau + 2; pair 31: its own top
+    const double nC = first ? B : A;                   // top of pair 2 tau + 1 <- top of pair 2 tau; pair 1: the bottom of pair 0
+    A = nA; B = D; C = nC; D = nD;
+}
+
 // Where the entry (slot r, slot c), r != c, of the Hermitian work matrix is STORED: only the upper block triangle is kept
 // (block row <= block column) and, inside a diagonal block, the entry (even slot, odd slot).  Returns the offset in the
 // element-major layout; `conj` says that the stored value is the conjugate of M[r][c].
@@ -135,6 +159,9 @@ __device__ __forceinline__ int priv_store_pos(int r, int c, bool& conj) {
     return pl * PS + priv_slot(x, pl);
 }
 __device__ __forceinline__ int rec_pos(int K, int e) { return e * PS + priv_slot(NUP + NB + K, e); }
+// second copy of the records for the eigenvector role, whose sixteen lanes of a DPP row read the records of pairs 2 tau (then
+// 2 tau + 1), tau = 0..15: even pairs on sixteen consecutive slots, odd pairs on the next sixteen
+__device__ __forceinline__ int rec2_pos(int K, int e) { return e * PS + priv_slot(NUP + 2 * NB + (K >> 1) + 16 * (K & 1), e); }
 #endif
 
 // the loop nest both roles run: `test(o2, n2)` adds the role's share of the off-diagonal / total norm, `round(rd, wr)` is one
@@ -202,7 +229,7 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
     const int Kn = k_first ? 0 : k_second ? 1 : k_last ? NB - 1 : Iu + 1;
     // own block (planes b = 0 / 1), record of the row pair, record of the column pair (entries 0 / 1; entry 2 = entry 0 + 2 planes);
     // the four seats and the record this thread publishes
-    int ra[6], wa[6];
+    int ra[6], wa[8];
     unsigned sgm[4];                                        // sign bit to flip on the imaginary part of an entry stored mirrored
     // (the solver works in Vs first: the caller's matrix is copied there, into the private layout -- `delta` added here, taken
     //  away again by the address sets of the other buffer)
@@ -216,6 +243,7 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
         sgm[e] = cj ? 0x80000000u : 0u;
     }
     wa[4] = delta + rec_pos(Kn, 0); wa[5] = delta + rec_pos(Kn, 1);
+    wa[6] = delta + rec2_pos(Kn, 0); wa[7] = delta + rec2_pos(Kn, 1);     // the eigenvector role's copy
     if (mrole) {                                            // caller's layout -> private layout, in the other buffer
 #pragma unroll
         for (int e = 0; e < 4; ++e) Ms[e * PS + ra[e & 1]] = Ms[e * PS + sys_pos<N>(Iu, Ju, e)];
@@ -231,7 +259,7 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
             n2 = o2;
         }
     };
-    auto round = [&](const int (&rd)[6], const int (&wr)[6]) __attribute__((always_inline)) {
+    auto round = [&](const int (&rd)[6], const int (&wr)[8]) __attribute__((always_inline)) {
         if (mrole) {
             const cplx i0 = Ms[rd[2]], i1 = Ms[rd[3]];      // (c, Re s), (Im s, a') of the row pair
             const cplx j0 = Ms[rd[4]], j1 = Ms[rd[5]];      // ... of the column pair
@@ -247,57 +275,66 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
                 cplx e0, e1, e2;
                 e0.re = n.c; e0.im = n.sr; e1.re = n.si; e1.im = n.an; e2.re = n.dn; e2.im = 0.0;
                 Ms[wr[4]] = e0; Ms[wr[5]] = e1; Ms[2 * PS + wr[4]] = e2;
+                Ms[wr[6]] = e0; Ms[wr[7]] = e1; Ms[2 * PS + wr[6]] = e2;
             }
             m00.im = flip_sign(m00.im, sgm[0]); m01.im = flip_sign(m01.im, sgm[1]);
             m10.im = flip_sign(m10.im, sgm[2]); m11.im = flip_sign(m11.im, sgm[3]);
             Ms[wr[0]] = m00; Ms[wr[1]] = m01; Ms[wr[2]] = m10; Ms[wr[3]] = m11;
         }
     };
-    return sweeps<6, 6>(ra, wa, -delta, red, tol2, test, round);
+    return sweeps<6, 8>(ra, wa, -delta, red, tol2, test, round);
 }
 
 __device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv, bool init_identity, double* red, double tol2) {
-    const int I = tv / NB, J = tv % NB;
-    const bool first = J == 0, last = J == NB - 1;
-    const bool diag = I == 0;                              // thread J of the first wavefront places pair J's rotated diagonal and annihilated entry
-    // pivot block of the column pair (convergence test only), its record; seats of the rotated diagonal and of the annihilated entry
-    int ra[4], wa[3];
+    // thread (R, tau): rows 2R, 2R + 1 of the eigenvector matrix, column pairs 2 tau and 2 tau + 1 (blocks b = 0, 1); the sixteen
+    // lanes of a DPP row are one ring of 32 pairs (ring_shift above), a wavefront holds four row pairs
+    const int R = tv / 16, tau = tv % 16;
+    const bool first = tau == 0;
+    // the 32 threads of the first two rings (half a wavefront) also place the rotated diagonal and the annihilated entry of pair Kd
+    const bool diag = R < 2;
+    const int Kd = 2 * tau + (R & 1);
+    // pivot block of pair Kd (convergence test only), the records of the thread's two pairs, the record of pair Kd; the three seats
+    int ra[7], wa[3];
     {
-        const int sa = jacobi_seat<N>(2 * J), sd = jacobi_seat<N>(2 * J + 1);
+        const int sa = jacobi_seat<N>(2 * Kd), sd = jacobi_seat<N>(2 * Kd + 1);
         bool cj;
-        ra[0] = delta + priv_slot(NUP + J, 0); ra[1] = delta + priv_slot(NUP + J, 1);
-        ra[2] = delta + rec_pos(J, 0); ra[3] = delta + rec_pos(J, 1);
+        ra[0] = delta + priv_slot(NUP + Kd, 0); ra[1] = delta + priv_slot(NUP + Kd, 1);
+        ra[2] = delta + rec2_pos(2 * tau, 0); ra[3] = delta + rec2_pos(2 * tau, 1);
+        ra[4] = delta + rec2_pos(2 * tau + 1, 0); ra[5] = delta + rec2_pos(2 * tau + 1, 1);
+        ra[6] = delta + rec2_pos(Kd, 0);
         wa[0] = delta + 3 * (sa & 1) * PS + priv_slot(NUP + (sa >> 1), sa & 1);
         wa[1] = delta + 3 * (sd & 1) * PS + priv_slot(NUP + (sd >> 1), sd & 1);
         wa[2] = delta + priv_store_pos(sa, sd, cj);
     }
-    // eigenvector blocks in registers: rows 2I, 2I + 1 (block 0) and 2I + 32, 2I + 33 (block 1); columns = slots 2J (p), 2J + 1 (q)
+    // eigenvector blocks (R, 2 tau + b) in registers: v0 = row 2R, v1 = row 2R + 1; p = top column of the pair, q = bottom column
     cplx v0p[2], v0q[2], v1p[2], v1q[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int Ik = I + 16 * k;
+    for (int b = 0; b < 2; ++b) {
+        const int J = 2 * tau + b;
         if (init_identity) {
-            v0p[k].re = (Ik == J) ? 1.0 : 0.0; v0p[k].im = 0.0; v1q[k] = v0p[k];
-            v0q[k].re = 0.0; v0q[k].im = 0.0; v1p[k] = v0q[k];
+            v0p[b].re = (R == J) ? 1.0 : 0.0; v0p[b].im = 0.0; v1q[b] = v0p[b];
+            v0q[b].re = 0.0; v0q[b].im = 0.0; v1p[b] = v0q[b];
         } else {
-            v0p[k] = Vs[0 * PS + sys_pos<N>(Ik, J, 0)]; v0q[k] = Vs[1 * PS + sys_pos<N>(Ik, J, 1)];
-            v1p[k] = Vs[2 * PS + sys_pos<N>(Ik, J, 0)]; v1q[k] = Vs[3 * PS + sys_pos<N>(Ik, J, 1)];
+            v0p[b] = Vs[0 * PS + sys_pos<N>(R, J, 0)]; v0q[b] = Vs[1 * PS + sys_pos<N>(R, J, 1)];
+            v1p[b] = Vs[2 * PS + sys_pos<N>(R, J, 0)]; v1q[b] = Vs[3 * PS + sys_pos<N>(R, J, 1)];
         }
     }
     FBX_BLOCK_SYNC();                                       // Vs is a matrix buffer from here on -- the one the solver starts in
-    // the pivot block of pair J into the private layout, and the record of the first round from it (visible behind the barriers
-    // of the first convergence test)
+    // the pivot block of pair Kd into the private layout, and the record of the first round from it, both copies (visible behind
+    // the barriers of the first convergence test)
     if (diag) {
-        const cplx a0 = Ms[0 * PS + sys_pos<N>(J, J, 0)], b0 = Ms[1 * PS + sys_pos<N>(J, J, 1)], d0 = Ms[3 * PS + sys_pos<N>(J, J, 1)];
+        const cplx a0 = Ms[0 * PS + sys_pos<N>(Kd, Kd, 0)], b0 = Ms[1 * PS + sys_pos<N>(Kd, Kd, 1)], d0 = Ms[3 * PS + sys_pos<N>(Kd, Kd, 1)];
         Ms[0 * PS + ra[0]] = a0; Ms[1 * PS + ra[1]] = b0; Ms[3 * PS + ra[1]] = d0;
         const JRot n = jacobi_rotation(a0.re, d0.re, b0.re, b0.im);
         cplx e0, e1, e2;
         e0.re = n.c; e0.im = n.sr; e1.re = n.si; e1.im = n.an; e2.re = n.dn; e2.im = 0.0;
-        Ms[ra[2]] = e0; Ms[ra[3]] = e1; Ms[2 * PS + ra[2]] = e2;
+        const int c1 = delta + rec_pos(Kd, 0), c1b = delta + rec_pos(Kd, 1), c2b = delta + rec2_pos(Kd, 1);
+        Ms[c1] = e0; Ms[c1b] = e1; Ms[2 * PS + c1] = e2;
+        Ms[ra[6]] = e0; Ms[c2b] = e1; Ms[2 * PS + ra[6]] = e2;
     }
     FBX_BLOCK_SYNC();
     double ev_a = 0.0, ev_d = 0.0;                          // (diag threads) the pair's diagonal at the last convergence test
-    auto test = [&](const int (&rd)[4], double& o2, double& n2) __attribute__((always_inline)) {
+    auto test = [&](const int (&rd)[7], double& o2, double& n2) __attribute__((always_inline)) {
         if (diag) {
             ev_a = Ms[0 * PS + rd[0]].re; ev_d = Ms[3 * PS + rd[1]].re;
             const cplx b = Ms[1 * PS + rd[1]];
@@ -305,33 +342,32 @@ __device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv
             n2 = o2 + ev_a * ev_a + ev_d * ev_d;
         }
     };
-    auto round = [&](const int (&rd)[4], const int (&wr)[3]) __attribute__((always_inline)) {
-        const cplx r0 = Ms[rd[2]], r1 = Ms[rd[3]];         // (c, Re s), (Im s, a')
+    auto round = [&](const int (&rd)[7], const int (&wr)[3]) __attribute__((always_inline)) {
+        const cplx x0 = Ms[rd[2]], x1 = Ms[rd[3]];         // pair 2 tau: (c, Re s), (Im s, a')
+        const cplx y0 = Ms[rd[4]], y1 = Ms[rd[5]];         // pair 2 tau + 1
         if (diag) {
-            cplx a; a.re = r1.im; a.im = 0.0; cplx d; d.re = Ms[2 * PS + rd[2]].re; d.im = 0.0; cplx z; z.re = 0.0; z.im = 0.0;
+            cplx a; a.re = (R & 1) ? y1.im : x1.im; a.im = 0.0; cplx d; d.re = Ms[2 * PS + rd[6]].re; d.im = 0.0; cplx z; z.re = 0.0; z.im = 0.0;
             Ms[wr[0]] = a; Ms[wr[1]] = d; Ms[wr[2]] = z;
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            jacobi_apply_v(r0.re, r0.im, r1.re, v0p[k], v0q[k], v1p[k], v1q[k]);
-            seat_shift(v0p[k].re, v0q[k].re, first, last); seat_shift(v0p[k].im, v0q[k].im, first, last);
-            seat_shift(v1p[k].re, v1q[k].re, first, last); seat_shift(v1p[k].im, v1q[k].im, first, last);
-        }
+        jacobi_apply_v(x0.re, x0.im, x1.re, v0p[0], v0q[0], v1p[0], v1q[0]);
+        jacobi_apply_v(y0.re, y0.im, y1.re, v0p[1], v0q[1], v1p[1], v1q[1]);
+        ring_shift(v0p[0].re, v0q[0].re, v0p[1].re, v0q[1].re, first); ring_shift(v0p[0].im, v0q[0].im, v0p[1].im, v0q[1].im, first);
+        ring_shift(v1p[0].re, v1q[0].re, v1p[1].re, v1q[1].re, first); ring_shift(v1p[0].im, v1q[0].im, v1p[1].im, v1q[1].im, first);
     };
-    const int sweep = sweeps<4, 3>(ra, wa, -delta, red, tol2, test, round);
+    const int sweep = sweeps<7, 3>(ra, wa, -delta, red, tol2, test, round);
     if (sweep == FBX_JACOBI_MAX_SWEEPS && diag) { ev_a = Ms[0 * PS + ra[0]].re; ev_d = Ms[3 * PS + ra[1]].re; }
     FBX_BLOCK_SYNC();
     // results where the callers expect them: the eigenvalues on the diagonal of Ms, the eigenvectors in Vs (both buffers are
     // free: every thread's last read lies behind a barrier)
     if (diag) {
         cplx a; a.re = ev_a; a.im = 0.0; cplx d; d.re = ev_d; d.im = 0.0;
-        Ms[0 * PS + sys_pos<N>(J, J, 0)] = a; Ms[3 * PS + sys_pos<N>(J, J, 1)] = d;
+        Ms[0 * PS + sys_pos<N>(Kd, Kd, 0)] = a; Ms[3 * PS + sys_pos<N>(Kd, Kd, 1)] = d;
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int Ik = I + 16 * k;
-        Vs[0 * PS + sys_pos<N>(Ik, J, 0)] = v0p[k]; Vs[1 * PS + sys_pos<N>(Ik, J, 1)] = v0q[k];
-        Vs[2 * PS + sys_pos<N>(Ik, J, 0)] = v1p[k]; Vs[3 * PS + sys_pos<N>(Ik, J, 1)] = v1q[k];
+    for (int b = 0; b < 2; ++b) {
+        const int J = 2 * tau + b;
+        Vs[0 * PS + sys_pos<N>(R, J, 0)] = v0p[b]; Vs[1 * PS + sys_pos<N>(R, J, 1)] = v0q[b];
+        Vs[2 * PS + sys_pos<N>(R, J, 0)] = v1p[b]; Vs[3 * PS + sys_pos<N>(R, J, 1)] = v1q[b];
     }
     return sweep;
 }
