@@ -160,9 +160,6 @@ __device__ __forceinline__ int priv_store_pos(int r, int c, bool& conj) {
     return pl * PS + priv_slot(x, pl);
 }
 __device__ __forceinline__ int rec_pos(int K, int e) { return e * PS + priv_slot(NUP + NB + K, e); }
-// second copy of the records for the eigenvector role, whose sixteen lanes of a DPP row read the records of pairs 2 tau (then
-// 2 tau + 1), tau = 0..15: even pairs on sixteen consecutive slots, odd pairs on the next sixteen
-__device__ __forceinline__ int rec2_pos(int K, int e) { return e * PS + priv_slot(NUP + 2 * NB + (K >> 1) + 16 * (K & 1), e); }
 #endif
 
 // the loop nest both roles run: `test(o2, n2)` adds the role's share of the off-diagonal / total norm, `round(rd, wr)` is one
@@ -230,7 +227,7 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
     const int Kn = k_first ? 0 : k_second ? 1 : k_last ? NB - 1 : Iu + 1;
     // own block (planes b = 0 / 1), record of the row pair, record of the column pair (entries 0 / 1; entry 2 = entry 0 + 2 planes);
     // the four seats and the record this thread publishes
-    int ra[6], wa[8];
+    int ra[6], wa[6];
     unsigned sgm[4];                                        // sign bit to flip on the imaginary part of an entry stored mirrored
     // (the solver works in Vs first: the caller's matrix is copied there, into the private layout -- `delta` added here, taken
     //  away again by the address sets of the other buffer)
@@ -244,7 +241,6 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
         sgm[e] = cj ? 0x80000000u : 0u;
     }
     wa[4] = delta + rec_pos(Kn, 0); wa[5] = delta + rec_pos(Kn, 1);
-    wa[6] = delta + rec2_pos(Kn, 0); wa[7] = delta + rec2_pos(Kn, 1);     // the eigenvector role's copy
     if (mrole) {                                            // caller's layout -> private layout, in the other buffer
 #pragma unroll
         for (int e = 0; e < 4; ++e) Ms[e * PS + ra[e & 1]] = Ms[e * PS + sys_pos<N>(Iu, Ju, e)];
@@ -260,7 +256,7 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
             n2 = o2;
         }
     };
-    auto round = [&](const int (&rd)[6], const int (&wr)[8]) __attribute__((always_inline)) {
+    auto round = [&](const int (&rd)[6], const int (&wr)[6]) __attribute__((always_inline)) {
         if (mrole) {
             const cplx i0 = Ms[rd[2]], i1 = Ms[rd[3]];      // (c, Re s), (Im s, a') of the row pair
             const cplx j0 = Ms[rd[4]], j1 = Ms[rd[5]];      // ... of the column pair
@@ -276,7 +272,6 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
                 cplx e0, e1, e2;
                 e0.re = n.c; e0.im = n.sr; e1.re = n.si; e1.im = n.an; e2.re = n.dn; e2.im = 0.0;
                 Ms[wr[4]] = e0; Ms[wr[5]] = e1; Ms[2 * PS + wr[4]] = e2;
-                Ms[wr[6]] = e0; Ms[wr[7]] = e1; Ms[2 * PS + wr[6]] = e2;
             }
             m00.im = flip_sign(m00.im, sgm[0]); m01.im = flip_sign(m01.im, sgm[1]);
             m10.im = flip_sign(m10.im, sgm[2]); m11.im = flip_sign(m11.im, sgm[3]);
@@ -287,7 +282,7 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
     //  of registers: with the priority here its arithmetic fills the time the matrix role waits for LDS.  1749 -> 1691 cycles per round
     //  together, 1725 / 1764 each alone)
     __builtin_amdgcn_s_setprio(3);
-    const int sweep = sweeps<6, 8>(ra, wa, -delta, red, tol2, test, round);
+    const int sweep = sweeps<6, 6>(ra, wa, -delta, red, tol2, test, round);
     __builtin_amdgcn_s_setprio(0);
     return sweep;
 }
@@ -301,14 +296,17 @@ __device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv
     const bool diag = R < 2;
     const int Kd = 2 * tau + (R & 1);
     // pivot block of pair Kd (convergence test only), the records of the thread's two pairs, the record of pair Kd; the three seats
+    // (the sixteen lanes of a ring read every second record: 2-way bank conflicts on these four loads -- off the round's chain, this
+    //  role runs a round behind; a second, conflict-free copy of the records cost the publishing wavefront three more stores ON
+    //  the chain: 1691 against 1656 cycles per round)
     int ra[7], wa[3];
     {
         const int sa = jacobi_seat<N>(2 * Kd), sd = jacobi_seat<N>(2 * Kd + 1);
         bool cj;
         ra[0] = delta + priv_slot(NUP + Kd, 0); ra[1] = delta + priv_slot(NUP + Kd, 1);
-        ra[2] = delta + rec2_pos(2 * tau, 0); ra[3] = delta + rec2_pos(2 * tau, 1);
-        ra[4] = delta + rec2_pos(2 * tau + 1, 0); ra[5] = delta + rec2_pos(2 * tau + 1, 1);
-        ra[6] = delta + rec2_pos(Kd, 0);
+        ra[2] = delta + rec_pos(2 * tau, 0); ra[3] = delta + rec_pos(2 * tau, 1);
+        ra[4] = delta + rec_pos(2 * tau + 1, 0); ra[5] = delta + rec_pos(2 * tau + 1, 1);
+        ra[6] = delta + rec_pos(Kd, 0);
         wa[0] = delta + 3 * (sa & 1) * PS + priv_slot(NUP + (sa >> 1), sa & 1);
         wa[1] = delta + 3 * (sd & 1) * PS + priv_slot(NUP + (sd >> 1), sd & 1);
         wa[2] = delta + priv_store_pos(sa, sd, cj);
@@ -327,7 +325,7 @@ __device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv
         }
     }
     FBX_BLOCK_SYNC();                                       // Vs is a matrix buffer from here on -- the one the solver starts in
-    // the pivot block of pair Kd into the private layout, and the record of the first round from it, both copies (visible behind
+    // the pivot block of pair Kd into the private layout, and the record of the first round from it (visible behind
     // the barriers of the first convergence test)
     if (diag) {
         const cplx a0 = Ms[0 * PS + sys_pos<N>(Kd, Kd, 0)], b0 = Ms[1 * PS + sys_pos<N>(Kd, Kd, 1)], d0 = Ms[3 * PS + sys_pos<N>(Kd, Kd, 1)];
@@ -335,9 +333,7 @@ __device__ __forceinline__ int vector_role(cplx* Ms, cplx* Vs, int delta, int tv
         const JRot n = jacobi_rotation(a0.re, d0.re, b0.re, b0.im);
         cplx e0, e1, e2;
         e0.re = n.c; e0.im = n.sr; e1.re = n.si; e1.im = n.an; e2.re = n.dn; e2.im = 0.0;
-        const int c1 = delta + rec_pos(Kd, 0), c1b = delta + rec_pos(Kd, 1), c2b = delta + rec2_pos(Kd, 1);
-        Ms[c1] = e0; Ms[c1b] = e1; Ms[2 * PS + c1] = e2;
-        Ms[ra[6]] = e0; Ms[c2b] = e1; Ms[2 * PS + ra[6]] = e2;
+        Ms[ra[6]] = e0; Ms[delta + rec_pos(Kd, 1)] = e1; Ms[2 * PS + ra[6]] = e2;
     }
     FBX_BLOCK_SYNC();
     double ev_a = 0.0, ev_d = 0.0;                          // (diag threads) the pair's diagonal at the last convergence test
