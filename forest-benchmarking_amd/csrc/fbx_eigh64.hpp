@@ -263,19 +263,19 @@ __device__ __forceinline__ int matrix_role(cplx* Ms, int delta, int t, double* r
             cplx m00 = Ms[0 * PS + rd[0]], m01 = Ms[1 * PS + rd[1]];
             cplx m10 = Ms[2 * PS + rd[0]], m11 = Ms[3 * PS + rd[1]];
             jacobi_apply_m(i0.re, i0.im, i1.re, j0.re, j0.im, j1.re, m00, m01, m10, m11);
-            if (owner) {
+            const cplx b = k_second ? m11 : k_last ? m00 : m01;    // (a publishing block's pivot entry is never stored mirrored)
+            m00.im = flip_sign(m00.im, sgm[0]); m01.im = flip_sign(m01.im, sgm[1]);
+            m10.im = flip_sign(m10.im, sgm[2]); m11.im = flip_sign(m11.im, sgm[3]);
+            Ms[wr[0]] = m00; Ms[wr[1]] = m01; Ms[wr[2]] = m10; Ms[wr[3]] = m11;
+            if (owner) {    // (behind the block's stores: they are on their way while the two reciprocal-square-root chains run)
                 const double dI = Ms[2 * PS + rd[2]].re, dJ = Ms[2 * PS + rd[4]].re;
                 const double a = k_second ? dI : i1.im;     // pair 1 takes the BOTTOM of pair 0
                 const double d = k_last ? j1.im : dJ;       // pair 31 takes the TOP of pair 31
-                const cplx b = k_second ? m11 : k_last ? m00 : m01;
                 const JRot n = jacobi_rotation(a, d, b.re, b.im);
                 cplx e0, e1, e2;
                 e0.re = n.c; e0.im = n.sr; e1.re = n.si; e1.im = n.an; e2.re = n.dn; e2.im = 0.0;
                 Ms[wr[4]] = e0; Ms[wr[5]] = e1; Ms[2 * PS + wr[4]] = e2;
             }
-            m00.im = flip_sign(m00.im, sgm[0]); m01.im = flip_sign(m01.im, sgm[1]);
-            m10.im = flip_sign(m10.im, sgm[2]); m11.im = flip_sign(m11.im, sgm[3]);
-            Ms[wr[0]] = m00; Ms[wr[1]] = m01; Ms[wr[2]] = m10; Ms[wr[3]] = m11;
         }
     };
     // (the matrix role is the chain of the round -- loads, update, stores, barrier; the eigenvector role below runs one round BEHIND, out
