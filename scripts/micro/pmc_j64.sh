@@ -1,6 +1,6 @@
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for b in jacobi64_bench_local jacobi64_bench jacobi64_bench_b64; do
+for b in jacobi64_bench_local jacobi64_bench; do
   $R/scripts/micro/$b 4 | tail -1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pj_$b -o pmc -- $R/scripts/micro/$b 4 > /dev/null 2>&1
   python3 - <<PY
