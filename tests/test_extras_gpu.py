@@ -36,6 +36,37 @@ def test_eigh_all_sizes(gpu, N):
     assert np.abs(wd - 3.0).max() == 0 and np.abs(vd - np.eye(N)).max() == 0
 
 
+def test_eigh_64_structured_inputs(gpu):
+    """The 64 x 64 workgroup solver (csrc/fbx_eigh64.hpp: rotations published by the thread that holds next round's pivot, records
+    and work matrix in its private LDS layout) on inputs whose pivots are special: all-zero, rank one, block diagonal with
+    repeated eigenvalues, off-diagonal entries whose squares underflow, 24 decades of dynamic range."""
+    from fbx import _lib
+    N = 64
+    rng = np.random.default_rng(64)
+    mats = [np.zeros((N, N), dtype=complex)]
+    u = rng.normal(size=N) + 1j * rng.normal(size=N)
+    mats.append(np.outer(u, u.conj()))                                            # rank one
+    blk = rng.normal(size=(8, 8)) + 1j * rng.normal(size=(8, 8)); blk = blk + blk.conj().T
+    mats.append(np.kron(np.eye(8), blk))                                          # every eigenvalue eight times
+    d = np.diag(np.arange(N, dtype=float)).astype(complex)
+    tiny = 1e-170 * (rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N)))
+    mats.append(d + tiny + tiny.conj().T)                                         # |b|^2 underflows: identity rotations
+    q, _ = np.linalg.qr(rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N)))
+    spec = np.logspace(-12, 12, N) * np.where(np.arange(N) % 3 == 0, -1.0, 1.0)
+    mats.append((q * spec) @ q.conj().T)
+    a = np.stack([0.5 * (m + m.conj().T) for m in mats])
+    w, v = _lib.eigh_batch(a)
+    assert np.isfinite(w).all() and np.isfinite(v).all()
+    assert (np.diff(w, axis=1) >= 0).all()
+    for b in range(len(mats)):
+        scale = max(1.0, np.abs(a[b]).max())
+        assert np.abs(w[b] - np.linalg.eigvalsh(a[b])).max() < 1e-12 * N * scale, b
+        assert np.abs(v[b].conj().T @ v[b] - np.eye(N)).max() < 1e-12, b
+        assert np.abs(a[b] @ v[b] - v[b] * w[b]).max() < 1e-11 * N * scale, b
+    assert np.abs(w[0]).max() == 0 and np.abs(v[0] - np.eye(N)).max() == 0        # nothing to rotate: the identity basis
+    assert np.abs(w[3] - np.arange(N)).max() < 1e-150 * N + 1e-300                  # rotations of angle ~1e-170 leave the diagonal alone
+
+
 def test_sqrtm_psd(gpu, g):
     from fbx.operator_tools import calculational as calc
     for N in (4, 16):
