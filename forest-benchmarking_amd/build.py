@@ -15,6 +15,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #                      12.85 -> 12.6 ms.  The register-starved two-wavefronts-per-SIMD kernel of fbx_pgdb_lean.hip runs at HALF
 #                      its speed with it -- hence the two translation units.
 #   fbx_pgdb3.hip      3-qubit kernel (1024-thread workgroups, 128 registers): 360.6 -> 335.0 ms per 256 reconstructions (-7 %).
+#                      Round 5, on the rebuilt solver: max-ILP 176.5, default 175.9, ITERATIVE-ILP 174.5 ms (Pauli in-basis 167.8 -> 167.0),
+#                      outputs identical -- iterative-ilp for this unit.
 #   fbx_pgdb1.hip      lane-per-item single-qubit kernel: no difference (66.4 vs 66.8 ms), default kept.
 #   fbx_pgdb_lean.hip  two-wavefronts-per-SIMD kernel (256 registers): -Os instead of -O3 (round 3: 560 instead of 664 B of scratch,
 #                      8192 items 73.2 -> 71.2 ms; round 4, after the kernel's re-layout: 66.3 against 71.5 ms -- the -O3 code of the
@@ -26,7 +28,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #                      the full-block form, as does every other unit.
 _MAX_ILP = "-mllvm -amdgpu-sched-strategy=max-ilp"
 FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", _MAX_ILP + " -DFBX_JACOBI_TWO_WORKERS").split(),
-              "fbx_pgdb3.hip": os.environ.get("FBX_PGDB3_FLAGS", _MAX_ILP).split(),
+              "fbx_pgdb3.hip": os.environ.get("FBX_PGDB3_FLAGS", "-mllvm -amdgpu-sched-strategy=iterative-ilp").split(),
               "fbx_pgdb_lean.hip": os.environ.get("FBX_PGDB_LEAN_FLAGS", "-Os -mllvm -disable-machine-licm").split()}
 
 
