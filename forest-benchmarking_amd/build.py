@@ -126,6 +126,25 @@ def build_barrier_test(verbose=True):
     return out
 
 
+def build_solver_test(verbose=True):
+    """libfbx_localrot.so: the product sources with the 3-qubit kernels' 64 x 64 eigensolver in its round-4 form (every thread
+    evaluates the rotations it applies, sys_pos layout, one column pair per eigenvector thread: -DFBX_EIGH64_LOCAL_ROTATIONS) -- only
+    loaded by tests/test_barriers_gpu.py, which requires the rebuilt solver to reproduce it bit for bit."""
+    out = os.path.join(HERE, "libfbx_localrot.so")
+    lib = build(verbose=verbose)
+    src = os.path.join(CSRC, "fbx_pgdb3.hip")
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(lib):
+        return out
+    obj = os.path.join(HERE, "build", "fbx_pgdb3.hip.localrot.o")
+    cmd = [HIPCC] + FLAGS + file_flags(src) + ["-DFBX_EIGH64_LOCAL_ROTATIONS", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs = [obj] + [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if s != src]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + MAP, "-ldl"] + objs + ["-o", out])
+    return out
+
+
 def build_variant(name, extra_flags, verbose=True):
     """Experiment builds: libfbx_<name>.so = the product objects with fbx_pgdb.hip and fbx_pgdb_lean.hip recompiled with extra
     -D flags (e.g. `python build.py --variant nosmall -DFBX_NO_SMALL_STEP`).  Not shipped, not loaded by tests."""
@@ -155,5 +174,6 @@ if __name__ == "__main__":
     if "--guard-test" in sys.argv:
         build_guard_test()
         build_barrier_test()
+        build_solver_test()
     else:
         build(force="--force" in sys.argv, profile="--profile" in sys.argv)

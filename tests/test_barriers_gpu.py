@@ -53,3 +53,18 @@ def test_lds_only_barriers_reproduce_full_barriers_bit_for_bit(gpu, tmp_path):
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
     assert (a["sic_fixed_iterations"] == 40).all() and a["sic_converge_dykstra"].min() > 100
+
+
+def test_published_rotation_solver_reproduces_the_local_one_bit_for_bit(gpu, tmp_path):
+    """Round 5 rebuilt the 64 x 64 eigensolver of the 3-qubit kernels (csrc/fbx_eigh64.hpp: rotations evaluated once and published,
+    owner-indexed LDS layout, eigenvector rings in DPP rows, the eigenvector role one round behind) without changing one operation
+    on one number: libfbx_localrot.so is the same source with the round-4 solver (-DFBX_EIGH64_LOCAL_ROTATIONS) and must agree BIT
+    FOR BIT -- estimates, counters, per-iteration traces, costs and the batched projection (replaces scipy.linalg.eigh at
+    operator_tools/project_superoperators.py:30)."""
+    if not os.path.exists(os.path.join(PKG, "libfbx_localrot.so")):
+        pytest.skip("libfbx_localrot.so not built (python forest-benchmarking_amd/build.py --guard-test)")
+    a = _run("libfbx.so", str(tmp_path / "published.npz"))
+    b = _run("libfbx_localrot.so", str(tmp_path / "local.npz"))
+    assert sorted(a.files) == sorted(b.files) and len(a.files) > 20
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
