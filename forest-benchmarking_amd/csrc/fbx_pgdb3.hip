@@ -177,23 +177,33 @@ __device__ void rotate_into_basis_mfma(Lds& L, int t) {
         L.Ms[sys_index<D>(16 * tm + g + 4 * r, colB)] = o;
     }
     FBX_BLOCK_SYNC();
+    // M' = V^H T is Hermitian and the eigensolver reads its upper block triangle only: the ten tiles (tm2 <= tn2) go to wavefronts
+    // 0-9 -- three tiles on two of the matrix-core pipes, two on the others, instead of four on each.  The six tiles below the
+    // diagonal keep T (proj_cp's norm check counts the upper tiles twice instead).
+    const bool upper = w < 10;
+    const int tm2 = w < 4 ? 0 : w < 7 ? 1 : w < 9 ? 2 : 3, tn2 = w < 4 ? w : w < 7 ? w - 3 : w < 9 ? w - 5 : 3;
+    const int colA2 = 16 * tm2 + c, colB2 = 16 * tn2 + c;
     v4d mre = {0.0, 0.0, 0.0, 0.0}, mim = {0.0, 0.0, 0.0, 0.0};
+    if (upper) {
 #pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {                   // M' = V^H T
-        const int k = 4 * ks + g;
-        const cplx v = L.Vs[sys_index<D>(k, colA)];     // conj((V^H)[colA][k])
-        const cplx q = L.Ms[sys_index<D>(k, colB)];     // T[k][colB]
-        mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v.re, q.re, mre, 0, 0, 0);
-        mim = __builtin_amdgcn_mfma_f64_16x16x4f64(v.re, q.im, mim, 0, 0, 0);
-        mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v.im, q.im, mre, 0, 0, 0);
-        mim = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.im, q.re, mim, 0, 0, 0);
+        for (int ks = 0; ks < 16; ++ks) {               // M' = V^H T
+            const int k = 4 * ks + g;
+            const cplx v = L.Vs[sys_index<D>(k, colA2)];    // conj((V^H)[colA2][k])
+            const cplx q = L.Ms[sys_index<D>(k, colB2)];    // T[k][colB2]
+            mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v.re, q.re, mre, 0, 0, 0);
+            mim = __builtin_amdgcn_mfma_f64_16x16x4f64(v.re, q.im, mim, 0, 0, 0);
+            mre = __builtin_amdgcn_mfma_f64_16x16x4f64(v.im, q.im, mre, 0, 0, 0);
+            mim = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.im, q.re, mim, 0, 0, 0);
+        }
     }
     FBX_BLOCK_SYNC();                                    // every wavefront is done reading T
+    if (upper) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * tm + g + 4 * r;
-        cplx o; o.re = mre[r]; o.im = row == colB ? 0.0 : mim[r];
-        L.Ms[sys_index<D>(row, colB)] = o;
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tm2 + g + 4 * r;
+            cplx o; o.re = mre[r]; o.im = row == colB2 ? 0.0 : mim[r];
+            L.Ms[sys_index<D>(row, colB2)] = o;
+        }
     }
     FBX_BLOCK_SYNC();
 }
@@ -310,8 +320,19 @@ __device__ __forceinline__ Blk proj_cp(const Blk& x_, Lds& L, int t_, int& sweep
         rotate_into_basis(L, Tg, t);
 #endif
         if (check_basis) {
+#ifndef FBX3_ROTATE_VALU
+            {   // (the matrix-core form leaves the tiles below the diagonal unwritten: the upper ones count twice)
+                const int ti = t / NB / 8, tj = t % NB / 8;      // tile of entry position t (the layout permutes column pairs inside aligned groups of 8 only)
+                const double wgt = ti < tj ? 2.0 : ti == tj ? 1.0 : 0.0;
+                double acc2 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * NT + t]; acc2 = fma(v.re, v.re, fma(v.im, v.im, acc2)); }
+                n2[1] = wgt * acc2;
+            }
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * NT + t]; n2[1] = fma(v.re, v.re, fma(v.im, v.im, n2[1])); }
+#endif
             bsum_multi<2>(n2, L);
             if (!(fabs(n2[1] - n2[0]) <= FBX_BASIS_NORM_TOL * n2[0])) {
                 (void)hermitise_into_ms(x, L, t, false);
