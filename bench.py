@@ -188,7 +188,7 @@ def pgdb3q_executed_flop(m, S, iters, dyk, work):
     # update 80) + 32 of them x (next round's rotation 42) + 512 eigenvector threads x (two block updates 2 x 40).  Round 4, every
     # thread evaluating the rotations it applies: 496 x 164 + 512 x 122; rounds 1-3: 1024 threads x 162
     f["jacobi_sweeps"] = sweeps * 63 * (496 * 80 + 32 * 42 + 512 * 80)
-    f["basis_change_mfma"] = dy * 2 * 64 ** 3 * 8                  # V^H H V as two dense complex 64^3 products on the fp64 matrix cores
+    f["basis_change_mfma"] = dy * (1 + 10 / 16) * 64 ** 3 * 8      # V^H H V on the fp64 matrix cores: H V in full, of V^H (H V) the ten upper tiles of sixteen
     f["reconstruct"] = terms * 1024 * 28
     f["dykstra_rest"] = dy * 1024 * 240
     f["tables_mfma"] = it * 3 * 2 * S * 64 * 64                    # T = C^T R^T (x2) and R^G = -W C^T / d^2 on the fp64 matrix cores
