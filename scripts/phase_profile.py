@@ -10,6 +10,8 @@ mode = sys.argv[2] if len(sys.argv) > 2 else 'fixed'
 design, us, e, c = synthetic.process_batch(int(os.environ.get('AB_NQ', '2')), os.environ.get('AB_BASIS', 'pauli'), B)     # AB_NQ=3 AB_BASIS=sic: the 3-qubit kernel
 _lib.set_device(0)
 lib = _lib.lib()
+if os.environ.get('AB_PIECES'):          # AB_PIECES=1: whole reconstructions in the two-waves kernel (its phase timers do not follow pieces)
+    _lib.set_option('pgdb_pieces', float(os.environ['AB_PIECES']))
 buf = _lib.DeviceBuffer(B * 8 * 8)
 lib.fbx_debug_set_phase_buffer.argtypes = [ctypes.c_void_p]
 lib.fbx_debug_set_phase_buffer(buf.ptr)
