@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=16,
                     help="items run through the oracle for cpu_baseline, its reference-faithful and multi-core variants and "
                          "the parity self-check (0 = skip every CPU leg; ~25 s of one core at the default)")
-    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "sweep3", "pgdb3", "pgdb1"],
+    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "sweep3", "pgdb3", "pgdb1", "mle_state", "mle_state3"],
                     help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "
                          "sweep / pgdb3 / pgdb1 = that workload as the primary line")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
@@ -73,6 +73,9 @@ def parse():
                          "GPU -- the same-workload anchor of the 1/2/4/8-GPU strong-scaling curve (0 = skip)")
     ap.add_argument("--spawn-timeout", type=float, default=1800.0,
                     help="seconds the self-spawned ranks (--gpus > 1 without a launcher) may take before they are killed")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the FULL record goes (every leg with its notes); stdout carries one short line per leg and, last, "
+                         "the compact headline the driver parses")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing: allow more ranks than visible GPUs (ranks share devices; host-file barrier)")
     return ap.parse_args()
@@ -136,6 +139,15 @@ def _profiled(key):
     """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
+def _measured_mfma_flop(kernel, items):
+    """fp64 MFMA operations of one launch counted by the hardware (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512), per item, or None."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_flops.json")))[f"{kernel}@{items}"]
+        return float(rec["mfma_flop"]) / float(rec["items_per_launch"])
     except Exception:
         return None
 
@@ -390,7 +402,7 @@ def run_sweep(args, comm, _lib, synthetic, with_cpu, n=2):
     ksec = kms / 1e3 / args.steps
     gbs = B * bytes_item / ksec / 1e9
     fid = d_f.to_array(np.float64, (min(B, 4096),))
-    line = {"metric": f"conversion sweep items/sec ({n}-qubit Kraus -> Choi -> PTM -> chi + process_fidelity)",
+    line = {"tag": f"sweep_{n}q", "metric": f"conversion sweep items/sec ({n}-qubit Kraus -> Choi -> PTM -> chi + process_fidelity)",
             "value": comm.world * B * args.steps / elapsed, "unit": "items/s", "n_gpus": comm.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -445,7 +457,8 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
     tflops = B * flop / ksec / 1e12
     ex, parts = pgdb3q_executed_flop(m, design.n_states, its, dyk, work)
     meas = _measured_flop("pgdb3_kernel<4>" if basis == "sic" else "pgdb3_kernel<14>", B)
-    line = {"metric": "process-tomography MLE reconstructions/sec (3-qubit, 64x64 Choi, 100 iters)",
+    mfma_meas = _measured_mfma_flop("pgdb3_kernel<4>" if basis == "sic" else "pgdb3_kernel<14>", B)
+    line = {"tag": f"pgdb_3q_{basis}", "metric": "process-tomography MLE reconstructions/sec (3-qubit, 64x64 Choi, 100 iters)",
             "value": comm.world * B * steps / elapsed, "unit": "reconstructions/s", "n_gpus": comm.world,
             "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -462,6 +475,8 @@ def run_pgdb3(args, comm, _lib, synthetic, with_cpu):
                          "unit": "TFLOP/s", "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
                          "executed_flop_measured": meas,
                          "measured_frac": (B * meas / ksec / 1e12 / FP64_PEAK_TFLOPS) if meas else None,
+                         "mfma_frac": B * (mfma_meas if mfma_meas else parts["basis_change_mfma"] + parts["tables_mfma"]) / ksec / 1e12 / FP64_PEAK_TFLOPS,
+                         "mfma_frac_source": "hardware count (profiles/pmc_flops.json)" if mfma_meas else "work-counter model",
                          "traffic": _profiled("pgdb3_kernel_hbm_bytes_per_launch" if basis == "sic" else "pgdb3pauli_kernel_hbm_bytes_per_launch"),
                          "kernel": "pgdb3_kernel", "kernel_ms": 1e3 * ksec,
                          "executed_flop": ex, "executed_breakdown": {k: round(v) for k, v in parts.items()},
@@ -507,7 +522,7 @@ def run_pgdb1(args, comm, _lib, synthetic, with_cpu):
     # cost evaluation 2 m x 45 + 32 S; a gradient 2 m x 30 + 64 S; a power-sum pass 2 m x 40; three Pauli transforms of 130
     ex = float(np.mean(work[:, 0] * 1080.0 + dyk * (1350.0 + 700.0) + work[:, 2] * (90.0 * m + 32.0 * S)
                        + its * (60.0 * m + 64.0 * S + 390.0) + work[:, 3] * 80.0 * m))
-    line = {"metric": "process-tomography MLE reconstructions/sec (1-qubit, to convergence)",
+    line = {"tag": "pgdb_1q", "metric": "process-tomography MLE reconstructions/sec (1-qubit, to convergence)",
             "value": comm.world * B * steps / elapsed, "unit": "reconstructions/s", "n_gpus": comm.world,
             "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -538,6 +553,87 @@ def run_pgdb1(args, comm, _lib, synthetic, with_cpu):
         line["cpu_baseline"] = {"value": n / dt, "unit": "reconstructions/s", "cores": 1, "kind": "port",
                                 "sample": f"first {n} experiments to convergence, numpy oracle with the design matrix hoisted, {dt:.1f} s"}
     for buf in (d_e, d_c, d_choi, d_it, d_dy, d_w):
+        buf.free()
+    return line
+
+
+def mle_state_executed_flop(n, m, updates):
+    """fp64 operations one state reconstruction executes per the source (csrc/fbx_state.hip, fma = 2, a division ~ 10): per
+    update Pauli expectations D x d x 2, per setting two guarded ratios + the weights ~ 40, synthesis D x d, two d x d complex
+    products 2 x 8 d^3, the complex division by the trace ~ 30 per entry, the step norm 6 per entry."""
+    d = 2 ** n
+    D = d * d
+    return updates * (2 * D * d + 40 * m + D * d + 16 * d ** 3 + 36 * D)
+
+
+def run_mle_state(args, comm, _lib, synthetic, with_cpu, n=2):
+    """The state-estimator half of north_star: iterative_mle_state_estimate (tomography.py:168-270, _R :273-338) with the
+    reference's defaults (epsilon 0.1, tol 1e-9) and maxiter = 100 -- 99 updates, the configuration of BASELINE.md section 2's
+    CPU probes (80 ms / 0.45 s per 2- / 3-qubit state) -- on a large resident batch: 4096 distinct experiments of the SURVEY 8d
+    recipe (Haar pure state mixed 5 % with I/d, 1000 shots per setting), tiled."""
+    distinct = 4096
+    B = {1: 1 << 21, 2: 1 << 20, 3: 1 << 18}[n]
+    design, _, e0, c0 = synthetic.state_batch(n, distinct, first_item=distinct * comm.rank, mixed=0.05)
+    reps = B // distinct
+    lib = _lib.lib()
+    d = 2 ** n
+    d_e, d_c = _lib.DeviceBuffer.from_array(np.tile(e0, (reps, 1))), _lib.DeviceBuffer.from_array(np.tile(c0, (reps, 1)))
+    d_rho, d_it, d_hit = _lib.DeviceBuffer(B * d * d * 16), _lib.DeviceBuffer(B * 4), _lib.DeviceBuffer(B * 4)
+    maxiter = args.iters
+
+    def step():
+        _lib.check(lib.fbx_mle_state_dev(design.handle, B, d_e.ptr, d_c.ptr, 0.1, 0.0, 0.0, 1e-9, maxiter,
+                                         d_rho.ptr, d_it.ptr, d_hit.ptr))
+
+    steps = max(1, min(args.steps, 10))
+    elapsed, kms = timed_steps(step, steps, min(args.warmup, 2), comm, _lib)
+    its = d_it.to_array(np.int32, (B,))[:distinct]
+    rho = d_rho.to_array(np.complex128, (distinct, d, d))
+    ksec = kms / 1e3 / steps
+    m = design.m
+    # the iteration counter starts at 1 and the cap check precedes the update (tomography.py:241-246): min(its, maxiter - 1) updates
+    ex = mle_state_executed_flop(n, m, float(np.mean(np.minimum(its, maxiter - 1))))
+    kernel = {1: "mle_state_packed_kernel<1>", 2: "mle_state_packed_kernel<2>", 3: "mle_state_kernel<3>"}[n]
+    meas = _measured_flop(kernel, B)
+    algo_bytes = 2 * m * 8 + d * d * 16 + 8
+    line = {"tag": f"mle_state_{n}q",
+            "metric": f"state-tomography iterative-MLE reconstructions/sec ({n}-qubit, maxiter {maxiter})",
+            "value": comm.world * B * steps / elapsed, "unit": "reconstructions/s", "n_gpus": comm.world,
+            "steps": steps, "warmup": min(args.warmup, 2), "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{B} {n}-qubit state tomographies per GPU ({distinct} distinct experiments x {reps}: Haar pure "
+                                   f"state mixed 5 % with I/d, {m} Pauli settings, 1000 shots), iterative_mle_state_estimate defaults "
+                                   f"(epsilon 0.1, tol 1e-9) with maxiter {maxiter} = {maxiter - 1} updates, inputs resident in HBM",
+                       "batch_per_gpu": B, "iters": maxiter, "parallelism": f"shard{comm.world}",
+                       "mean_outer_iters": float(its.mean()), "max_outer_iters": int(its.max()),
+                       "max_trace_error": float(np.abs(np.trace(rho, axis1=1, axis2=2) - 1).max())},
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU through LDS round trips (no MFMA: d <= 8)",
+                         "achieved": B * ex / ksec / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": B * ex / ksec / 1e12 / FP64_PEAK_TFLOPS,
+                         "executed_flop": ex, "executed_flop_measured": meas,
+                         "measured_frac": (B * meas / ksec / 1e12 / FP64_PEAK_TFLOPS) if meas else None, "mfma_frac": 0.0,
+                         "traffic": _profiled(f"mle_state{n}_kernel_hbm_bytes_per_launch"),
+                         "kernel": kernel, "kernel_ms": 1e3 * ksec,
+                         "hbm": {"achieved": B * algo_bytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": B * algo_bytes / ksec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": B * algo_bytes},
+                         "note": "executed flops per reconstruction from the source (fma = 2, division ~ 10) x batch / HIP-event kernel "
+                                 "time; a dependent chain of ~8 LDS round trips per update bounds it, not the fp64 pipe (DESIGN.md 4.7)"}}
+    if with_cpu and comm.rank == 0:
+        od, oe, _, _ = _oracle()
+        dd = od.Design(design.n_qubits, design.kind, design.in_labels, design.paulis, design.coefs)
+        import warnings
+        k, t0, dev = 0, time.perf_counter(), 0.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            while k < 64 and time.perf_counter() - t0 < max(3.0, args.cpu_sample / 3):
+                want = oe.iterative_mle_state_estimate(dd, e0[k], c0[k], maxiter=maxiter)
+                dev = max(dev, float(np.abs(want - rho[k]).max()))
+                k += 1
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": k / dt, "unit": "reconstructions/s", "cores": 1, "kind": "port",
+                                "sample": f"first {k} experiments, numpy oracle, maxiter {maxiter}, {dt:.1f} s"}
+        line["config"]["max_abs_diff_vs_oracle"] = dev
+    for buf in (d_e, d_c, d_rho, d_it, d_hit):
         buf.free()
     return line
 
@@ -595,6 +691,7 @@ def pgdb_roofline(batch, st, kernel_s, iters):
     algo_bytes = 2 * m * 8 + 4096
     kernel = ("pgdb_lean_pieces_kernel" if B > 1024 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
     measured = _measured_flop(kernel, B)
+    mfma_measured = _measured_mfma_flop(kernel, B)
     out = {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": B * ex / kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": B * ex / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
            "traffic": _profiled({1024: "pgdb_kernel_hbm_bytes_per_launch", 8192: "pgdb_lean8192_hbm_bytes_per_launch",
@@ -603,6 +700,10 @@ def pgdb_roofline(batch, st, kernel_s, iters):
            "executed_flop": ex, "executed_breakdown": {k: round(v) for k, v in parts.items()},
            "executed_flop_measured": measured,
            "measured_frac": (B * measured / kernel_s / 1e12 / FP64_PEAK_TFLOPS) if measured else None,
+           # MFMA utilisation AS a utilisation: matrix-core flops / the dense fp64 MFMA peak / kernel time (<= 1 by construction)
+           "mfma_frac": B * (mfma_measured if mfma_measured else parts["basis_change_mfma"]) / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
+           "mfma_frac_source": "hardware count (profiles/pmc_flops.json)" if mfma_measured else "work-counter model",
+           "note_short": "executed fp64 flops (work counters x per-unit source counts; measured_frac = hardware count) / kernel time / 78.6 TFLOP/s; mfma_frac = matrix-core share",
            "dense_accounting_tflops": dense, "dense_accounting_frac": dense / FP64_PEAK_TFLOPS,
            "note": "PGDB is fp64-compute / latency bound (SURVEY.md 8d).  achieved / frac = flops the kernel really executes "
                    "per reconstruction (work counters: Jacobi sweeps, eigenvalue terms, cost evaluations; x per-unit counts "
@@ -818,6 +919,147 @@ def single_gpu_extras(args, comm, _lib, synthetic, batch, line):
             {k: f[k] for k in ("mode", "items", "share_le_1e-9", "share_le_1e-8", "max_abs_choi_diff", "max_process_fidelity_diff")} for f in fx]
 
 
+# ================================================================================== output
+# What the driver keeps of a run is the tail of stdout, and it parses the LAST line.  Round 5's single 20 KB line outgrew
+# that; since round 6 the full record goes to gpurun_out/bench_detail.json, every secondary workload is printed as its own
+# short line FIRST, and the last stdout line is the compact headline object (< 4 KB; tests/test_bench_line.py).
+HEADLINE_MAX_BYTES = 4096
+_ROOFLINE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "measured_frac", "mfma_frac", "traffic", "kernel", "kernel_ms")
+
+
+def _sig(x, digits=6):
+    """floats to `digits` significant digits, recursively (a bench line is read by people and size-capped)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if np.isfinite(x) else None
+    if isinstance(x, (np.floating,)):
+        return _sig(float(x), digits)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3].rstrip() + "..."
+
+
+def compact_roofline(r):
+    out = _pick(r, _ROOFLINE_KEEP)
+    if r and "traffic" in r and "traffic" not in out:
+        out["traffic"] = None
+    return out
+
+
+def compact_cpu(c, sample_chars=120):
+    out = _pick(c, ("value", "unit", "cores", "kind"))
+    if c and "sample" in c:
+        out["sample"] = _short(c["sample"], sample_chars)
+    return out
+
+
+def compact_secondary(line):
+    """one short stdout line per secondary workload: what it is, its rate, its roofline, its CPU baseline"""
+    cfg = line.get("config", {})
+    out = {"detail": line.get("tag", "secondary"), "metric": line["metric"], "value": line["value"], "unit": line["unit"],
+           "n_gpus": line.get("n_gpus", 1), "steps": line.get("steps"), "warmup": line.get("warmup"),
+           "ms_per_step": line.get("ms_per_step"), "dtype": line.get("dtype", "f64"),
+           "config": {"workload": _short(cfg.get("workload", ""), 200),
+                      **_pick(cfg, ("batch_per_gpu", "items_per_gpu", "iters", "mean_outer_iters", "mean_dykstra_iters",
+                                    "mean_jacobi_sweeps"))},
+           "roofline": compact_roofline(line.get("roofline"))}
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = compact_cpu(line["cpu_baseline"])
+    return _sig(out)
+
+
+def compact_headline(line):
+    """The LAST stdout line: the bench contract's keys + `roofline` + `cpu_baseline`, with everything the driver's record should
+    keep folded into `config` as bare numbers.  Always < HEADLINE_MAX_BYTES."""
+    cfg = line.get("config", {})
+    c = {"workload": _short(cfg.get("workload", ""), 260),
+         **_pick(cfg, ("batch_per_gpu", "items_per_gpu", "total_batch", "iters", "parallelism", "device", "compute_units",
+                       "mean_outer_iters", "mean_dykstra_iters", "mean_backtracks", "mean_jacobi_sweeps",
+                       "mean_fidelity_to_cnot", "max_outer_iters"))}
+    if isinstance(cfg.get("collectives"), dict):
+        c["collectives"] = _pick(cfg["collectives"], ("backend", "ranks", "rccl_version"))
+    if "transfer_inclusive" in cfg:
+        c["transfer_inclusive"] = _pick(cfg["transfer_inclusive"], ("value", "ms_per_call", "fraction_of_resident"))
+    if "converge_mode" in line:
+        c["converge_mode"] = _pick(line["converge_mode"], ("value", "ms_per_step", "mean_outer_iters"))
+    if "cpu_reference_faithful_1core" in cfg:
+        c["cpu_reference_faithful_1core"] = _pick(cfg["cpu_reference_faithful_1core"], ("value",))
+    if "cpu_multicore" in cfg:
+        c["cpu_multicore"] = _pick(cfg["cpu_multicore"], ("value", "cores"))
+    if "parity_vs_reference_fixtures" in cfg:
+        c["parity_vs_reference_fixtures"] = [
+            {"mode": "fixed100" if f["mode"].startswith("fixed") else "converge", "items": f["items"],
+             "le_1e-9": f["share_le_1e-9"], "le_1e-8": f["share_le_1e-8"], "max_choi": f["max_abs_choi_diff"],
+             "max_fidelity": f["max_process_fidelity_diff"]} for f in cfg["parity_vs_reference_fixtures"]]
+    for key, val in line.items():
+        if key.startswith("strong_") and isinstance(val, dict):
+            c[key] = {**_pick(val, ("value", "ms_per_step", "kernel_ms")),
+                      **{k: v for k, v in compact_roofline(val.get("roofline")).items() if k in ("frac", "measured_frac", "mfma_frac")}}
+            c["multi_gpu_expectation"] = ("extrapolation: each of N ranks runs its 65536/N share at the one-GPU rate of that share "
+                                          "(no data-path collective); no multi-GPU lease has run it")
+    if "per_gpu_1024" in line:
+        c["per_gpu_1024"] = _pick(line["per_gpu_1024"], ("value", "ms_per_step", "kernel_ms"))
+    if "secondary" in line:
+        c["secondary"] = {s.get("tag", _short(s["metric"], 60)): {"value": s["value"], **_pick(compact_roofline(s.get("roofline")), ("frac",))}
+                          for s in line["secondary"]}
+    c["detail"] = "earlier stdout lines + gpurun_out/bench_detail.json"
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data") if k in line}
+    out["config"] = c
+    out["roofline"] = compact_roofline(line.get("roofline"))
+    if line.get("roofline", {}).get("note"):
+        out["roofline"]["note"] = _short(line["roofline"]["note_short"] if "note_short" in line["roofline"] else line["roofline"]["note"], 160)
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = compact_cpu(line["cpu_baseline"], 160)
+    out = _sig(out)
+    # belt and braces: drop the optional parts, largest first, until the line fits
+    for victim in ("secondary", "multi_gpu_expectation", "collectives", "cpu_multicore", "converge_mode"):
+        if len(json.dumps(out)) < HEADLINE_MAX_BYTES:
+            break
+        out["config"].pop(victim, None)
+    return out
+
+
+def emit(line, stream=None, detail_out=None):
+    """Full record -> gpurun_out/bench_detail.json; per-workload detail lines; the compact headline LAST."""
+    stream = stream or sys.stdout
+    detail_out = detail_out or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(detail_out), exist_ok=True)
+        with open(detail_out, "w") as fh:
+            json.dump(line, fh)
+    except OSError:
+        pass
+    for sec in line.get("secondary", []):
+        print(json.dumps(compact_secondary(sec)), file=stream)
+    for key in ("parity_vs_reference_fixtures", "parity_self_check", "pcie_inclusive", "single_experiment_latency_ms"):
+        if key in line:
+            print(json.dumps(_sig({"detail": key, "data": line[key]})), file=stream)
+    for key, val in line.items():
+        if key.startswith("strong_") and isinstance(val, dict):
+            d = {"detail": key, **_pick(val, ("value", "unit", "n_gpus", "scaling", "steps", "warmup", "ms_per_step", "kernel_ms",
+                                              "mean_dykstra_iters", "mean_jacobi_sweeps")),
+                 "workload": _short(val.get("workload", ""), 200), "roofline": compact_roofline(val.get("roofline")),
+                 "pcie_inclusive": val.get("pcie_inclusive")}
+            print(json.dumps(_sig(d)), file=stream)
+    head = compact_headline(line)
+    text = json.dumps(head)
+    assert len(text) < HEADLINE_MAX_BYTES, len(text)
+    print(text, file=stream, flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -863,6 +1105,8 @@ def main():
         line = run_pgdb3(args, comm, _lib, synthetic, with_cpu)
     elif args.workload == "pgdb1":
         line = run_pgdb1(args, comm, _lib, synthetic, with_cpu)
+    elif args.workload in ("mle_state", "mle_state3"):
+        line = run_mle_state(args, comm, _lib, synthetic, with_cpu, n=2 if args.workload == "mle_state" else 3)
     else:
         secondary = []
         if args.workload == "all" and comm.world == 1:
@@ -874,6 +1118,8 @@ def main():
             args.in_basis = "pauli"                          # the stretch form of configs[3]: 13 608 settings
             secondary.append(run_pgdb3(args, comm, _lib, synthetic, False))
             secondary.append(run_pgdb1(args, comm, _lib, synthetic, with_cpu))
+            secondary.append(run_mle_state(args, comm, _lib, synthetic, with_cpu, n=2))
+            secondary.append(run_mle_state(args, comm, _lib, synthetic, with_cpu, n=3))
             args.in_basis = basis
             _lib.release_workspace()
         line, batch = run_pgdb(args, comm, _lib, synthetic, rank_info)
@@ -892,7 +1138,7 @@ def main():
     if rdzv is not None:
         rdzv.close()
     if comm.rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line, detail_out=args.detail_out)
 
 
 if __name__ == "__main__":

@@ -62,6 +62,111 @@ __global__ void debug_log_kernel(const double* x, double* out, long long n) {
 }
 #endif
 
+// _cost / _grad_cost (tomography.py:597-633) as functions of their own: ONE evaluation of the negative log-likelihood and of its
+// gradient at a given Choi matrix, with the very device functions the reconstruction kernels use -- Choi -> Pauli coefficients
+// (choi_to_pauli_real), T = R C (predict_table), the clipped probabilities and fast_log_pos, the per-state weights through LDS
+// atomics, R^G = -(W C^T) / d^2 and the inverse transform (pauli_real_to_choi_blk) -- so that the gradient, which the reconstruction
+// never outputs, can be held against the oracle directly (tests/test_cost_grad_gpu.py).  `nvec` is the reference's `n`: row 2 k /
+// 2 k + 1 = normalised +1 / -1 counts of result k.  Any number of settings (the outcome slots are walked from HBM).
+template <int NQ>
+__global__ void __launch_bounds__(64)
+pgdb_cost_grad_kernel(DesignDev des, long long B, const double* __restrict__ nvec, const double* __restrict__ choi_in, double eps,
+                      double* __restrict__ cost_out, double* __restrict__ grad_out) {
+    constexpr int d = 1 << NQ, D = d * d, LD = D + 1, NB = D / 2, NACT = NB * NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const long long item = blockIdx.x;
+    const int m = des.m, S = des.S;
+    PgdbLds<NQ, false> L;
+    L.carve(smem, S, 0);
+    for (int idx = lane; idx < D * S; idx += 64) L.Cl[(idx % S) * D + idx / S] = des.C[idx];     // des.C is [D][S]
+    Blk est = blk_zero();
+    if (lane < NACT) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+            const double* o = choi_in + ((item * D + row) * D + col) * 2;
+            est.re[e] = o[0]; est.im[e] = o[1];
+        }
+    }
+    FBX_WAVE_SYNC();
+    blk_store<D, LD>(L.choi.Mw, lane, est);
+    FBX_WAVE_SYNC();
+    choi_to_pauli_real<NQ>(L.choi.Mw, L.Rb, lane);
+    FBX_WAVE_SYNC();
+    predict_table<NQ>(L.Rb, L.Cl, L.Test, S, lane);
+    double* Wt = L.Tupd;                        // [S][D]
+    for (int idx = lane; idx < D * S; idx += 64) Wt[idx] = 0.0;
+    FBX_WAVE_SYNC();
+    const double half_dd = 0.5 / (double)(d * d);
+    const bool unit_coefs = des.unit_coefs != 0;
+    const double* nv = nvec + item * 2 * m;
+    double acc = 0.0;
+    for (int g = lane; g < m; g += 64) {
+        const uint32_t dw = des.sp[g];
+        const int st = dw >> 16, p = dw & 0xffff, k = des.order[g];
+        const double cf = unit_coefs ? 1.0 : des.coef[g];
+        const double tr = L.Test[st * D], ex = cf * L.Test[st * D + p];
+        double pp = (tr + ex) * half_dd, pm = (tr - ex) * half_dd;
+        pp = pp < eps ? eps : pp; pm = pm < eps ? eps : pm;
+        const double np_ = nv[2 * k], nm_ = nv[2 * k + 1];
+        acc -= np_ * fast_log_pos(pp) + nm_ * fast_log_pos(pm);
+        const double ep = np_ / pp, em = nm_ / pm;
+        atomicAdd(&Wt[st * D], 0.5 * (ep + em));
+        atomicAdd(&Wt[st * D + p], cf * 0.5 * (ep - em));
+    }
+    acc = uniform(wave_sum(acc));
+    if (lane == 0 && cost_out) cost_out[item] = acc;
+    FBX_WAVE_SYNC();
+    if (!grad_out) return;
+    {
+        constexpr int JB = (D * D + 63) / 64;
+        const int i = lane % D, j0 = (lane / D) * JB;
+        if (j0 < D) {
+            double a[JB];
+#pragma unroll
+            for (int r = 0; r < JB; ++r) a[r] = 0.0;
+            for (int st = 0; st < S; ++st) {
+                const double w = Wt[st * D + i];
+#pragma unroll
+                for (int r = 0; r < JB; ++r) a[r] = fma(w, L.Cl[st * D + j0 + r], a[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < JB; ++r) L.Rb[(j0 + r) * D + i] = -a[r] / (double)(d * d);
+        }
+    }
+    FBX_WAVE_SYNC();
+    const Blk grad = pauli_real_to_choi_blk<NQ>(L.Rb, L.choi.Mw, lane);
+    if (lane < NACT) {
+        const int I = lane / NB, J = lane % NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+            double* o = grad_out + ((item * D + row) * D + col) * 2;
+            o[0] = grad.re[e]; o[1] = grad.im[e];
+        }
+    }
+}
+
+int pgdb3_cost_grad_launch(const fbx_design* des, int64_t B, const double* nvec, const double* choi, double eps, double* cost,
+                           double* grad);     // fbx_pgdb3.hip
+
+template <int NQ>
+static int launch_cost_grad(const fbx_design* des, int64_t B, const double* nvec, const double* choi, double eps, double* cost,
+                            double* grad) {
+    const size_t lds = PgdbLds<NQ, false>::bytes(des->dev.S, 0);
+    if (lds > 160 * 1024) {
+        set_error("fbx_pgdb_cost_grad: too many distinct input states for the LDS-resident tables");
+        return FBX_ERR_UNSUPPORTED;
+    }
+    FBX_HIP(hipFuncSetAttribute((const void*)pgdb_cost_grad_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((pgdb_cost_grad_kernel<NQ>), dim3((unsigned)B), dim3(64), lds, stream(), des->dev, (long long)B, nvec, choi, eps,
+                       cost, grad);
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 constexpr int BASIS_CAP = 32;              // Dykstra iterations per projection that get a stored basis
 
 #ifdef FBX_DIAGNOSTICS
@@ -477,6 +582,49 @@ staged:
     if (cost_out) FBX_HIP(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
     if (work_out) FBX_HIP(hipMemcpyAsync(work_out, dsw.p, sizeof(int32_t) * 4 * B, hipMemcpyDeviceToHost, stream()));
     if (trace_bytes) FBX_HIP(hipMemcpyAsync(trace_out, dtr.p, trace_bytes, hipMemcpyDeviceToHost, stream()));
+    FBX_HIP(hipStreamSynchronize(stream()));
+    return FBX_OK;
+}
+
+// _cost / _grad_cost (tomography.py:597-633); include/fbx.h
+int fbx_pgdb_cost_grad_dev(const fbx_design* design, int64_t B, const double* d_nvec, const double* d_choi_in, double eps,
+                           double* d_cost_out, double* d_grad_out) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    { const int r = check_design(design, "fbx_pgdb_cost_grad"); if (r) return r; }
+    FBX_REQUIRE(design->dev.kind == FBX_KIND_PROCESS, "fbx_pgdb_cost_grad: needs a process design");
+    FBX_REQUIRE(B >= 0, "fbx_pgdb_cost_grad: negative batch");
+    FBX_REQUIRE(B == 0 || (d_nvec && d_choi_in && (d_cost_out || d_grad_out)), "fbx_pgdb_cost_grad: NULL buffer");
+    FBX_REQUIRE(eps >= 0.0, "fbx_pgdb_cost_grad: eps must be a non-negative number");      // (also rejects NaN)
+    if (B == 0) return FBX_OK;
+    switch (design->dev.n) {
+        case 1: return launch_cost_grad<1>(design, B, d_nvec, d_choi_in, eps, d_cost_out, d_grad_out);
+        case 2: return launch_cost_grad<2>(design, B, d_nvec, d_choi_in, eps, d_cost_out, d_grad_out);
+        case 3: return pgdb3_cost_grad_launch(design, B, d_nvec, d_choi_in, eps, d_cost_out, d_grad_out);
+    }
+    set_error("fbx_pgdb_cost_grad: process designs of 1 to 3 qubits");
+    return FBX_ERR_UNSUPPORTED;
+}
+
+int fbx_pgdb_cost_grad(const fbx_design* design, int64_t B, const double* nvec, const double* choi_in, double eps,
+                       double* cost_out, double* grad_out) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    { const int r = check_design(design, "fbx_pgdb_cost_grad"); if (r) return r; }
+    FBX_REQUIRE(B >= 0, "fbx_pgdb_cost_grad: negative batch");
+    FBX_REQUIRE(B == 0 || (nvec && choi_in && (cost_out || grad_out)), "fbx_pgdb_cost_grad: NULL buffer");
+    if (B == 0) return FBX_OK;
+    const size_t m = design->dev.m, DD = (size_t)design->dev.D * design->dev.D;
+    DevBuf dn, dchoi, dcost, dgrad;
+    if ((rc = dn.alloc(sizeof(double) * 2 * B * m)) || (rc = dchoi.alloc(sizeof(double) * 2 * B * DD)) ||
+        (rc = dcost.alloc(sizeof(double) * B)) || (grad_out && (rc = dgrad.alloc(sizeof(double) * 2 * B * DD))))
+        return rc;
+    FBX_HIP(hipMemcpyAsync(dn.p, nvec, sizeof(double) * 2 * B * m, hipMemcpyHostToDevice, stream()));
+    FBX_HIP(hipMemcpyAsync(dchoi.p, choi_in, sizeof(double) * 2 * B * DD, hipMemcpyHostToDevice, stream()));
+    rc = fbx_pgdb_cost_grad_dev(design, B, dn.as<double>(), dchoi.as<double>(), eps, dcost.as<double>(), grad_out ? dgrad.as<double>() : nullptr);
+    if (rc) { (void)hipStreamSynchronize(stream()); return rc; }
+    if (cost_out) FBX_HIP(hipMemcpyAsync(cost_out, dcost.p, sizeof(double) * B, hipMemcpyDeviceToHost, stream()));
+    if (grad_out) FBX_HIP(hipMemcpyAsync(grad_out, dgrad.p, sizeof(double) * 2 * B * DD, hipMemcpyDeviceToHost, stream()));
     FBX_HIP(hipStreamSynchronize(stream()));
     return FBX_OK;
 }

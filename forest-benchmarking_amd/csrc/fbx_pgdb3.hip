@@ -954,6 +954,126 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     return FBX_OK;
 }
 
+// _cost / _grad_cost (tomography.py:597-633) for 3 qubits as a function of their own (fbx_pgdb_cost_grad; the 1- / 2-qubit form and
+// the reasons are in fbx_pgdb.hip): one evaluation with the device functions of pgdb3_kernel -- choi_to_pauli, the matrix-core
+// table product, the run-wise deterministic identity row of W, gradient_coefficients, pauli_to_choi.  Any number of settings:
+// thread t owns the contiguous run [t MJ, (t + 1) MJ) of the state-grouped settings, MJ = ceil(m / 1024) at run time; eta = n / p
+// waits in `eta` (HBM, [2 m] per item) between the pass that consumes the table and the pass that fills W in its place.
+__global__ void __launch_bounds__(1024)
+pgdb3_cost_grad_kernel(DesignDev des, long long B, const double* __restrict__ nvec, const double* __restrict__ choi_in, double eps,
+                       double* __restrict__ cost_out, double* __restrict__ grad_out, double* __restrict__ eta) {
+    using namespace p3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds L; L.carve(smem);
+    PhaseClock pc; pc.reset(); L.pc = &pc;
+    const int t = threadIdx.x;
+    const long long item = blockIdx.x;
+    const int m = des.m, S = des.S, MJ = (m + NT - 1) / NT;
+    const bool unit_coefs = des.unit_coefs != 0;
+    const double half_dd = 0.5 / (double)(d * d);
+    const int I = t / NB, J = t % NB;
+    Blk est;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+        const double* o = choi_in + ((item * D + row) * D + col) * 2;
+        est.re[e] = o[0]; est.im[e] = o[1];
+    }
+    choi_to_pauli(est, L, t);
+    predict_table(des, L, t);
+    const double* nv = nvec + item * 2 * m;
+    double* et = eta + item * 2 * m;
+    double acc = 0.0;
+    for (int j = 0; j < MJ; ++j) {
+        const int g = t * MJ + j;
+        if (g < m) {
+            const uint32_t w = des.sp[g];
+            const int s = w >> 16, p = w & 0xffff, k = des.order[g];
+            const double cf = unit_coefs ? 1.0 : des.coef[g];
+            const double tr = L.T[s * D], ex = cf * L.T[s * D + p];
+            double pp = (tr + ex) * half_dd, pm = (tr - ex) * half_dd;
+            pp = pp < eps ? eps : pp; pm = pm < eps ? eps : pm;
+            const double np_ = nv[2 * k], nm_ = nv[2 * k + 1];
+            acc -= np_ * fast_log_pos(pp) + nm_ * fast_log_pos(pm);
+            et[2 * g] = np_ / pp; et[2 * g + 1] = nm_ / pm;
+        }
+    }
+    acc = bsum(acc, L);
+    if (t == 0 && cost_out) cost_out[item] = acc;
+    if (!grad_out) return;
+    FBX_BLOCK_SYNC();                              // T fully consumed
+    double* W = L.T;
+    double* pfirst = L.Rt + 768;                  // overlays R (dead here), past the small scratch
+    double* plast = pfirst + NT;
+    int* sfirst = (int*)(plast + NT);
+    int* slast = sfirst + NT;
+    for (int idx = t; idx < D * S; idx += NT) W[idx] = 0.0;
+    sfirst[t] = -1; slast[t] = -1; pfirst[t] = 0.0; plast[t] = 0.0;
+    FBX_BLOCK_SYNC();
+    {
+        int run_state = -1; double run = 0.0; bool first_done = false;
+        for (int j = 0; j < MJ; ++j) {
+            const int g = t * MJ + j;
+            if (g < m) {
+                const uint32_t w = des.sp[g];
+                const int s = w >> 16, p = w & 0xffff;
+                const double cf = unit_coefs ? 1.0 : des.coef[g];
+                const double ep = et[2 * g], em = et[2 * g + 1];      // (written by this very thread)
+                atomicAdd(&W[p * S + s], cf * 0.5 * (ep - em));
+                if (s != run_state) {
+                    if (run_state >= 0) {
+                        if (!first_done) { pfirst[t] = run; sfirst[t] = run_state; first_done = true; }
+                        else atomicAdd(&W[run_state], run);
+                    }
+                    run_state = s; run = 0.0;
+                }
+                run += 0.5 * (ep + em);
+            }
+        }
+        if (run_state >= 0) {
+            if (!first_done) { pfirst[t] = run; sfirst[t] = run_state; }
+            else { plast[t] = run; slast[t] = run_state; }
+        }
+    }
+    FBX_BLOCK_SYNC();
+    for (int s = t; s < S; s += NT) {
+        const int g0 = des.sptr[s], g1 = des.sptr[s + 1];
+        if (g1 > g0) {
+            double a = 0.0;
+            for (int tt = g0 / MJ; tt <= (g1 - 1) / MJ; ++tt) {
+                if (sfirst[tt] == s) a += pfirst[tt];
+                if (slast[tt] == s) a += plast[tt];
+            }
+            W[s] += a;
+        }
+    }
+    FBX_BLOCK_SYNC();
+    gradient_coefficients(des, L, W, t);
+    const Blk grad = pauli_to_choi(L, t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 2 * I + (e >> 1), col = 2 * J + (e & 1);
+        double* o = grad_out + ((item * D + row) * D + col) * 2;
+        o[0] = grad.re[e]; o[1] = grad.im[e];
+    }
+}
+
+int pgdb3_cost_grad_launch(const fbx_design* des, int64_t B, const double* nvec, const double* choi, double eps, double* cost,
+                           double* grad) {
+    const size_t lds = p3::Lds::bytes();
+    if ((size_t)des->dev.S * p3::D * sizeof(double) > 2 * sizeof(cplx) * p3::D * p3::D) {
+        set_error("fbx_pgdb_cost_grad: too many distinct input states for the 3-qubit kernel");
+        return FBX_ERR_UNSUPPORTED;
+    }
+    DevBuf eta;
+    { const int rc = eta.alloc(sizeof(double) * 2 * (size_t)B * des->dev.m); if (rc) return rc; }
+    FBX_HIP(hipFuncSetAttribute((const void*)pgdb3_cost_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pgdb3_cost_grad_kernel, dim3((unsigned)B), dim3(1024), lds, stream(), des->dev, (long long)B, nvec, choi, eps, cost,
+                       grad, eta.as<double>());
+    FBX_HIP(hipGetLastError());
+    return FBX_OK;
+}
+
 // ---- 3-qubit Choi projections (fbx_proj_choi) and linear inversion (fbx_linv_process) on the same
 // 1024-thread building blocks
 __global__ void __launch_bounds__(1024)

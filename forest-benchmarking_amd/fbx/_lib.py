@@ -75,6 +75,8 @@ PROTOTYPES = {
     "fbx_pgdb_process": [_vp, _i64, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _ip, _ip, _ip, _dp, _ip],
     "fbx_pgdb_process_dev": [_vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "fbx_pgdb_process_ex": [_vp, _i64, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _ip, _ip, _ip, _dp, _ip, _ip, C.c_int],
+    "fbx_pgdb_cost_grad": [_vp, _i64, _dp, _dp, C.c_double, _dp, _dp],
+    "fbx_pgdb_cost_grad_dev": [_vp, _i64, _vp, _vp, C.c_double, _vp, _vp],
     "fbx_pgdb_process_ex_dev": [_vp, _i64, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int],
     "fbx_linv_process": [_vp, _i64, _dp, _dp],
     "fbx_linv_state": [_vp, _i64, _dp, _dp],

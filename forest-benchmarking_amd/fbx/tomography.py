@@ -333,6 +333,68 @@ def pgdb_process_estimate(results: List[ExperimentResult], qubits: List[int],
     return pgdb_process_estimate_batch(design, e, c, trace_preserving)[0]
 
 
+# --------------------------------------------------------------------------------------------------
+# _extract_from_results / _cost / _grad_cost (tomography.py:494-539, :597-633) as callable functions.
+# The reference's A in C^{2m x D^2} is never materialised here: the design tables stand for it.
+# --------------------------------------------------------------------------------------------------
+class DesignMatrix:
+    """What ``_extract_from_results`` returns in the place of the reference's dense ``A``: the design tables the kernels apply
+    it through (``p = A vec(E)`` is ``T = R C`` plus ``2 m`` look-ups).  ``shape`` is that of the dense matrix."""
+
+    def __init__(self, design: Design):
+        self.design = design
+        self.shape = (2 * design.m, design.dim ** 4)
+
+    def __repr__(self):
+        return f"DesignMatrix({self.design.n_qubits} qubits, {self.design.m} settings; dense shape {self.shape})"
+
+
+def normalised_counts(expectations, total_counts) -> np.ndarray:
+    """The reference's ``n`` (tomography.py:528-538) for a batch: [B, 2 m], row 2 k / 2 k + 1 = the +1 / -1 counts of result k
+    over the grand total of the experiment -- the same three floating-point operations per entry as the reference's."""
+    e = np.atleast_2d(np.asarray(expectations, dtype=np.float64))
+    c = np.broadcast_to(np.atleast_2d(np.asarray(total_counts, dtype=np.float64)), e.shape)
+    plus = (1 + e) / 2
+    n = np.empty(e.shape[:1] + (2 * e.shape[1],))
+    n[:, 0::2] = c * plus
+    n[:, 1::2] = c * (1 - plus)
+    return n / c.sum(axis=1, keepdims=True)
+
+
+def _extract_from_results(results: List[ExperimentResult], qubits: List[int]) -> Tuple[DesignMatrix, np.ndarray]:
+    """tomography.py:494-539: ``(A, n)`` with ``n`` the [2 m, 1] column of normalised counts exactly as the reference builds it and
+    ``A`` a :class:`DesignMatrix` (the tables that apply the reference's dense matrix)."""
+    design, e, c = flatten_results(results, qubits, "process")
+    return DesignMatrix(design), normalised_counts(e, c)[0][:, None]
+
+
+def cost_and_gradient_batch(design: Design, n, estimates, eps=1e-6, gradient=True):
+    """``(_cost, _grad_cost)`` for a batch: ``n`` [B, 2 m] (:func:`normalised_counts`), ``estimates`` [B, D, D] Hermitian Choi
+    matrices; one launch of ``fbx_pgdb_cost_grad`` (the reconstruction kernels' own table products).  Returns ``cost[B]`` and
+    ``grad[B, D, D]`` (None when ``gradient`` is False)."""
+    design = design.design if isinstance(design, DesignMatrix) else design
+    D = design.dim ** 2
+    est = _lib.c128(estimates).reshape(-1, D, D)
+    nv = np.ascontiguousarray(np.asarray(n, dtype=np.float64).reshape(est.shape[0], -1))
+    if nv.shape[1] != 2 * design.m:
+        raise ValueError(f"n must hold 2 m = {2 * design.m} normalised counts per estimate")
+    cost = np.empty(est.shape[0])
+    grad = np.empty_like(est) if gradient else None
+    _lib.check(_lib.lib().fbx_pgdb_cost_grad(design.handle, est.shape[0], _lib.dptr(nv), _lib.dptr(est.view(np.float64)), float(eps),
+                                             _lib.dptr(cost), _lib.dptr(grad.view(np.float64)) if gradient else None))
+    return cost, grad
+
+
+def _cost(A, n, estimate, eps=1e-6):
+    """tomography.py:597-614 -- returns the reference's [1, 1] array (``-n.T @ log(p)``)."""
+    return cost_and_gradient_batch(A, np.asarray(n).reshape(1, -1), np.asarray(estimate)[None], eps, gradient=False)[0].reshape(1, 1)
+
+
+def _grad_cost(A, n, estimate, eps=1e-6):
+    """tomography.py:617-633."""
+    return cost_and_gradient_batch(A, np.asarray(n).reshape(1, -1), np.asarray(estimate)[None], eps)[1][0]
+
+
 def process_fidelity_variance_batch(design: Design, expectations, total_counts, target_ptm,
                                     n_resamples: int = 40, seed: int = 0, prior_counts=1,
                                     trace_preserving=True, mode="converge", max_iters=0,

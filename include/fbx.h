@@ -237,6 +237,18 @@ int fbx_pgdb_process_ex_dev(const fbx_design* design, int64_t B, const double* d
                             int32_t* d_dykstra_out, int32_t* d_backtracks_out, double* d_cost_out,
                             int32_t* d_work_out, int32_t* d_trace_out, int trace_iters);
 
+/* _cost and _grad_cost (tomography.py:597-614, :617-633) as functions of their own: ONE evaluation of the negative log-likelihood
+ * -n^T log(clip(A vec(E), eps)) and of its gradient -unvec(A^H (n / clip(A vec(E), eps))) at the Choi matrices choi_in[B][D][D]
+ * (Hermitian, as every iterate of the estimator is), computed with the device functions of the reconstruction kernels (Pauli
+ * transform, prediction table T = R C, per-state weights, R^G = -(W C^T) / d^2, inverse transform): a diagnostic that pins the
+ * gradient -- which fbx_pgdb_process never outputs -- directly.  `nvec` is the reference's n of _extract_from_results
+ * (tomography.py:528-538): [B][2 m], row 2 k / 2 k + 1 = the +1 / -1 counts of result k over the grand total.  `design` stands
+ * for A (never materialised).  cost_out[B] or grad_out[B][D][D] may be NULL (not both).  1..3 qubits, any number of settings. */
+int fbx_pgdb_cost_grad(const fbx_design* design, int64_t B, const double* nvec, const double* choi_in, double eps,
+                       double* cost_out, double* grad_out);
+int fbx_pgdb_cost_grad_dev(const fbx_design* design, int64_t B, const double* d_nvec, const double* d_choi_in, double eps,
+                           double* d_cost_out, double* d_grad_out);
+
 /* linear_inv_process_estimate (tomography.py:459-491): choi_out[B][D][D]. */
 int fbx_linv_process(const fbx_design* design, int64_t B, const double* expect,
                      double* choi_out);

@@ -52,34 +52,56 @@ def test_rccl_communicator_single_rank(gpu):
 
 
 def _bench(*args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
-                         timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    """(compact headline = the LAST stdout line, the full record bench.py writes beside it)"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--detail-out", detail], capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = out.stdout.strip().splitlines()
+        assert len(lines[-1]) < 4096, len(lines[-1])                       # what the driver's tail must hold whole
+        assert all(isinstance(json.loads(ln), dict) for ln in lines)
+        return json.loads(lines[-1]), json.load(open(detail))
 
 
 def test_bench_spawns_its_own_ranks(gpu):
     """`python bench.py --gpus 2` with no launcher: two ranks, the configs[4]-shaped strong split (scaled down),
     the weak 1024-per-GPU leg (scaled down), one JSON line from rank 0."""
-    line = _bench("--gpus", "2", "--oversubscribe", "--steps", "2", "--warmup", "1", "--total-batch", "600",
-                  "--batch", "128", "--iters", "20")
+    line, full = _bench("--gpus", "2", "--oversubscribe", "--steps", "2", "--warmup", "1", "--total-batch", "600",
+                        "--batch", "128", "--iters", "20")
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
     assert line["config"]["total_batch"] == 600 and line["config"]["batch_per_gpu"] == 300
     assert line["config"]["collectives"]["ranks"] == 2
     assert line["config"]["collectives"]["backend"] in ("rccl", "host-files")
     assert line["config"]["mean_outer_iters"] == 20.0 and line["value"] > 0
-    assert line["per_gpu_1024"]["scaling"] == "weak" and line["per_gpu_1024"]["value"] > 0
-    assert line["roofline"]["executed_flop"] > 0 and line["vs_baseline"] is None
+    assert line["config"]["per_gpu_1024"]["value"] > 0 and full["per_gpu_1024"]["scaling"] == "weak"
+    assert 0 < line["roofline"]["frac"] < 1 and full["roofline"]["executed_flop"] > 0 and line["vs_baseline"] is None
+    assert full["value"] == pytest.approx(line["value"], rel=1e-5)
 
 
 def test_bench_single_rank_headline_only(gpu):
-    line = _bench("--workload", "pgdb", "--steps", "2", "--warmup", "1", "--batch", "256", "--iters", "30", "--cpu-sample", "0")
+    line, full = _bench("--workload", "pgdb", "--steps", "2", "--warmup", "1", "--batch", "256", "--iters", "30", "--cpu-sample", "0")
     assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["config"]["batch_per_gpu"] == 256
-    r = line["roofline"]
+    r = full["roofline"]
     # frac is the EXECUTED fraction of the fp64 peak (never above 1); the dense-A accounting figure sits beside it
-    assert r["bound"] == "mfma" and 0 < r["frac"] < 1.0 and r["frac"] < r["dense_accounting_frac"] and r["kernel_ms"] <= line["ms_per_step"] * 1.05
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1.0 and r["frac"] < r["dense_accounting_frac"] and r["kernel_ms"] <= full["ms_per_step"] * 1.05
     assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-12 and r["executed_flop"] > 0
-    assert "secondary" not in line and "cpu_baseline" not in line
+    assert 0 <= r["mfma_frac"] < r["frac"]                                # matrix-core share of the peak: a utilisation, <= 1
+    assert "secondary" not in full and "cpu_baseline" not in full
+    c = line["roofline"]
+    assert set(c) >= {"bound", "achieved", "peak", "unit", "frac", "mfma_frac", "traffic", "kernel", "kernel_ms"}
+    assert c["frac"] == pytest.approx(r["frac"], rel=1e-4) and c["kernel"].startswith("pgdb_kernel<2,")
+
+
+def test_bench_state_mle_workload(gpu):
+    """The state-estimator half of north_star has a bench line: rate, executed-flop roofline, the oracle beside it."""
+    line, full = _bench("--workload", "mle_state", "--steps", "2", "--warmup", "1", "--iters", "100", "--cpu-sample", "6")
+    assert line["metric"].startswith("state-tomography iterative-MLE") and line["unit"] == "reconstructions/s" and line["value"] > 1e5
+    assert line["config"]["mean_outer_iters"] == 100.0                  # 1000-shot data never reaches tol 1e-9 in 99 updates
+    assert full["config"]["max_abs_diff_vs_oracle"] < 1e-10 and full["config"]["max_trace_error"] < 1e-12
+    assert line["roofline"]["kernel"] == "mle_state_packed_kernel<2>" and 0 < line["roofline"]["frac"] < 1
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
 
 
 def test_bench_refuses_to_share_a_gpu_without_oversubscribe(gpu):
@@ -198,8 +220,8 @@ def test_two_rank_rccl_collectives_and_sharded_estimator(gpu, tmp_path):
 
 def test_bench_two_gpus_over_rccl(gpu):
     _needs_two_gpus()
-    line = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--total-batch", "4096", "--batch", "256", "--iters", "30")
-    col = line["config"]["collectives"]
+    line, full = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--total-batch", "4096", "--batch", "256", "--iters", "30")
+    col = full["config"]["collectives"]
     assert col["backend"] == "rccl" and col["ranks"] == 2 and "rccl_failure" not in col
     assert len({d["pci_bus_id"] for d in col["rank_devices"]}) == 2 and sorted(d["rank"] for d in col["rank_devices"]) == [0, 1]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["batch_per_gpu"] == 2048
