@@ -1,13 +1,13 @@
 #!/bin/bash
-# rocprofv3 evidence of round 4 for every bench workload (run ON the GPU box):
-#   bash scripts/profile_round4.sh r04 [workloads...]
+# rocprofv3 evidence of a round for every bench workload (run ON the GPU box):
+#   bash scripts/profile_bench.sh r06 [workloads...]
 # Per workload: one --kernel-trace --stats run and, in SEPARATE runs (never combined with a trace domain), the --pmc groups
 #   FETCH_SIZE | WRITE_SIZE | fp64 operation counts | two SQ occupancy / stall groups.
-# scripts/summarize_round4.py condenses them into gpurun_out/profile_<tag>/ (copy to profiles/<tag>/) and writes the two files
+# scripts/summarize_profile.py condenses them into gpurun_out/profile_<tag>/ (copy to profiles/<tag>/) and writes the two files
 # bench.py reads: pmc_traffic.json (HBM bytes per launch) and pmc_flops.json (fp64 operations per launch, counted by the hardware).
 set -u
-TAG=${1:-r04}; shift || true
-WLS=${*:-"pgdb lean8192 lean65536 sweep sweep3 pgdb3 pgdb3pauli pgdb1"}
+TAG=${1:-r06}; shift || true
+WLS=${*:-"pgdb lean8192 lean65536 sweep sweep3 pgdb3 pgdb3pauli pgdb1 mle_state mle_state3"}
 cd "$(dirname "$0")/.."
 REPO=$PWD
 export TMPDIR=/tmp
@@ -24,6 +24,8 @@ bench_args() {
         pgdb3)      echo "--workload pgdb3" ;;
         pgdb3pauli) echo "--workload pgdb3 --in-basis pauli" ;;
         pgdb1)      echo "--workload pgdb1" ;;
+        mle_state)  echo "--workload mle_state" ;;
+        mle_state3) echo "--workload mle_state3" ;;
     esac
 }
 cd /tmp
@@ -40,4 +42,4 @@ for wl in $WLS; do
     done
 done
 cd "$REPO"
-python scripts/summarize_round4.py "$OUT" "$DST" "$TAG" $WLS
+python scripts/summarize_profile.py "$OUT" "$DST" "$TAG" $WLS

@@ -1,6 +1,6 @@
-"""Condense the rocprofv3 output of scripts/profile_round4.sh.
+"""Condense the rocprofv3 output of scripts/profile_bench.sh.
 
-    python scripts/summarize_round4.py <raw dir> <summary dir> <tag> <workloads...>
+    python scripts/summarize_profile.py <raw dir> <summary dir> <tag> <workloads...>
 
 Per workload: the kernel-trace stats CSV, the bench line printed under rocprofv3, and the --pmc passes as means per launch of the
 workload's dominant kernel.  HBM bytes follow the guide's gfx950 correction (FETCH_SIZE counts 64-byte requests as 32: KiB x 1024
@@ -23,11 +23,15 @@ WL = {"pgdb": ("pgdb_kernel<2, 9>", "pgdb_kernel_hbm_bytes_per_launch", 1024, "p
       "sweep3": ("sweep3_regs_kernel", "sweep3_kernel_hbm_bytes_per_launch", 65536, "sweep3_regs_kernel"),
       "pgdb3": ("pgdb3_kernel<4>", "pgdb3_kernel_hbm_bytes_per_launch", 256, "pgdb3_kernel<4>"),
       "pgdb3pauli": ("pgdb3_kernel<14>", "pgdb3pauli_kernel_hbm_bytes_per_launch", 256, "pgdb3_kernel<14>"),
-      "pgdb1": ("pgdb1_step_kernel", "pgdb1_kernel_hbm_bytes_per_launch", 1 << 20, "pgdb1_step_kernel")}
+      "pgdb1": ("pgdb1_step_kernel", "pgdb1_kernel_hbm_bytes_per_launch", 1 << 20, "pgdb1_step_kernel"),
+      "mle_state": ("mle_state_packed_kernel<2>", "mle_state2_kernel_hbm_bytes_per_launch", 1 << 20, "mle_state_packed_kernel<2>"),
+      "mle_state3": ("mle_state_kernel<3>", "mle_state3_kernel_hbm_bytes_per_launch", 1 << 18, "mle_state_kernel<3>")}
 # workloads whose bench step is MANY launches of the kernel (one per outer iteration): counters are summed over a step's launches.
 # The --pmc passes run bench.py with --steps 2 --warmup 1 = 3 calls.
 PER_CALL = {"pgdb1": 3}
 
+FP64_PEAK, CUS, CLOCK_HZ = 78.6e12, 256, 2.4e9     # MI355X_MICROARCH.md: fp64 vector = fp64 MFMA dense peak, 256 CUs, 2.4 GHz
+kernel_s = {}                                       # workload -> mean duration of its dominant kernel (kernel trace), seconds
 lines, summary, traffic, flops = [], {"tag": tag, "kernels": {}}, {"tag": tag}, {"tag": tag}
 summary["note"] = ("means per launch of each workload's dominant kernel (pgdb1: sums over the launches of one call); separate --pmc passes (never combined with a trace domain); "
                    "bench.py <workload> --steps 2 --warmup 1 --cpu-sample 0")
@@ -49,6 +53,9 @@ for wl in wls:
         for k, v in byk.items():
             ds = [x[0] for x in v]
             r = v[0][1]
+            if sub in k:
+                # (pgdb1: one call = all its launches; the trace run is --steps 5 --warmup 1 = 6 calls)
+                kernel_s[wl] = sum(ds) / (6 if wl in PER_CALL else len(ds)) / 1e9
             lines.append(f"{k[:110]}: calls={len(ds)} avg_ms={sum(ds)/len(ds)/1e6:.3f} min_ms={min(ds)/1e6:.3f} max_ms={max(ds)/1e6:.3f} "
                          f"lds={r.get('LDS_Block_Size','?')} vgpr={r.get('VGPR_Count','?')} accum_vgpr={r.get('Accum_VGPR_Count','?')} "
                          f"sgpr={r.get('SGPR_Count','?')} scratch={r.get('Scratch_Size', r.get('Private_Segment_Size','?'))}")
@@ -85,8 +92,14 @@ for wl in wls:
                      ("vmem_active_over_wave_cycles", "SQ_ACTIVE_INST_VMEM")):
             if g(c) is not None:
                 e[k] = g(c) / g("SQ_WAVE_CYCLES")
-    if g("SQ_BUSY_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
-        e["mfma_busy_over_sq_busy"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_BUSY_CYCLES")
+    # MFMA utilisation AS a utilisation (<= 1 by construction): matrix-core flops over the dense fp64 MFMA peak for the kernel's
+    # duration, and matrix-core busy cycles over the cycles the chip's 1024 matrix-core pipes (4 per CU) had in that time
+    if kernel_s.get(wl) and "fp64_flop_per_launch" in e:
+        e["kernel_ms"] = 1e3 * kernel_s[wl]
+        e["mfma_frac_of_fp64_peak"] = mfma / FP64_PEAK / kernel_s[wl]
+        e["fp64_frac_of_peak"] = (valu + mfma) / FP64_PEAK / kernel_s[wl]
+    if kernel_s.get(wl) and g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+        e["mfma_busy_over_pipe_cycles"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * CUS * kernel_s[wl] * CLOCK_HZ)
     if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None:
         e["lds_bank_conflict_over_lds_active"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
     summary["kernels"][wl] = e
