@@ -27,7 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #                      12.38 -> 12.10 ms, to convergence 10.25 -> 9.75 ms; the two-waves kernel is 5 % SLOWER with it (spills) and keeps
 #                      the full-block form, as does every other unit.
 _MAX_ILP = "-mllvm -amdgpu-sched-strategy=max-ilp"
-FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", _MAX_ILP + " -DFBX_JACOBI_TWO_WORKERS").split(),
+FILE_FLAGS = {"fbx_pgdb.hip": os.environ.get("FBX_PGDB_FLAGS", _MAX_ILP).split(),
               "fbx_pgdb3.hip": os.environ.get("FBX_PGDB3_FLAGS", "-mllvm -amdgpu-sched-strategy=iterative-ilp").split(),
               "fbx_pgdb_lean.hip": os.environ.get("FBX_PGDB_LEAN_FLAGS", "-Os -mllvm -disable-machine-licm").split()}
 

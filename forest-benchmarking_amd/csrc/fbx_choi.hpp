@@ -11,13 +11,6 @@
 #pragma once
 #include "fbx_eigh.hpp"
 
-#ifndef FBX_COMPACT_DYKSTRA
-#define FBX_COMPACT_DYKSTRA 0   // 1: Dykstra carried with two matrices per lane in EVERY 1- / 2-qubit kernel, not only in the two-waves-per-SIMD
-                               // ones (measured: the one-wave kernel, which has the registers, is 3.5 % slower with it at B = 1024)
-#endif
-#ifndef FBX_WARM_START
-#define FBX_WARM_START 1     // reuse the previous eigenvectors inside one Dykstra run (reset per run)
-#endif
 
 namespace fbx {
 
@@ -25,11 +18,15 @@ namespace fbx {
 // variant, 16.5 KB per reconstruction instead of 39 KB): no separate staging matrix -- the Pauli transforms
 // stage through Ms and spill into Vs (both dead outside a projection), the partial trace inside a projection
 // through Ms alone (dead once the eigenvalues are read) with an unpadded leading dimension.
-template <int NQ, bool LEAN = false>
+// TWO_WORKERS: the CP projections of this work area use the two-workers-per-upper-block form of the 16 x 16 eigensolver
+// (fbx_eigh.hpp, JacobiWave<16, true>) -- set by the one-wavefront-per-SIMD PGDB body, whose lone wavefront gains 2-5 % from it; every
+// other user keeps the full-block form (the register-capped two-waves kernel is 5 % slower with it).
+template <int NQ, bool LEAN = false, bool TWO_WORKERS = false>
 struct ChoiLds {
     static constexpr int d = 1 << NQ, D = d * d, LD = D + 1, LDs = d + 1;
     static constexpr int LDpt = LEAN ? D : LD;     // leading dimension of the partial-trace staging
     static constexpr bool lean = LEAN;
+    static constexpr bool two_workers = TWO_WORKERS && D == 16;
     cplx* Mw;      // [D * LD]   row-major staging matrix (Pauli transforms); LEAN: = Ms, running into Vs
     cplx* Mpt;     // partial-trace staging: Mw, or Ms (LEAN)
     cplx* Ts;      // scratch of the generic warm-start basis change (D != 16): Mw, or (LEAN, where Mw IS Ms) a block of its own
@@ -70,7 +67,6 @@ template <int NQ, class LdsT>
 __device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool warm = false,
                        bool check_basis = false) {
     constexpr int D = LdsT::D;
-    lane = FBX_LOCAL(lane);
     FBX_WAVE_SYNC();                       // previous readers of Ms / Vs are done
     sys_store<D>(L.Ms, lane, x);
     FBX_WAVE_SYNC();
@@ -92,20 +88,16 @@ __device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool wa
     double hn2 = -1.0;
     if (warm && check_basis) hn2 = uniform(wave_sum(blk_norm2(h)));
     if (warm) {
-#ifndef FBX_ROTATE_VALU
         if constexpr (D == 16) jacobi_rotate_into_basis_mfma16(L.Ms, L.Vs, lane);
         else
-#endif
         {
             jacobi_rotate_into_basis<D>(L.Ms, L.Vs, L.Ts, lane);
         }
     }
     int sw;
-#ifndef FBX_JACOBI_NO_PIPELINE
     if constexpr (D == 16) {
-        sw = jacobi_eigh_wave<D>(L.Ms, L.Vs, lane, !warm, hn2, L.jtol2);
+        sw = jacobi_eigh_wave<D, LdsT::two_workers>(L.Ms, L.Vs, lane, !warm, hn2, L.jtol2);
     } else
-#endif
     {
         if (warm && check_basis) {
             constexpr int LS = (D / 2) * (D / 2), PS = sys_plane<D>();
@@ -144,7 +136,6 @@ __device__ Blk proj_cp_blk(const Blk& x, LdsT& L, int lane, int& sweeps, bool wa
 // keep=[0], dims=[d, d].  Stages `x` through Mw.
 template <int NQ, class LdsT>
 __device__ void partial_trace_out(const Blk& x, LdsT& L, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int d = LdsT::d, D = LdsT::D, LD = LdsT::LDpt, LDs = LdsT::LDs;
     FBX_WAVE_SYNC();
     blk_store<D, LD>(L.Mpt, lane, x);
@@ -165,7 +156,6 @@ __device__ void partial_trace_out(const Blk& x, LdsT& L, int lane) {
 // subtract kron(corr / d, I_d) where corr (d x d) is in L.pt
 template <int NQ, class LdsT>
 __device__ __forceinline__ Blk subtract_kron_pt(const Blk& x, const LdsT& L, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int d = LdsT::d, D = LdsT::D, LDs = LdsT::LDs, NB = D / 2;
     Blk r = x;
     if (lane < NB * NB) {
@@ -256,7 +246,6 @@ struct BasisStore {
 // block of -kron(C / d, I_d) for the d x d matrix C staged in LDS: what a TP / TNI projection adds to its argument
 template <class LdsT>
 __device__ __forceinline__ Blk tp_change_blk(const cplx* C, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int d = LdsT::d, D = LdsT::D, LDs = LdsT::LDs, NB = D / 2;
     Blk r = blk_zero();
     if (lane < NB * NB) {
@@ -290,10 +279,10 @@ __device__ Blk proj_physical_blk_compact(const Blk& x, bool trace_preserving, Ld
     int it = 0;
     for (; it < max_iter; ++it) {
         ++iters;
-        bool warm = FBX_WARM_START && it > 0;
+        bool warm = it > 0;
         bool from_slot = false;
         const int sweeps_before = sweeps;
-        if (FBX_WARM_START && have_store && it < store->nprev && (it == 0 || store->use_prev)) {
+        if (have_store && it < store->nprev && (it == 0 || store->use_prev)) {
             from_slot = true;
             FBX_WAVE_SYNC();
             if (store->pf_slot != it) store->template prefetch<DD>(it, lane);
@@ -305,10 +294,10 @@ __device__ Blk proj_physical_blk_compact(const Blk& x, bool trace_preserving, Ld
             store->pf_slot = -1;
             warm = true;
         }
-        if (FBX_WARM_START && have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
+        if (have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
             store->template prefetch<DD>(it + 1, lane);
         const Blk cp = proj_cp_blk<NQ>(u, L, lane, sweeps, warm, from_slot);
-        if (FBX_WARM_START && have_store && it < store->cap && (it == 0 || store->write_all)) {
+        if (have_store && it < store->cap && (it == 0 || store->write_all)) {
             if (!(from_slot && sweeps == sweeps_before)) {
                 fbx_global_cplx_ptr dst = (fbx_global_cplx_ptr)(store->g + (size_t)it * DD);
 #pragma unroll
@@ -357,7 +346,7 @@ template <int NQ, class LdsT>
 __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, int lane,
                                  int& iters, int& sweeps, int max_iter = 100000,
                                  BasisStore* store = nullptr) {
-    if constexpr (LdsT::lean || FBX_COMPACT_DYKSTRA) return proj_physical_blk_compact<NQ>(x, trace_preserving, L, lane, iters, sweeps, max_iter, store);
+    if constexpr (LdsT::lean) return proj_physical_blk_compact<NQ>(x, trace_preserving, L, lane, iters, sweeps, max_iter, store);
     constexpr int DD = LdsT::D * LdsT::D;
     Blk old_cp = blk_zero(), old_tp = blk_zero(), last_cp = blk_zero();
     Blk last_state = x, new_state = x;
@@ -370,10 +359,10 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, i
     for (; it < max_iter; ++it) {
         ++iters;
         const Blk pre_cp = blk_sub(last_state, old_cp);
-        bool warm = FBX_WARM_START && it > 0;
+        bool warm = it > 0;
         bool from_slot = false;
         const int sweeps_before = sweeps;
-        if (FBX_WARM_START && have_store && it < store->nprev && (it == 0 || store->use_prev)) {
+        if (have_store && it < store->nprev && (it == 0 || store->use_prev)) {
             from_slot = true;
             FBX_WAVE_SYNC();
             if (store->pf_slot != it) store->template prefetch<DD>(it, lane);      // nothing in flight: fetch now
@@ -383,9 +372,6 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, i
                 if (idx < DD) L.Vs[sys_linear<LdsT::D>(idx)] = store->pf[u];
             }
             store->pf_slot = -1;
-#ifdef FBX_DBG_WAITPHASE
-            PH_STOP(*L.pc, 7);
-#endif
 #ifdef FBX_DBG_CORRUPT_BASIS                   // test hook: damage every basis loaded for Dykstra iteration 1
             if (it == 1 && lane < 3) L.Vs[sys_linear<LdsT::D>(17 * lane)].re += 0.25;
 #endif
@@ -393,10 +379,10 @@ __device__ Blk proj_physical_blk(const Blk& x, bool trace_preserving, LdsT& L, i
         }
         // the basis of the NEXT iteration is requested before this iteration's decomposition, so that
         // its HBM / L2 latency lies behind the Jacobi sweeps
-        if (FBX_WARM_START && have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
+        if (have_store && store->use_prev && it + 1 < store->nprev && it + 1 < store->cap)
             store->template prefetch<DD>(it + 1, lane);
         const Blk cp = proj_cp_blk<NQ>(pre_cp, L, lane, sweeps, warm, from_slot);
-        if (FBX_WARM_START && have_store && it < store->cap && (it == 0 || store->write_all)) {
+        if (have_store && it < store->cap && (it == 0 || store->write_all)) {
             // Write-back of the basis (4 KB per decomposition).  Slot j > 0 is only read by a call whose outer
             // step is below FBX_BASIS_STEP, and the outer step shrinks by ~1.2x per iteration: the slots are
             // written from FBX_BASIS_WRITE_STEP (30x the threshold; 4x and 10x measured 1.3 % slower at B = 1024, 30x is free) on -- before that only
@@ -498,7 +484,6 @@ __device__ __forceinline__ void pauli_coeff_position(int i, int j, int& row, int
 // E staged in Mw (destroyed) -> real coefficients Rb[D*D]
 template <int NQ>
 __device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
 #pragma unroll
     for (int t = NQ - 1; t >= 0; --t) {            // input-qubit sites: row bit NQ + t, col bit NQ + t
@@ -520,7 +505,6 @@ __device__ void choi_to_pauli_real(cplx* Mw, double* Rb, int lane) {
 // real coefficients Rb -> Choi block of this lane (Mw is scratch)
 template <int NQ>
 __device__ Blk pauli_real_to_choi_blk(const double* Rb, cplx* Mw, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
     FBX_WAVE_SYNC();
     for (int idx = lane; idx < D * D; idx += 64) {

@@ -40,12 +40,8 @@ int option_pgdb_packed_1q();                     // fbx_set_option("pgdb_packed_
 // <this> x the previous outer step (relative to ||H||_F), never tighter than 1e-13; 0 = always 1e-13.
 // Surveys against the oracle: 2 qubits, 704 items -- identical deviation histogram at 1e-8
 // and at 0; 3 qubits, 66 items -- 9e-11 at 1e-7 and at 0 alike (7e-10 at 3e-7, 4.5e-10 on 18 items at 1e-6, 1.3e-8 at 1e-5).
-#ifndef FBX_JTOL_REL
 #define FBX_JTOL_REL 1e-8
-#endif
-#ifndef FBX3_JTOL_REL
 #define FBX3_JTOL_REL 1e-7
-#endif
 int ensure_device();     // FBX_OK or FBX_ERR_NO_DEVICE (message set)
 int copy_streams(hipStream_t* in, hipStream_t* out, hipStream_t* compute2);   // the calling thread's H2D / D2H / second compute stream (created on first use)
 int ordering_events(int n, hipEvent_t** out);            // >= n reusable events of the calling thread (no timing)
@@ -165,11 +161,7 @@ struct __attribute__((aligned(16))) cplx { double re, im; };
 // s_barrier nor a wait -- only that the compiler keeps the order and does not carry LDS values in
 // registers across the boundary.  __syncthreads() would add `s_waitcnt vmcnt(0) lgkmcnt(0)`: every
 // outstanding LDS access AND every outstanding HBM load / store (the basis prefetch) completed first.
-#ifdef FBX_WAVE_SYNC_IS_BARRIER
-#define FBX_WAVE_SYNC() __syncthreads()
-#else
 #define FBX_WAVE_SYNC() asm volatile("" ::: "memory")
-#endif
 
 // Workgroup barrier of the multi-wave kernels.  __syncthreads() is a release / acquire fence on ALL memory plus
 // s_barrier: it waits for every outstanding global load and store of the wave (s_waitcnt vmcnt(0)) at every barrier.
@@ -209,18 +201,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-#ifdef FBX_SHUFFLE_REDUCTIONS
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-#else
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_permute<0xB1>(v);          // quad_perm [1,0,3,2]
     v += dpp_permute<0x4E>(v);          // quad_perm [2,3,0,1]
@@ -235,7 +215,6 @@ __device__ __forceinline__ double wave_max(double v) {
     v = fmax(v, dpp_permute<0x140>(v));
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
-#endif
 // sum over all NT threads of the workgroup (every thread receives the same total, summed in one
 // fixed order); `red` is NT/64 doubles of LDS scratch, unused for single-wave workgroups
 template <int NT>
@@ -280,13 +259,6 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // them in the 1024-thread kernels, which have 128 registers: hoisted, they are spilled at kernel entry and re-read from
 // scratch (HBM latency, one wait each) in front of every phase.
 __device__ __forceinline__ int opaque(int v) { __asm__ volatile("" : "+v"(v)); return v; }
-// FBX_LOCAL(lane): opaque in the translation units that define FBX_LOCAL_INDEX_MATH (the register-starved two-waves-per-SIMD
-// 2-qubit kernel), the plain value elsewhere (the one-wave kernel has the registers and keeps its hoisted constants).
-#ifdef FBX_LOCAL_INDEX_MATH
-#define FBX_LOCAL(x) fbx::opaque(x)
-#else
-#define FBX_LOCAL(x) (x)
-#endif
 
 // Raw buffer access (buffer_load / buffer_store with an SGPR resource, ONE 32-bit VGPR byte offset and an SGPR / immediate row
 // offset) for per-lane rows of a wave-private slice: no 64-bit per-lane address arithmetic, which the compiler otherwise hoists
@@ -312,18 +284,9 @@ __device__ __forceinline__ unsigned buf_load_u32(__amdgpu_buffer_rsrc_t r, unsig
 // one cubically convergent step  y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2.
 // Avoids the IEEE sqrt / divide expansions in the Jacobi rotation's dependent chain.
 __device__ __forceinline__ double fast_rsqrt(double x) {
-#ifdef FBX_EXACT_RSQRT
-    return 1.0 / sqrt(x);
-#endif
     const double y = __builtin_amdgcn_rsq(x);
     const double e = fma(-x * y, y, 1.0);
     const double p = fma(0.375, e, 0.5);
-#ifdef FBX_RSQRT_EXTRA
-    double z = fma(y * e, p, y);
-    const double hx = 0.5 * x;
-    z = z * fma(-hx * z, z, 1.5);
-    return z;
-#endif
     return fma(y * e, p, y);
 }
 

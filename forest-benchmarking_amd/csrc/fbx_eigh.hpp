@@ -203,13 +203,9 @@ __device__ __forceinline__ Blk sys_load_adjoint(const cplx* Ms, int lane) {
 }
 
 constexpr int FBX_JACOBI_MAX_SWEEPS = 40;
-#ifndef FBX_JACOBI_TOL2_VALUE
 #define FBX_JACOBI_TOL2_VALUE 1e-26
-#endif
 constexpr double FBX_JACOBI_TOL2 = FBX_JACOBI_TOL2_VALUE;
-#ifndef FBX_BASIS_NORM_TOL
 #define FBX_BASIS_NORM_TOL 1e-9      // relative change of ||.||_F^2 under a stored basis above which it is discarded
-#endif   // stop when off(A)^2 <= TOL2 * ||A||_F^2
 
 // Rotation helpers ----------------------------------------------------------------------------
 // Rotation R = [[c, s], [-conj(s), c]] that diagonalises the Hermitian pivot [[a, b], [conj(b), d]]
@@ -225,24 +221,6 @@ __device__ __forceinline__ JRot jacobi_rotation(double a, double d, double br, d
 }
 __device__ __forceinline__ JRot jacobi_rotation_beta(double a, double d, double br, double bi, double beta) {
     const double delta = 0.5 * (d - a);
-#ifdef FBX_JACOBI_LIVE_SELECTS      // round-2 form: explicit identity rotation for b == 0 (13 more instructions per round)
-    const double h2 = fma(delta, delta, beta);
-    const bool live = beta > 1e-290;                   // else: identity rotation
-    const double ih = fast_rsqrt(live ? h2 : 1.0);
-    const double x = fma(0.5 * fabs(delta), ih, 0.5);  // (1 + q) / 2 in [0.5, 1]
-    const double ic = fast_rsqrt(x);
-    const double f = (delta >= 0.0 ? 0.5 : -0.5) * ih * ic;
-    const double c = x * ic;
-    const double fb = f * beta;
-    const double u = fma(f * fb, 2.0 * delta, -2.0 * c * fb);
-    JRot r;
-    r.c = live ? c : 1.0;
-    r.sr = live ? f * br : 0.0;
-    r.si = live ? f * bi : 0.0;
-    r.an = live ? a + u : a;
-    r.dn = live ? d - u : d;
-    return r;
-#else
     // |delta| + 1e-150 (absorbed by any |delta| > 1e-134, so every ordinary rotation is bit-identical to the form
     // above) keeps h2 > 0: for b == 0 the formulas then give q = 1, c = 1, s = f b = 0, u = 0 by themselves -- the
     // identity rotation without a single select.  (b so small that |b|^2 underflows while delta == 0 exactly:
@@ -258,7 +236,6 @@ __device__ __forceinline__ JRot jacobi_rotation_beta(double a, double d, double 
     JRot r;
     r.c = x * ic; r.sr = f * br; r.si = f * bi; r.an = a + u; r.dn = d - u;
     return r;
-#endif
 }
 
 // 2x2 block update  m <- R_I^H m R_J  and eigenvector columns  v <- v R_J
@@ -322,9 +299,11 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 // (scripts/micro/run_jacobi_vdpp.sh, profiles/r05): 1180 -> 1017 cycles per round at one wavefront per SIMD, 1635 -> 1433 at
 // two, 2595 -> 2096 at four.  The same rotations are applied to the same data: results are bit-identical to the LDS form
 // (-DFBX_JACOBI_V_THROUGH_LDS keeps it for A/Bs).
-#ifndef FBX_JACOBI_NO_PIPELINE
-#if defined(FBX_JACOBI_TWO_WORKERS) && !defined(FBX_JACOBI_V_THROUGH_LDS)
-// Round 5, second step (-DFBX_JACOBI_TWO_WORKERS: the translation unit of the one-wavefront-per-SIMD PGDB kernels, build.py): the
+// The solver exists in two forms selected by a TEMPLATE TAG at the call site (fbx_choi.hpp: ChoiLds<..., TWO_WORKERS>), not by a
+// per-file macro: jacobi_eigh_wave<N, true> below (two workers per upper block; only the diagonal of Ms is meaningful on exit) and
+// jacobi_eigh_wave<N, false> (every lane its full block).  Two names for two post-conditions -- no ODR hazard under -fgpu-rdc / LTO.
+template <int N, bool TWO_WORKERS = false> struct JacobiWave;
+// Round 5, second step (the one-wavefront-per-SIMD PGDB kernels, whose ChoiLds carries the tag): the
 // HERMITIAN SYMMETRY of the work matrix, used without idling a lane.  In the form below this one lane (I, J) and lane (J, I) both
 // compute their whole 2 x 2 block -- conjugate transposes of each other.
 // Here only the upper block triangle exists; its block (I, J), I < J, has TWO workers: lane (I, J) computes column 0 of the updated
@@ -345,15 +324,11 @@ struct __attribute__((aligned(16))) JRec { double c, sr, si, an, dn, pad; };
 // for full blocks, i.e. the 49.8 % bank conflicts of profiles/r05 gone -- changes nothing in isolation (940 vs 941 cycles per round:
 // the conflicts are not on the dependent chain) and costs the kernel its table look-ups: B = 1024 fixed-100 12.17 -> 12.52 ms.)
 template <int N>
-__device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
-                                   double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
+struct JacobiWave<N, true> {
+static __device__ int run(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
+                          double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(N == 16 && LS == 64, "every lane of the wavefront owns one eigenvector block");
-    #ifdef FBX_JACOBI_LOCAL_CONSTANTS      // (experiment for the register-capped kernels: the per-lane constants below recomputed per call, not hoisted)
-    lane = opaque(lane);
-#else
-    lane = FBX_LOCAL(lane);
-#endif
     const int Ir = lane / NB, Jc = lane % NB;
     const int me = lane;
     const bool diag = Ir == Jc, wb = Ir > Jc;                  // wb: second worker of the upper block (Jc, Ir)
@@ -466,13 +441,13 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
     FBX_WAVE_SYNC();
     return sweep;
 }
-#elif !defined(FBX_JACOBI_V_THROUGH_LDS)
+};
 template <int N>
-__device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
-                                double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
+struct JacobiWave<N, false> {
+static __device__ int run(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
+                          double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(N == 16 && LS == 64, "every lane of the wavefront owns one 2x2 block; a block row is half a DPP row");
-    lane = FBX_LOCAL(lane);
     const int I = lane / NB, J = lane % NB;
     const int me = lane;
     int wm[4];
@@ -554,95 +529,19 @@ __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, in
     FBX_WAVE_SYNC();
     return sweep;
 }
-#else
-template <int N>
+};
+template <int N, bool TWO_WORKERS = false>
 __device__ int jacobi_eigh_wave(cplx* __restrict__ Ms, cplx* __restrict__ Vs, int lane, bool init_identity,
-                                double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
-    constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
-    static_assert(LS == 64, "every lane of the wavefront owns one 2x2 block");
-    lane = FBX_LOCAL(lane);
-    const int I = lane / NB, J = lane % NB;
-    const int me = lane;
-    int wm[4], wv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int sa = jacobi_seat<N>(2 * I + (e >> 1)), sb = jacobi_seat<N>(2 * J + (e & 1));
-        wm[e] = ((sa & 1) * 2 + (sb & 1)) * PS + (sa >> 1) * NB + (sb >> 1);
-        wv[e] = ((e >> 1) * 2 + (sb & 1)) * PS + I * NB + (sb >> 1);
-    }
-    const int dJ = J * NB + J;
-    const int src_lane = (lane & 63) - J + I;
-    // The eigenvector block is kept one seat permutation BEHIND the matrix: every round first
-    // finishes the pending update (rotate, write to the seats, read back), so the registers start
-    // with the columns pulled back through the permutation -- V[row][seat(col)] -- and the first
-    // pending rotation is the identity.
-    cplx v0p, v0q, v1p, v1q;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        cplx v;
-        if (init_identity) {
-            v.re = (2 * I + (e >> 1) == jacobi_seat<N>(2 * J + (e & 1))) ? 1.0 : 0.0; v.im = 0.0;
-        } else v = Vs[wv[e]];
-        if (e == 0) v0p = v; else if (e == 1) v0q = v; else if (e == 2) v1p = v; else v1q = v;
-    }
-    double pc = 1.0, psr = 0.0, psi = 0.0;          // rotation whose eigenvector update is still pending
-    int sweep = 0;
-    double n2 = 0.0;                                // ||A||_F^2: invariant under the rotations, reduced once
-    for (; sweep < FBX_JACOBI_MAX_SWEEPS; ++sweep) {
-        {
-            double o2 = 0.0, a_all = 0.0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const cplx v = Ms[e * PS + me];
-                const double a2 = v.re * v.re + v.im * v.im;
-                a_all += a2;
-                if (!(I == J && (e == 0 || e == 3))) o2 += a2;
-            }
-            o2 = uniform(wave_sum(o2));
-            if (sweep == 0) n2 = uniform(wave_sum(a_all));
-            // expect_n2 >= 0: the matrix was brought into a basis loaded from memory; a unitary similarity
-            // keeps ||.||_F^2 (here to FBX_BASIS_NORM_TOL), a damaged basis does not -> tell the caller (-1)
-            if (sweep == 0 && expect_n2 >= 0.0 && !(fabs(n2 - expect_n2) <= FBX_BASIS_NORM_TOL * expect_n2)) return -1;
-            if (!(o2 > tol2 * n2)) break;
-        }
-        for (int r = 0; r < N - 1; ++r) {
-            const double aJ = Ms[0 * PS + dJ].re, dJ_ = Ms[3 * PS + dJ].re;
-            const cplx bJ = Ms[1 * PS + dJ];
-            cplx m00 = Ms[0 * PS + me], m01 = Ms[1 * PS + me];
-            cplx m10 = Ms[2 * PS + me], m11 = Ms[3 * PS + me];
-            // pending eigenvector update of the previous round (identity the very first time), written
-            // to its seats and read back as this round's block -- independent of the chain below
-            jacobi_apply_v(pc, psr, psi, v0p, v0q, v1p, v1q);
-            Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
-            v0p = Vs[0 * PS + me]; v0q = Vs[1 * PS + me]; v1p = Vs[2 * PS + me]; v1q = Vs[3 * PS + me];
-            const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
-            JRot rI;
-            rI.c = __shfl(rJ.c, src_lane); rI.sr = __shfl(rJ.sr, src_lane); rI.si = __shfl(rJ.si, src_lane);
-            jacobi_apply_m(rI.c, rI.sr, rI.si, rJ.c, rJ.sr, rJ.si, m00, m01, m10, m11);
-            if (I == J) {   // the annihilated pair: exact zeros, real diagonal (see jacobi_eigh_simple)
-                m01.re = m01.im = 0.0; m10.re = m10.im = 0.0;
-                m00.im = 0.0; m11.im = 0.0;
-            }
-            Ms[wm[0]] = m00; Ms[wm[1]] = m01; Ms[wm[2]] = m10; Ms[wm[3]] = m11;
-            pc = rJ.c; psr = rJ.sr; psi = rJ.si;
-        }
-    }
-    jacobi_apply_v(pc, psr, psi, v0p, v0q, v1p, v1q);      // flush the last pending update
-    Vs[wv[0]] = v0p; Vs[wv[1]] = v0q; Vs[wv[2]] = v1p; Vs[wv[3]] = v1q;
-    FBX_WAVE_SYNC();
-    return sweep;
+                                                double expect_n2 = -1.0, double tol2 = FBX_JACOBI_TOL2) {
+    return JacobiWave<N, TWO_WORKERS>::run(Ms, Vs, lane, init_identity, expect_n2, tol2);
 }
-#endif
-#endif
 
 template <int N, int NT = 64>
 __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identity = true,
                                   double* red = nullptr, double tol2 = FBX_JACOBI_TOL2) {
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     static_assert(LS <= NT, "one lane per 2x2 block");
-#ifndef FBX_JACOBI_NO_PIPELINE
     if constexpr (NT <= 64 && N == 16) { (void)red; return jacobi_eigh_wave<N>(Ms, Vs, lane, init_identity, -1.0, tol2); }
-#endif
     const bool act = lane < LS;
     const int I = act ? lane / NB : 0, J = act ? lane % NB : 0;
     // own block of plane e: me0 for the planes with b = 0 (e = 0, 2), me1 for b = 1 (they differ only for N = 64)
@@ -684,10 +583,6 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             if (!(o2 > tol2 * n2)) break;
         }
         for (int r = 0; r < N - 1; ++r) {
-#ifdef FBX_JACOBI_TWO_CHAINS
-            const double aI = Ms[0 * PS + dI0].re, dI_ = Ms[3 * PS + dI1].re;
-            const cplx bI = Ms[1 * PS + dI1];
-#endif
             const double aJ = Ms[0 * PS + dJ0].re, dJ_ = Ms[3 * PS + dJ1].re;
             const cplx bJ = Ms[1 * PS + dJ1];
             cplx m00 = Ms[0 * PS + me0], m01 = Ms[1 * PS + me1];
@@ -699,14 +594,10 @@ __device__ int jacobi_eigh_simple(cplx* Ms, cplx* Vs, int lane, bool init_identi
             // reads above see the previous round and the next round's reads see the writes below.
             if constexpr (NT > 64) FBX_BLOCK_SYNC();
             const JRot rJ = jacobi_rotation(aJ, dJ_, bJ.re, bJ.im);
-#ifdef FBX_JACOBI_TWO_CHAINS
-            const JRot rI = jacobi_rotation(aI, dI_, bI.re, bI.im);
-#else
             // the row rotation (pair I) is the column rotation of the lane (I, I) of this block row,
             // which sits in the same wavefront: fetch it instead of computing a second chain
             JRot rI;
             rI.c = __shfl(rJ.c, src_lane); rI.sr = __shfl(rJ.sr, src_lane); rI.si = __shfl(rJ.si, src_lane);
-#endif
             jacobi_apply_m(rI.c, rI.sr, rI.si, rJ.c, rJ.sr, rJ.si, m00, m01, m10, m11);
             jacobi_apply_v(rJ.c, rJ.sr, rJ.si, v0p, v0q, v1p, v1q);
             if (I == J) {   // the annihilated pair: exact zeros, real diagonal
@@ -783,10 +674,8 @@ __device__ void jacobi_rotate_into_basis(cplx* Ms, const cplx* Vs, cplx* Ts, int
 // the V element loaded as B operand of the first product, and T[4 k4 + (l >> 4)][l & 15] is
 // accumulator k4 of this lane.  8 LDS loads + 4 stores per lane instead of 128 + 8 for the
 // register-blocked VALU form, which is LDS-bandwidth bound with four wavefronts per CU.
-#ifndef FBX_ROTATE_VALU
 typedef double fbx_v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void jacobi_rotate_into_basis_mfma16(cplx* Ms, const cplx* Vs, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int NB = 8, PS = sys_plane<16>();
     const int c = lane & 15, g = lane >> 4;
     auto at = [](int r, int cc) { return ((r & 1) * 2 + (cc & 1)) * PS + (r >> 1) * NB + (cc >> 1); };
@@ -821,7 +710,6 @@ __device__ __forceinline__ void jacobi_rotate_into_basis_mfma16(cplx* Ms, const 
     }
     FBX_WAVE_SYNC();
 }
-#endif
 
 template <int N, int NT = 64>
 __device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, int lane,
@@ -834,7 +722,6 @@ __device__ __forceinline__ int jacobi_eigh_lds(cplx* Ms, cplx* Vs, JRec* rec, in
 // terms with lam[k] == 0 are skipped (wave-uniform branch).
 template <int N>
 __device__ __forceinline__ Blk reconstruct_blk(const cplx* Vs, const double* lam, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int NB = N / 2, LS = NB * NB, PS = sys_plane<N>();
     Blk out = blk_zero();
     const bool act = lane < LS;

@@ -27,28 +27,14 @@ extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
 #else
 #define FBX_PHASE_OUT3(b0) ((long long*)nullptr)
 #endif
-#ifndef FBX3_BASIS_STEP
 #define FBX3_BASIS_STEP 3e-2           // outer step below which Dykstra iteration j starts from the previous call's basis j.  The 2-qubit kernel's
                                        // 1e-3 (FBX_BASIS_STEP) is too timid here: same-box A/B (scripts/ab_time3.py, 256 items) 331.6 ms at
                                        // 1e-3 / 3e-2, 324.4 at 1e-2 / 1e-1, 317.2 at 3e-2 / 3e-1, 317.1 at 1e-1 / 1 -- a starting basis only
                                        // changes how many sweeps a decomposition needs, never the tolerance it runs to
-#endif
-#ifndef FBX3_BASIS_WRITE_STEP
 #define FBX3_BASIS_WRITE_STEP 3e-1     // outer step below which every basis is written back (10 x the threshold above, as in the 2-qubit kernel)
-#endif
-#ifndef FBX3_BASIS_CHAIN_SWEEPS
 #define FBX3_BASIS_CHAIN_SWEEPS 216   // as FBX_BASIS_CHAIN_SWEEPS of the 2-qubit kernel (fbx_pgdb.hip)
-#endif
 
-#ifndef FBX3_PARK_DYKSTRA
 #define FBX3_PARK_DYKSTRA 0      // (measured: 271.7 against 272.8 ms per 256 reconstructions -- not worth 64 GB of traffic per launch)
-#endif
-#ifndef FBX3_OPAQUE
-#define FBX3_OPAQUE 1
-#endif
-#if !FBX3_OPAQUE
-#define opaque(x) (x)
-#endif
 namespace p3 {
 constexpr int NQ = 3, d = 8, D = 64, NB = 32, NT = 1024, LD = 64, LDs = d + 1;
 constexpr double EPS = 1e-6, GAMMA = 0.3, STOP = 1e-10, ALPHA_MIN = 1e-15;
@@ -153,7 +139,6 @@ __device__ void rotate_into_basis(Lds& L, cplx* Tg, int t) {
 // H[m][k] = conj(H[k][m]) (H is exactly Hermitian: it was just symmetrised) and (V^H)[m][k] = conj(V[k][m]).
 // 2 x 16 x 2 b128 loads and 8 stores per lane instead of 2 x 64 x 4 loads; the products themselves take
 // 128 x 32 cycles per wavefront (the VALU form: 68.7 k cycles per decomposition, this one: see DESIGN.md 4.4).
-#ifndef FBX3_ROTATE_VALU
 __device__ void rotate_into_basis_mfma(Lds& L, int t) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     t = opaque(t);
@@ -207,28 +192,17 @@ __device__ void rotate_into_basis_mfma(Lds& L, int t) {
     }
     FBX_BLOCK_SYNC();
 }
-#endif
 
 // The 64 x 64 eigensolver as a REAL function call: inlined into the 1024-thread kernels, its per-thread address
 // constants and those of every other phase are hoisted out of the Dykstra loop together and spilled -- with scratch
 // reloads inside the Jacobi round loop.  Behind a call boundary the solver is allocated on its own (80 registers, no
 // scratch, as in eigh_kernel<64, 1024>) and the caller's live values are saved around the call, once per decomposition.
-#ifndef FBX3_JACOBI_CALL
 #define FBX3_JACOBI_CALL 0      // 1: behind a call boundary (noinline), 0: inlined into the kernels (round 4: 296 -> 274 ms per 256 reconstructions;
                                 // the role-split solver needs more than the 80 caller-saved registers and saved 49 more to scratch per call)
-#endif
-#if FBX3_JACOBI_CALL
-__device__ __attribute__((noinline))
-#else
 __device__ __forceinline__
-#endif
 int jacobi64(cplx* Ms, cplx* Vs, int t, bool init_identity, double* red, double tol2) {
     t = opaque(t);
-#ifdef FBX3_JACOBI_ROUND3          // the one-block-per-thread form of rounds 1-3 (A/B builds)
-    return jacobi_eigh_simple<D, NT>(Ms, Vs, t, init_identity, red, tol2);
-#else
     return jacobi_eigh64<NT>(Ms, Vs, t, init_identity, red, tol2);     // fbx_eigh64.hpp
-#endif
 }
 
 // ---- V diag(lam) V^H for the 64 x 64 eigenvectors in Vs: the block of thread (I, J) is sum_k lam_k V[2I + a][k] conj(V[2J + b][k]).
@@ -314,13 +288,8 @@ __device__ __forceinline__ Blk proj_cp(const Blk& x_, Lds& L, int t_, int& sweep
         // a basis loaded from the store is only trusted if the change of basis kept ||.||_F^2 (unitary
         // similarity); otherwise the matrix is restored and the decomposition starts from the identity
         // (same guard as proj_cp_blk, fbx_choi.hpp)
-#ifndef FBX3_ROTATE_VALU
         (void)Tg; rotate_into_basis_mfma(L, t);
-#else
-        rotate_into_basis(L, Tg, t);
-#endif
         if (check_basis) {
-#ifndef FBX3_ROTATE_VALU
             {   // (the matrix-core form leaves the tiles below the diagonal unwritten: the upper ones count twice)
                 const int ti = t / NB / 8, tj = t % NB / 8;      // tile of entry position t (the layout permutes column pairs inside aligned groups of 8 only)
                 const double wgt = ti < tj ? 2.0 : ti == tj ? 1.0 : 0.0;
@@ -329,10 +298,6 @@ __device__ __forceinline__ Blk proj_cp(const Blk& x_, Lds& L, int t_, int& sweep
                 for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * NT + t]; acc2 = fma(v.re, v.re, fma(v.im, v.im, acc2)); }
                 n2[1] = wgt * acc2;
             }
-#else
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const cplx v = L.Ms[e * NT + t]; n2[1] = fma(v.re, v.re, fma(v.im, v.im, n2[1])); }
-#endif
             bsum_multi<2>(n2, L);
             if (!(fabs(n2[1] - n2[0]) <= FBX_BASIS_NORM_TOL * n2[0])) {
                 (void)hermitise_into_ms(x, L, t, false);
@@ -418,11 +383,7 @@ __device__ Blk proj_tni(const Blk& x, Lds& L, int t, int& sweeps) {   // project
 
 // -DFBX3_DYK_DETAIL (diagnostics, with FBX_PHASE_TIMERS): the phases of a Dykstra iteration take over the timer slots of
 // the outer phases -- 3 basis load, 7 basis write-back, 4 TP / TNI projection, 5 stopping functional (2 then = Hermitise only)
-#ifdef FBX3_DYK_DETAIL
-#define PH3(ph) PH_STOP(*L.pc, ph)
-#else
 #define PH3(ph)
-#endif
 // one stored basis (64 KiB, the layout of Vs) from HBM / L2 into LDS without passing through registers: every lane moves
 // four 16-byte entries; the LDS address of a global_load_lds is wave-uniform base + lane * 16
 // s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima): the consumer side
@@ -826,11 +787,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
         { const double tr_ = des.eig_rel_tol * outer_step; L.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }   // as in fbx_pgdb.hip
         const Blk proj = proj_physical(x, trace_preserving != 0, L, t, dyk, sweeps,
                                        scratch,
-#if FBX3_PARK_DYKSTRA
-                                       basis.g ? &basis : nullptr, park.dyk());
-#else
                                        basis.g ? &basis : nullptr, nullptr);
-#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const cplx v = park.est()[e * NT + t]; est.re[e] = v.re; est.im[e] = v.im; }
         const Blk upd = blk_sub(proj, est);
@@ -927,9 +884,7 @@ static int launch3(const fbx_design* des, int64_t B, const double* e, const doub
     // per-workgroup store of Dykstra eigenvector bases (BASIS_CAP x 64 KiB); batches are processed in
     // chunks so the store stays bounded (512 workgroups = 768 MiB)
     constexpr int64_t CHUNK = 512;
-#ifndef FBX_BASIS_CAP3
 #define FBX_BASIS_CAP3 24
-#endif
     constexpr int BASIS_CAP = FBX_BASIS_CAP3;   // Dykstra iterations per projection with a stored basis (64 KiB each)
     // (a grow-only workspace of the calling thread, released by fbx_release_workspace)
     void* w = nullptr;

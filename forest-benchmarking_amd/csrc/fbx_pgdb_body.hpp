@@ -7,27 +7,14 @@
 #include "fbx_choi.hpp"
 #include <cstdlib>
 #include <vector>
-#ifndef FBX_LEAN_MIN_BATCH
 #define FBX_LEAN_MIN_BATCH 1025     // batch size from which the two-waves-per-SIMD kernel is used (2 qubits): one reconstruction more than
                                     // the chip has SIMDs.  The one-wave kernel is the faster chain (1024 items: 12.7 against 15.3 ms), but item
                                     // 1025 starts a second round on it (1152 items: 19.8 against 16.1 ms; scripts/lean_crossover.py; round 3's
                                     // crossover, before the pieces, lay between 1100 and 1280)
-#endif
-#ifndef FBX_PACKED_1Q_MIN_BATCH
 #define FBX_PACKED_1Q_MIN_BATCH 8192  // single-qubit batches from which the lane-per-item kernel is used (fbx_pgdb1.hip)
-#endif
-#ifndef FBX_BASIS_CHAIN_SWEEPS
 #define FBX_BASIS_CHAIN_SWEEPS 216  // Jacobi sweeps a chain of stored bases may accumulate (per slot, on average) before a cold restart
-#endif
-#ifndef FBX_BASIS_STEP
 #define FBX_BASIS_STEP 1e-3
-#endif
-#ifndef FBX_BASIS_WRITE_STEP
 #define FBX_BASIS_WRITE_STEP 3e-2     // outer step below which every Dykstra basis is written back (fbx_choi.hpp BasisStore)
-#endif
-#ifndef FBX_DBG_NOVALID
-#define FBX_DBG_NOVALID 0
-#endif
 
 namespace fbx {
 
@@ -35,12 +22,7 @@ constexpr double PGDB_EPS = 1e-6;     // probability clip, tomography.py:597,613
 constexpr double PGDB_GAMMA = 0.3;    // tomography.py:567
 constexpr double PGDB_STOP = 1e-10;   // tomography.py:589
 constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
-#ifndef FBX_DBG_NOLADDER
-#define FBX_DBG_NOLADDER 0
-#endif
-#ifndef FBX_SMALL_STEP_LIMIT
 #define FBX_SMALL_STEP_LIMIT 0x1p-3      // alpha * max |pu / pe| below which the line search uses the power-sum series
-#endif
 
 // LEAN (2 waves per SIMD at large batches): 19.4 KB instead of 39 KB per reconstruction, so that eight wavefronts share a CU's
 // 160 KB.  The Bloch matrix is read through L2 (DesignDev::Ct); the normalised counts n+- live in REGISTERS (2 MAXJ doubles per
@@ -51,7 +33,7 @@ constexpr double PGDB_ALPHA_MIN = 1e-15;  // tomography.py:584
 // an L2 workspace: 72 + registers of per-outcome probabilities, 216 spilled registers and ~9 KB of L2 reads per cost evaluation.
 template <int NQ, bool LEAN = false>
 struct PgdbLds {
-    ChoiLds<NQ, LEAN> choi;
+    ChoiLds<NQ, LEAN, !LEAN> choi;      // the one-wave body: two workers per upper block in the 16 x 16 eigensolver (fbx_choi.hpp)
     double* Rb;     // [D*D]  Pauli coefficients (one matrix at a time), TRANSPOSED: Rb[j * D + i] = R[i][j]   (LEAN: inside Vs)
     double* Test;   // [S*D]  predicted tr(P_i E(rho_s)) for the current estimate
     double* Tupd;   // [S*D]  same for the update direction; reused as Wt[S][D] in the gradient
@@ -109,7 +91,6 @@ __host__ __device__ constexpr bool pgdb_ct_fits(int S) {
 // took 16k cycles per call for the 36-state design.
 template <int NQ>
 __device__ void predict_table(const double* Rb, const double* Ct, double* T, int S, int lane) {
-    lane = FBX_LOCAL(lane);
     constexpr int D = ChoiLds<NQ>::D, STEP = 64 / D;
     const int i = lane % D, q = lane / D;
     double r[D];
@@ -155,11 +136,8 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     // the one-wave kernel and LOOPS in the lean one (the slot index is wave-uniform: register arrays are indexed through
     // s_set_gpr_idx): unrolled they are 6.4 KB of code per slot -- 58 of the 91 KB of the 540-setting instantiation, against a
     // 64 KB instruction cache that eight wavefronts in eight different phases share.
-#ifndef FBX_FAT_SLOT_UNROLL
-#define FBX_FAT_SLOT_UNROLL MAXJ     // (experiment: 1 = the one-wave kernel loops over its slots too)
-#endif
-    constexpr int SLOT_UNROLL = LEAN ? 1 : (FBX_FAT_SLOT_UNROLL);
-    int lane = threadIdx.x & 63;            // (re-made opaque per phase in the lean kernel: FBX_LOCAL, fbx_common.hpp)
+    constexpr int SLOT_UNROLL = LEAN ? 1 : MAXJ;
+    int lane = threadIdx.x & 63;
     const long long item = item_;
     const int m = des.m, S = des.S;
     const int nslots = STREAM ? (m + 63) / 64 : MAXJ;       // outcome slots per lane (a compile-time constant unless STREAM)
@@ -370,7 +348,6 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
     while (true) {
         if (mode == FBX_MODE_FIXED && iters >= max_iters) break;
         if (PIECES && iters >= piece_stop) { paused = true; break; }
-        lane = FBX_LOCAL(lane);
         const int dyk_before = dyk, bt_before = backtracks;       // per-iteration trace (fbx_pgdb_process_ex)
         // A stored basis is the product of all rotations applied to its chain since the last cold start, and every
         // rotation costs ~1e-16 of unitarity: the chains are dropped once they have absorbed FBX_BASIS_CHAIN_SWEEPS
@@ -379,18 +356,11 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         // iterations whatever had happened, i.e. also in the stalled iterations, whose frozen decompositions apply
         // no rotation at all, and a cold restart costs ~10 sweeps more than a warm projection).  The first basis of this iteration's
         // projection is requested now, so that it arrives behind the gradient.
-#ifdef FBX_BASIS_RESET_MASK      // round-1 rule, for A/B builds: every (MASK + 1) iterations
-        if ((iters & FBX_BASIS_RESET_MASK) == 0 || FBX_DBG_NOVALID) basis.nprev = 0;
-        (void)chain_start;
-#else
-        if (iters == 0 || FBX_DBG_NOVALID ||
+        if (iters == 0 ||
             sweeps - chain_start >= FBX_BASIS_CHAIN_SWEEPS * (basis.nprev > 0 ? basis.nprev : 1)) {
             basis.nprev = 0; chain_start = sweeps;
         }
-#endif
-#ifndef FBX_NO_VFIRST
-        if (basis.g && basis.nprev > 0 && FBX_WARM_START) basis.template prefetch<D * D>(0, lane);
-#endif
+        if (basis.g && basis.nprev > 0) basis.template prefetch<D * D>(0, lane);
         // ---- prediction table of the current estimate
         FBX_WAVE_SYNC();
         blk_store<D, LD>(L.choi.Mw, lane, est);
@@ -479,12 +449,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         { const double tr_ = des.eig_rel_tol * outer_step; L.choi.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }
         basis.write_all = outer_step < FBX_BASIS_WRITE_STEP;
         const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
-#ifdef FBX_NO_VFIRST
-                                               nullptr);
-#else
                                                &basis);
-#endif
-        lane = FBX_LOCAL(lane);
         const Blk upd = blk_sub(proj, est);
         Blk grad = blk_zero();
         if (lane < NACT) {
@@ -511,7 +476,6 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         load_probs(L.Tupd, pup, pum, 0.0);
         PH_STOP(pc, 3);
         // ---- backtracking line search (tomography.py:575-585)
-#ifndef FBX_NO_SMALL_STEP
         // Small steps: cost(alpha) = cost(0) - sum n log1p(alpha pu / pe), and cost(0) is old_cost.
         // Once alpha |pu / pe| < 2^-9 for every outcome (and nothing sits at the clip), log1p is a
         // degree-6 polynomial to < 1e-17 relative -- 8 instructions per outcome instead of ~40.  The
@@ -638,32 +602,23 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
             double acc = series(alpha);
             if (near_clip)                   // the listed outcomes: exact difference of clipped logs
                 acc += uniform(wave_sum(clip_n * clipped_log(fma(alpha, clip_pu, clip_pe)) - clip_base));
-#ifndef FBX_LS_ROUNDED
             ls_exact = true; ls_diff = -acc;
-#endif
             return old_cost - acc;
         };
         auto rejected = [&](double change_) __attribute__((always_inline)) -> bool {
             return ls_exact ? (ls_diff > change_) : (new_cost > old_cost + change_);
         };
-#else
-        auto cost_step = [&](double alpha) -> double { ++ls_full; return cost_at(alpha); };
-        auto rejected = [&](double change_) -> bool { return new_cost > old_cost + change_; };
-#endif
         double alpha = 1.0;
         new_cost = cost_step(alpha);
         double change = PGDB_GAMMA * alpha * ipr;
-#ifndef FBX_NO_SMALL_STEP
         int small_fails = 0;
-#endif
         while (rejected(change)) {
-#ifndef FBX_NO_SMALL_STEP
             // Two series evaluations in a row have failed: this is one of the long halving runs of a
             // stalled iteration.  The rest of the ladder alpha 2^-L, L = 1, 2, ... is evaluated in ONE pass,
             // lane L taking its own alpha (same series; the listed outcomes, one per lane so far, are
             // walked from their LDS list by every lane), and the first L that the sequential loop would
             // have stopped at -- sufficient decrease, or alpha below the floor -- is taken.
-            if (small_fails >= 2 && !FBX_DBG_NOLADDER) {
+            if (small_fails >= 2) {
                 const double a_l = __builtin_ldexp(alpha, -lane), c_l = __builtin_ldexp(change, -lane);
                 double acc = series(a_l);
                 if (near_clip) {
@@ -674,11 +629,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
                     }
                 }
                 const double val = old_cost - acc;
-#ifndef FBX_LS_ROUNDED
                 const bool rej_l = -acc > c_l;
-#else
-                const bool rej_l = val > old_cost + c_l;
-#endif
                 const unsigned long long stop = __ballot(lane >= 1 && (a_l < PGDB_ALPHA_MIN || !rej_l));
                 const int Ls = __builtin_ctzll(stop);          // alpha <= 1: lane 50 is below the floor at the latest
                 alpha = __builtin_ldexp(alpha, -Ls); change = __builtin_ldexp(change, -Ls);
@@ -686,12 +637,9 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
                 backtracks += Ls;
                 break;
             }
-#endif
             alpha *= 0.5;
             change *= 0.5;
-#ifndef FBX_NO_SMALL_STEP
             if (small_regime(alpha)) ++small_fails;
-#endif
             new_cost = cost_step(alpha);
             ++backtracks;
             if (alpha < PGDB_ALPHA_MIN) break;

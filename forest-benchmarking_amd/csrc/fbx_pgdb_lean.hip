@@ -1,16 +1,7 @@
 // fbx_pgdb_lean.hip -- the two-wavefronts-per-SIMD form of the 2-qubit PGDB kernel (batches that put more than one reconstruction
 // on a SIMD anyway: BASELINE configs[4], 8192 per GPU).  Its own translation unit so that it keeps the compiler's default
 // instruction scheduling (fbx_pgdb_body.hpp).  Reference: tomography.py:542-633, operator_tools/project_superoperators.py:19-144.
-// -DFBX_LEAN_LOCAL_INDEX_MATH: per-phase index arithmetic recomputed instead of hoisted (fbx_common.hpp, FBX_LOCAL).  Measured in
-// round 4: scratch 160 -> 32 B per lane, and 62.5 against 61.8 ms at 8192 reconstructions (same box) -- the recomputation costs more
-// issue slots than the 32 spilled constants cost waits.  Off by default.
-#ifdef FBX_LEAN_LOCAL_INDEX_MATH
-#define FBX_LOCAL_INDEX_MATH
-#endif
 #include "fbx_pgdb_body.hpp"
-#ifndef FBX_LEAN_WAVES
-#define FBX_LEAN_WAVES 2          // wavefronts per SIMD the register budget is set for (3: 168 registers -- measured)
-#endif
 
 namespace fbx {
 
@@ -18,7 +9,7 @@ namespace fbx {
 // registers: TWO wavefronts per SIMD, i.e. two dependent Jacobi chains interleaved on every SIMD.  Results are bit-identical to
 // pgdb_kernel's (same arithmetic; only where operands are kept differs -- PgdbLds<NQ, true>).
 template <int NQ, int MAXJ>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FBX_LEAN_WAVES, FBX_LEAN_WAVES)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                  const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
                  double* __restrict__ choi_out, int* __restrict__ iters_out,
@@ -47,7 +38,7 @@ pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 // agent-scope acquire fence and reads.  A ticket's predecessor was drawn nb tickets earlier by a workgroup that is running, so the
 // wait is almost never entered and cannot deadlock.  Results are bit-identical to the one-launch-per-reconstruction form.
 template <int NQ, int MAXJ>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FBX_LEAN_WAVES, FBX_LEAN_WAVES)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pgdb_lean_pieces_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                         const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
                         double* __restrict__ choi_out, int* __restrict__ iters_out,

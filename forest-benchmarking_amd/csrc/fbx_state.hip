@@ -918,9 +918,6 @@ static int launch_eigh(int64_t B, const double* da, double* dw, double* dv) {
 
 using namespace fbx;
 
-#ifndef FBX_MLE_UNPACKED
-#define FBX_MLE_UNPACKED 0      // diagnostics: 1 = always one reconstruction per wavefront
-#endif
 
 // =====================================================================================================
 // 4 and 5 qubits (16 x 16 and 32 x 32 density matrices, 255 / 1023 settings): ONE WORKGROUP OF d*d THREADS per state
@@ -1293,7 +1290,7 @@ int fbx_mle_state_dev(const fbx_design* design, int64_t B, const double* d_expec
     if (n == 4) return launch_mle_big<4>(design, B, d_expect, d_counts, epsilon, entropy_penalty, beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
     if (n == 5) return launch_mle_big<5>(design, B, d_expect, d_counts, epsilon, entropy_penalty, beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
     const size_t lds = state_lds(n, (int)m);           // (designs beyond 64 KiB of per-setting staging take the streamed form: StateLds::staged)
-    const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D && !FBX_MLE_UNPACKED;
+    const bool packed = entropy_penalty == 0.0 && beta == 0.0 && n <= 2 && m <= D;
     if (packed && n == 1)
         hipLaunchKernelGGL(mle_state_packed_kernel<1>, dim3((unsigned)((B + 15) / 16)), dim3(64), 0, stream(), design->dev,
                            (long long)B, d_expect, epsilon, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);

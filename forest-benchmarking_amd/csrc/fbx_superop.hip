@@ -621,7 +621,6 @@ static int launch_sweep3_regs(int64_t B, int K, const double* kraus, const doubl
 
 static int launch_convert3(int from, int to, int64_t B, const double* in, int K, double* out) {
     constexpr size_t D = 64;
-#ifndef FBX_CONVERT3_GENERAL_ONLY
     const char* v1s = getenv("FBX_CONVERT3_V1");            // 1 = the one-stage-per-pass kernels (A/B, tests)
     const bool v1 = v1s && atoi(v1s) != 0;
     // from Kraus operators: the sweep kernel with one output (operators read once, the result written once, coalesced)
@@ -633,7 +632,6 @@ static int launch_convert3(int from, int to, int64_t B, const double* in, int K,
     if (from == FBX_REP_SUPEROP && to == FBX_REP_PAULI_LIOUVILLE) return v1 ? launch_convert3_fast<2>(B, in, out) : launch_convert3_regs<2>(B, in, out);
     if (from == FBX_REP_PAULI_LIOUVILLE && to == FBX_REP_SUPEROP) return v1 ? launch_convert3_fast<3>(B, in, out) : launch_convert3_regs<3>(B, in, out);
     if ((from == FBX_REP_CHOI && to == FBX_REP_SUPEROP) || (from == FBX_REP_SUPEROP && to == FBX_REP_CHOI)) return launch_convert3_fast<4>(B, in, out);
-#endif
     const size_t lds = 2 * sizeof(cplx) * D * D + sizeof(double) * 128 + sizeof(cplx) * (size_t)(K > 0 ? K : 1) * D;
     if (lds > 160 * 1024) { set_error("fbx_convert: too many Kraus operators for LDS staging (3 qubits: at most 31)"); return FBX_ERR_UNSUPPORTED; }
     FBX_HIP(hipFuncSetAttribute((const void*)convert3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -644,11 +642,7 @@ static int launch_convert3(int from, int to, int64_t B, const double* in, int K,
 
 // results of the sweep are written once and never re-read by the kernel: stream them past the caches
 typedef double fbx_d2v __attribute__((ext_vector_type(2)));
-#ifdef FBX_SWEEP_PLAIN_STORES
-#define FBX_STREAM_STORE(ptr, val) (*(ptr) = (val))
-#else
 #define FBX_STREAM_STORE(ptr, val) __builtin_nontemporal_store(fbx_d2v{(val).x, (val).y}, reinterpret_cast<fbx_d2v*>(ptr))
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // fused Kraus sweep (BASELINE config 3)
@@ -695,181 +689,9 @@ sweep_kernel(long long B, int K, const double* __restrict__ kraus, const double*
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 2-qubit sweep, tuned: the two basis changes are radix-2 butterflies over the four tensor sites
-// (each site pairs two index bits; I/Z = sum/difference of the (0,0),(1,1) entries, X/Y = sum /
-// +-i difference of the (0,1),(1,0) entries), done in place in LDS with one quad per lane, followed
-// by a bit-permuting gather so that every HBM store is a coalesced 1 KiB wave transaction.
-// Per item: 1 KiB read (K = 4), 12 KiB + 8 B written; 8 butterfly stages instead of two
-// 16 x 16 x 16 dense products.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int insert_zero_bits(int v, int lo, int hi) {   // lo < hi bit positions
-    int r = (v & ((1 << lo) - 1)) | ((v >> lo) << (lo + 1));                  // zero at `lo`
-    r = (r & ((1 << hi) - 1)) | ((r >> hi) << (hi + 1));                      // zero at `hi`
-    return r;
-}
-// one butterfly stage on the 16 x 16 matrix M (leading dimension 17): P / Q = bit positions in the
-// 8-bit element index row*16 + col; ysign = +1 / -1 selects +i / -i for the Y combination
-__device__ __forceinline__ void pauli_stage(cplx* M, int lane, int pbit, int qbit, double ysign) {
-    const int lo = pbit < qbit ? pbit : qbit, hi = pbit < qbit ? qbit : pbit;
-    const int base = insert_zero_bits(lane, lo, hi);
-    const int i00 = base, i11 = base | (1 << pbit) | (1 << qbit), i01 = base | (1 << qbit), i10 = base | (1 << pbit);
-    auto addr = [](int idx) { return (idx >> 4) * 17 + (idx & 15); };
-    const cplx c00 = M[addr(i00)], c11 = M[addr(i11)], c01 = M[addr(i01)], c10 = M[addr(i10)];
-    cplx oi, oz, ox, oy;
-    oi.re = c00.re + c11.re; oi.im = c00.im + c11.im;
-    oz.re = c00.re - c11.re; oz.im = c00.im - c11.im;
-    ox.re = c01.re + c10.re; ox.im = c01.im + c10.im;
-    const double dr = c01.re - c10.re, di = c01.im - c10.im;                 // +-i * (dr + i di)
-    oy.re = -ysign * di; oy.im = ysign * dr;
-    M[addr(i00)] = oi; M[addr(i11)] = oz; M[addr(i01)] = ox; M[addr(i10)] = oy;
-}
-
-// the same stage on two independent matrices at once: all eight loads are in flight before the first
-// butterfly, so the two transforms hide each other's LDS latency
-__device__ __forceinline__ void pauli_stage_pair(cplx* M0, int p0, int q0, double y0, cplx* M1, int p1, int q1,
-                                                 double y1, int lane) {
-    auto addr = [](int idx) { return (idx >> 4) * 17 + (idx & 15); };
-    int ix[2][4];
-    const int pb[2] = {p0, p1}, qb[2] = {q0, q1};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int lo = pb[k] < qb[k] ? pb[k] : qb[k], hi = pb[k] < qb[k] ? qb[k] : pb[k];
-        const int base = insert_zero_bits(lane, lo, hi);
-        ix[k][0] = addr(base); ix[k][1] = addr(base | (1 << pb[k]) | (1 << qb[k]));
-        ix[k][2] = addr(base | (1 << qb[k])); ix[k][3] = addr(base | (1 << pb[k]));
-    }
-    cplx c[2][4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { c[0][e] = M0[ix[0][e]]; c[1][e] = M1[ix[1][e]]; }
-    const double ys[2] = {y0, y1};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        cplx oi, oz, ox, oy;
-        oi.re = c[k][0].re + c[k][1].re; oi.im = c[k][0].im + c[k][1].im;
-        oz.re = c[k][0].re - c[k][1].re; oz.im = c[k][0].im - c[k][1].im;
-        ox.re = c[k][2].re + c[k][3].re; ox.im = c[k][2].im + c[k][3].im;
-        const double dr = c[k][2].re - c[k][3].re, di = c[k][2].im - c[k][3].im;
-        oy.re = -ys[k] * di; oy.im = ys[k] * dr;
-        cplx* M = k == 0 ? M0 : M1;
-        M[ix[k][0]] = oi; M[ix[k][1]] = oz; M[ix[k][2]] = ox; M[ix[k][3]] = oy;
-    }
-}
-
-__global__ void __launch_bounds__(64)
-sweep2q_kernel(long long B, int K, const double* __restrict__ kraus, const double* __restrict__ ptm_ref,
-               double* __restrict__ choi_out, double* __restrict__ ptm_out, double* __restrict__ chi_out,
-               double* __restrict__ fid_out) {
-    constexpr int D = 16, LD = 17;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx* A = (cplx*)smem;                 // Choi -> Pauli-Liouville
-    cplx* W = A + D * LD;                  // Choi -> chi
-    cplx* kb = W + D * LD;                 // vec of the Kraus operators
-    const int lane = threadIdx.x;
-    const int col = lane & 15, q = lane >> 4;
-    cplx ref[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        ref[r].re = ref[r].im = 0.0;
-        if (ptm_ref) { ref[r].re = ptm_ref[2 * (lane + 64 * r)]; ref[r].im = ptm_ref[2 * (lane + 64 * r) + 1]; }
-    }
-    // One wavefront per workgroup: its LDS instructions execute in program order, so the stages
-    // below need no barrier and no wait -- only a compiler fence that keeps LDS values out of
-    // registers across a stage boundary.  The next item's Kraus operators are fetched from HBM
-    // while the current item is transformed.
-#define FBX_WAVE_FENCE() asm volatile("" ::: "memory")
-    const int n_ld = (K * D + 63) / 64;              // 16-byte loads per lane and item (K <= 16: at most 4)
-    double2 nxt[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        nxt[u].x = nxt[u].y = 0.0;
-        const int idx = lane + 64 * u;
-        if (u < n_ld && idx < K * D && (long long)blockIdx.x < B)
-            nxt[u] = *reinterpret_cast<const double2*>(kraus + (blockIdx.x * (long long)K * D + idx) * 2);
-    }
-    for (long long item = blockIdx.x; item < B; item += gridDim.x) {
-        // ---- Kraus operators, stored as vec(K_t)[c*4 + r] = K_t[r][c]
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = lane + 64 * u;
-            if (u < n_ld && idx < K * D) {
-                const int t = idx >> 4, rr = (idx >> 2) & 3, cc = idx & 3;
-                cplx c; c.re = nxt[u].x; c.im = nxt[u].y;
-                kb[t * D + cc * 4 + rr] = c;
-            }
-        }
-        {
-            const long long nitem = item + gridDim.x;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = lane + 64 * u;
-                if (u < n_ld && idx < K * D && nitem < B)
-                    nxt[u] = *reinterpret_cast<const double2*>(kraus + (nitem * (long long)K * D + idx) * 2);
-            }
-        }
-        FBX_WAVE_FENCE();
-        // ---- kraus2choi: C[row][col] = sum_t vK_t[row] conj(vK_t[col]); lane owns rows q + 4 r
-        cplx acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r].re = acc[r].im = 0.0;
-        for (int t = 0; t < K; ++t) {
-            const cplx b = kb[t * D + col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const cplx a = kb[t * D + q + 4 * r];
-                acc[r].re += a.re * b.re + a.im * b.im;
-                acc[r].im += a.im * b.re - a.re * b.im;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            A[(q + 4 * r) * LD + col] = acc[r];
-            W[(q + 4 * r) * LD + col] = acc[r];
-            if (choi_out) {
-                double2 v; v.x = acc[r].re; v.y = acc[r].im;
-                FBX_STREAM_STORE(reinterpret_cast<double2*>(choi_out + (item * D * D + lane + 64 * r) * 2), v);
-            }
-        }
-        FBX_WAVE_FENCE();
-        // ---- Pauli-Liouville (A): sites pair (row bit, col bit); element index = row * 16 + col, so
-        // the row bits are index bits 7..4 (a1 a0 b1 b0) and the col bits 3..0; -i for the input
-        // qubits (P_j^T), +i for the output qubits (P_i).
-        // ---- chi (W): sites pair (a bit, b bit) of the same index; rows carry vec(P_k)^H, columns vec(P_l)
-        pauli_stage_pair(A, 7, 3, -1.0, W, 7, 5, -1.0, lane); FBX_WAVE_FENCE();
-        pauli_stage_pair(A, 6, 2, -1.0, W, 6, 4, -1.0, lane); FBX_WAVE_FENCE();
-        pauli_stage_pair(A, 5, 1, +1.0, W, 3, 1, +1.0, lane); FBX_WAVE_FENCE();
-        pauli_stage_pair(A, 4, 0, +1.0, W, 2, 0, +1.0, lane); FBX_WAVE_FENCE();
-        // ---- gather to matrix order, scale, store; process fidelity on the fly
-        double fr = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = lane + 64 * r, i = idx >> 4, j = idx & 15;
-            {   // R[i][j]: digits (2 rowbit + colbit): i = 8 b1 + 4 b1' + 2 b0 + b0', j likewise from a
-                const int row = ((j >> 3) & 1) << 3 | ((j >> 1) & 1) << 2 | ((i >> 3) & 1) << 1 | ((i >> 1) & 1);
-                const int cl = ((j >> 2) & 1) << 3 | (j & 1) << 2 | ((i >> 2) & 1) << 1 | (i & 1);
-                cplx v = A[row * LD + cl]; v.re *= 0.25; v.im *= 0.25;
-                fr += ref[r].re * v.re + ref[r].im * v.im;
-                if (ptm_out) { double2 o; o.x = v.re; o.y = v.im; FBX_STREAM_STORE(reinterpret_cast<double2*>(ptm_out + (item * D * D + idx) * 2), o); }
-            }
-            if (chi_out) {   // chi[k][l]: k = 8 a1 + 4 b1 + 2 a0 + b0 over the row bits (a1 a0 b1 b0)
-                const int row = ((i >> 3) & 1) << 3 | ((i >> 1) & 1) << 2 | ((i >> 2) & 1) << 1 | (i & 1);
-                const int cl = ((j >> 3) & 1) << 3 | ((j >> 1) & 1) << 2 | ((j >> 2) & 1) << 1 | (j & 1);
-                cplx v = W[row * LD + cl]; v.re *= 0.0625; v.im *= 0.0625;
-                double2 o; o.x = v.re; o.y = v.im;
-                FBX_STREAM_STORE(reinterpret_cast<double2*>(chi_out + (item * D * D + idx) * 2), o);
-            }
-        }
-        if (fid_out) {
-            fr = wave_sum(fr);
-            if (lane == 0) fid_out[item] = (4.0 * (fr / 16.0) + 1.0) / 5.0;
-        }
-        FBX_WAVE_FENCE();
-    }
-#undef FBX_WAVE_FENCE
-}
 
 // ---------------------------------------------------------------------------------------------
-// sweep2q_pair_kernel: the same pipeline with HALF the LDS traffic (the kernel above is LDS-bandwidth
+// sweep2q_pair_kernel: the same pipeline with HALF the LDS traffic (round 1's one-item-per-wavefront kernel was LDS-bandwidth
 // bound: ~100 KB per item).  A wavefront takes TWO Kraus sets; 16 lanes own one 16 x 16 matrix (A ->
 // Pauli-Liouville and W -> chi of each item), 16 elements per lane, so that TWO butterfly stages run in
 // registers per pass and one LDS transpose separates the two passes.  The passes are ordered so that the
@@ -1019,14 +841,8 @@ sweep2q_pair_kernel(long long B, int K, const double* __restrict__ kraus, const 
 #undef FBX_WAVE_FENCE
 }
 
-// build-time selection of the 2-qubit sweep kernel (diagnostics): 0 = paired items (product),
-// 1 = one item per wavefront, 2 = the generic kernel
-#ifndef FBX_SWEEP_VARIANT
-#define FBX_SWEEP_VARIANT 0
-#endif
-#ifndef FBX_SWEEP_GRID
+// persistent grid of the 2-qubit sweep: 8 wavefronts resident per CU, the rest queued
 #define FBX_SWEEP_GRID (256 * 16)
-#endif
 static_assert(FBX_SWEEP_GRID > 0, "FBX_SWEEP_GRID must be positive");
 
 template <int NQ>
@@ -1035,7 +851,7 @@ static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm
     constexpr int d = 1 << NQ, D = d * d, LD = D + 1;
     const size_t lds = sizeof(cplx) * (4 * D * LD + (size_t)K * D);
     if (lds > 160 * 1024) { set_error("fbx_kraus_sweep: too many Kraus operators"); return FBX_ERR_UNSUPPORTED; }
-    if (NQ == 2 && K <= 16 && FBX_SWEEP_VARIANT == 0) {
+    if (NQ == 2 && K <= 16) {
         // reference in Choi form for the on-the-fly fidelity (one 16 x 16 conversion per call, into a
         // workspace of the calling thread)
         double* choi_ref = nullptr;
@@ -1051,13 +867,6 @@ static int launch_sweep(int64_t B, int K, const double* kraus, const double* ptm
         const unsigned gridp = (unsigned)(n_pairs < cap ? n_pairs : cap);
         hipLaunchKernelGGL(sweep2q_pair_kernel, dim3(gridp), dim3(64), ldsp, stream(), (long long)B, K, kraus,
                            (const double*)choi_ref, choi, ptm, chi, fid);
-        FBX_HIP(hipGetLastError());
-        return FBX_OK;
-    }
-    if (NQ == 2 && K <= 16 && FBX_SWEEP_VARIANT == 1) {
-        const size_t lds2 = sizeof(cplx) * (2 * 16 * 17 + (size_t)K * 16);
-        const unsigned grid2 = (unsigned)(B < 256 * 16 ? B : 256 * 16);
-        hipLaunchKernelGGL(sweep2q_kernel, dim3(grid2), dim3(64), lds2, stream(), (long long)B, K, kraus, ptm_ref, choi, ptm, chi, fid);
         FBX_HIP(hipGetLastError());
         return FBX_OK;
     }

@@ -272,10 +272,10 @@ def test_lean_two_waves_per_simd_kernel_agrees_with_the_one_wave_kernel(gpu, bas
         # 60 fixed iterations run past convergence, where the halving count of a stalled iteration is decided at rounding level
         # (measured 2.7e-10 / +-152 halvings in 60 iterations; scripts/lean_vs_onewave_diffs.py)
         conv = kw["mode"] == "converge"
-        assert np.abs(big[:128] - small).max() < (1e-12 if conv else 1e-9)
+        assert np.abs(big[:128] - small).max() < (1e-12 if conv else 5e-10)     # measured: 6e-14 / 2.7e-10
         for k in ("iterations", "dykstra") + (("backtracks",) if conv else ()):
             assert np.array_equal(sb[k][:128], ss[k]) and np.array_equal(sb[k][-128:], ss[k]), k
-        assert np.abs(sb["backtracks"][:128].astype(int) - ss["backtracks"]).max() <= (0 if conv else 200)
+        assert np.abs(sb["backtracks"][:128].astype(int) - ss["backtracks"]).max() <= (0 if conv else 170)      # measured: 152
         assert np.abs(sb["cost"][:128] - ss["cost"]).max() < 1e-13
 
 
