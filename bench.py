@@ -687,9 +687,13 @@ def pgdb_roofline(batch, st, kernel_s, iters):
     kernel never performs and exceeds the peak at large batches, so it is not a utilisation figure."""
     B, m, S = batch.B, batch.design.m, batch.design.n_states
     dense = B * ALGO_FLOP_PER_RECON * (iters / 100.0) / kernel_s / 1e12
-    ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"], two_workers=B <= 1024)
+    # which kernel ran (csrc/fbx_pgdb.hip launch_pgdb): the two-waves-per-SIMD body from 1025 items on when the design's Bloch table fits
+    # beside the Pauli coefficients (at most 50 input states), else the one-wave body -- whose eigensolver has two workers per block
+    lean = B > 1024 and S <= 50
+    ex, parts = pgdb2q_executed_flop(m, S, st["iterations"], st["dykstra"], st["backtracks"], st["work"], two_workers=not lean)
     algo_bytes = 2 * m * 8 + 4096
-    kernel = ("pgdb_lean_pieces_kernel" if B > 1024 else "pgdb_kernel") + ("<2,9>" if m > 256 else "<2,4>")
+    kernel = ("pgdb_lean_pieces_kernel" if lean else "pgdb_pieces_kernel" if B > 1024 else "pgdb_kernel") + \
+             ("<2,4>" if m <= 256 else "<2,9>" if m <= 576 else "<2,16>")
     measured = _measured_flop(kernel, B)
     mfma_measured = _measured_mfma_flop(kernel, B)
     out = {"bound": "mfma", "pipe": "fp64 VALU + MFMA", "achieved": B * ex / kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,

@@ -220,7 +220,8 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
             void* w = nullptr;
             const int rc = workspace(WS_PGDB_BASIS, total, &w);
             if (rc == FBX_OK) { wsp = (char*)w; break; }
-            if (rc != FBX_ERR_NOMEM || ex.ws_items > 0 || ws_items <= 1024) return rc;
+            // (the streamed instantiations keep 16 B x m of normalised counts per slot: a huge merged design may need fewer slots than 1024)
+            if (rc != FBX_ERR_NOMEM || ex.ws_items > 0 || ws_items <= (STREAM ? 1 : 1024)) return rc;
             (void)hipGetLastError();
             ws_items /= 2; CHUNK = ws_items;
         }
@@ -266,7 +267,8 @@ static int launch_pgdb(const fbx_design* des, int64_t B, const double* e, const 
                     // and allows ~10 ms per outer iteration -- 50 x what one costs on a device that several launches share.  Long
                     // pieces buy nothing (the tail of a launch is one piece either way): a caller with a huge fixed iteration
                     // count gets more pieces (up to 64) and, beyond 512 iterations per piece, whole reconstructions.
-                    while (a.piece_iters > 64 && pieces < 64 && (int64_t)pieces * 2 * nb < (int64_t)1 << 30) { pieces *= 2; a.piece_iters = (span + pieces - 1) / pieces; }
+                    // (an explicit FBX_LEAN_PIECE_ITERS is taken as given: no doubling)
+                    while (!(wv && *wv) && a.piece_iters > 64 && pieces < 64 && (int64_t)pieces * 2 * nb < (int64_t)1 << 30) { pieces *= 2; a.piece_iters = (span + pieces - 1) / pieces; }
                     if (a.piece_iters > 512) pieces = 1;
                 }
                 if (pieces > 1) {

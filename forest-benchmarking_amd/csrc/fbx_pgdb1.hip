@@ -17,7 +17,7 @@
 // Replaces (file:line under forest/benchmarking/): pgdb_process_estimate tomography.py:542-594 with _cost / _grad_cost
 // :597-633 and proj_choi_to_physical operator_tools/project_superoperators.py:87-144, for n_qubits = 1.
 #include "fbx_common.hpp"
-#ifdef FBX_P1_PROFILE
+#ifdef FBX_PHASE_TIMERS
 // profile build (scripts/pgdb1_phase_profile.py): wall cycles of a wavefront between the marks of an outer iteration
 // [0] gradient, [1] projection, [2] update + first cost, [3] line search, [4] whole kernel per wavefront; trip counts as the
 // WAVEFRONT runs them (odd slot) and summed over its lanes (the even slot that follows): 5/6 outer iterations, 7/8 Dykstra
@@ -343,7 +343,7 @@ static int pgdb1_binned_chunk(const fbx_design* des, long long first, long long 
     return FBX_OK;
 }
 
-#ifdef FBX_P1_PROFILE
+#ifdef FBX_PHASE_TIMERS
 static int pgdb1_dispatch_(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode, int max_iters,
                    double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw, const PgdbExtras& ex);
 int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const double* c, int tp, int mode, int max_iters,

@@ -22,7 +22,7 @@
 #include <cstdint>
 #include <cmath>
 
-// profiling hooks (defined by fbx_pgdb1.hip in -DFBX_P1_PROFILE builds only): wall cycles between marks, wave-level trip counts
+// profiling hooks (defined by fbx_pgdb1.hip in -DFBX_PHASE_TIMERS builds only: build.py --profile): wall cycles between marks, wave-level trip counts
 #ifndef P1_PROF_BEGIN
 #define P1_PROF_BEGIN
 #define P1_PROF(k)

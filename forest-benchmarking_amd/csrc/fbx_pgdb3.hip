@@ -71,7 +71,7 @@ __device__ __forceinline__ double bsum(double v, Lds& L) { return block_sum<NT>(
 // loads per thread and call for the Dykstra stopping functional: 17 k cycles of the ~420 k of a Dykstra iteration).
 template <int K>
 __device__ __forceinline__ void bsum_multi(double (&v)[K], Lds& L) {
-    static_assert(K <= 8 && NT / 64 == 16, "sixteen wavefronts, at most two values per row of lanes");
+    static_assert((K <= 4 || K == 8) && NT / 64 == 16, "sixteen wavefronts; the second-stage load of values 4 .. K - 1 indexes with a mask: K x 16 must be a power of two");
     const int lane = threadIdx.x & 63;
     double mine = 0.0;                                  // lane k < K publishes value k of this wavefront
 #pragma unroll

@@ -71,7 +71,7 @@ static int lean_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {
     return FBX_OK;
 }
 
-// Designs beyond the register-resident instantiations (2 qubits: more than 1024 settings; 1 qubit: more than 1024): the same
+// Designs beyond the register-resident instantiations (2 qubits: more than 1024 settings; 1 qubit: more than 256): the same
 // kernel with MAXJ = 0 -- outcome slots streamed from HBM / L2 (fbx_pgdb_body.hpp, STREAM), whole reconstructions.
 template <int NQ>
 static int stream_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {

@@ -434,16 +434,18 @@ int fbx_get_option(const char* name, double* value) {
 
 int fbx_release_workspace(void) {
     if (g_device.load() < 0) return FBX_OK;
+    int worker_rc = FBX_OK;
     if (!in_device_worker() && device_list_size() > 1) {      // the workers of the device list hold the memory of multi-device calls
         std::lock_guard<std::mutex> lk(g_workers_mu);
         for (Worker* w : g_workers) worker_post(w, [] { return fbx_release_workspace(); });
-        for (Worker* w : g_workers) (void)worker_wait(w);
+        for (Worker* w : g_workers) { const int rc = worker_wait(w); if (rc != FBX_OK && worker_rc == FBX_OK) worker_rc = rc; }
     }
-    if (!t_ctx) return FBX_OK;
-    ThreadCtx* c = t_ctx;
-    if (c->stream && c->epoch == g_epoch.load()) FBX_HIP(hipStreamSynchronize(c->stream));
-    c->drop_memory();
-    return FBX_OK;
+    if (t_ctx) {
+        ThreadCtx* c = t_ctx;
+        if (c->stream && c->epoch == g_epoch.load()) FBX_HIP(hipStreamSynchronize(c->stream));
+        c->drop_memory();
+    }
+    return worker_rc;                 // the first failure of a device worker's release, if any
 }
 
 int fbx_malloc(void** dev_ptr, size_t bytes) {

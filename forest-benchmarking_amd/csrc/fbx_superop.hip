@@ -1629,17 +1629,36 @@ int fbx_convert_dev(int from_rep, int to_rep, int n_qubits, int64_t B, const dou
         if (n_qubits == 1) return launch_convert<1>(from, to, B, in, k, out);
         return launch_convert<2>(from, to, B, in, k, out);
     };
+    auto dispatch_n = [&](int from, int to, int64_t nb, const double* in, int k, double* out, bool psd) -> int {
+        if (n_qubits == 5) return launch_convert_big<5>(from, to, nb, in, k, out, psd);
+        if (n_qubits == 4) return launch_convert_big<4>(from, to, nb, in, k, out, psd);
+        if (n_qubits == 3) return launch_convert3(from, to, nb, in, k, out);
+        if (n_qubits == 1) return launch_convert<1>(from, to, nb, in, k, out);
+        return launch_convert<2>(from, to, nb, in, k, out);
+    };
     const int rc = dispatch(from_rep, to_rep, d_in, K, d_out, false);
+    // (from a Kraus set the launchers above return FBX_ERR_UNSUPPORTED for exactly one reason: K operators do not fit their LDS staging)
     if (rc != FBX_ERR_UNSUPPORTED || from_rep != FBX_REP_KRAUS) return rc;
     // More Kraus operators than the fused kernels stage in LDS (K x D x 16 B against 160 KiB: 40 operators for 4 qubits, 10 for
     // 5): the Choi matrix from the basis-free kernel, which takes any K (one thread per entry, operators read through L2),
-    // then on from there -- the Choi matrix of a Kraus set is PSD, so the way into chi is the linear one.
-    const size_t D = (size_t)1 << (2 * n_qubits);
-    if (to_rep == FBX_REP_CHOI) return fbx_convert_general_dev(FBX_REP_KRAUS, FBX_REP_CHOI, 1 << n_qubits, B, d_in, K, d_out);
-    DevBuf choi;
-    FBX_TRY(choi.alloc(D * D * sizeof(cplx) * (size_t)B));
-    FBX_TRY(fbx_convert_general_dev(FBX_REP_KRAUS, FBX_REP_CHOI, 1 << n_qubits, B, d_in, K, choi.as<double>()));
-    return dispatch(FBX_REP_CHOI, to_rep, choi.as<double>(), 0, d_out, true);
+    // then on from there -- the Choi matrix of a Kraus set is PSD, so the way into chi is the linear one.  In chunks of at
+    // most 256 MiB of Choi matrices (a 5-qubit item is 16 MiB), like convert_into_chi_big.
+    const size_t D = (size_t)1 << (2 * n_qubits), d = (size_t)1 << n_qubits;
+    int rc2 = FBX_OK;
+    if (to_rep == FBX_REP_CHOI) rc2 = fbx_convert_general_dev(FBX_REP_KRAUS, FBX_REP_CHOI, 1 << n_qubits, B, d_in, K, d_out);
+    else {
+        const size_t per_item = D * D * sizeof(cplx);
+        const int64_t chunk = (int64_t)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)256 << 20) / per_item));
+        DevBuf choi;
+        FBX_TRY(choi.alloc(per_item * (size_t)chunk));
+        for (int64_t b0 = 0; b0 < B && rc2 == FBX_OK; b0 += chunk) {
+            const int64_t nb = std::min<int64_t>(chunk, B - b0);
+            rc2 = fbx_convert_general_dev(FBX_REP_KRAUS, FBX_REP_CHOI, 1 << n_qubits, nb, d_in + (size_t)b0 * K * d * d * 2, K, choi.as<double>());
+            if (rc2 == FBX_OK) rc2 = dispatch_n(FBX_REP_CHOI, to_rep, nb, choi.as<double>(), 0, d_out + (size_t)b0 * D * D * 2, true);
+        }
+    }
+    if (rc2 == FBX_OK) set_error("");              // the fused path's "too many Kraus operators" is not this call's outcome
+    return rc2;
 }
 
 static int convert_general_check(int from_rep, int to_rep, int dim, int64_t B, const void* in, int K, const void* out) {

@@ -101,7 +101,10 @@ int         fbx_set_devices(const int* device_ids, int count);
 int         fbx_device_name(char* buf, size_t len, int* compute_units);
 int         fbx_device_id(int* ordinal, char* pci_bus_id, size_t len);   /* the selected device; "0000:05:00.0"-style id (len >= 16) */
 int         fbx_synchronize(void);                  /* the calling thread's stream */
-int         fbx_release_workspace(void);            /* free the calling thread's cached device workspaces / staging pool */
+/* Frees the calling thread's cached device workspaces / staging pool.  With a device list of more than one entry
+ * (fbx_set_devices) it ALSO asks every device worker to free its own and waits for them: it takes the device-list lock, so it
+ * blocks while a multi-device call of any thread is running, and returns the first worker's error code if one fails. */
+int         fbx_release_workspace(void);
 /* Process-wide DEFAULTS, read when a kernel is launched.  A thread that needs its own value passes it per call
  * (fbx_pgdb_process_ex): changing an option changes the arithmetic of every thread's later launches.
  *   "pgdb_eig_rel_tol"  (default 1e-8), "pgdb3_eig_rel_tol" (default 1e-7; 3 qubits): while the projected-gradient

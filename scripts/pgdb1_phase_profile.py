@@ -1,9 +1,9 @@
 """Where a wavefront of the single-qubit lane-per-item kernel spends its cycles (profile build: python
-forest-benchmarking_amd/build.py --variant p1prof -DFBX_P1_PROFILE with FBX_VARIANT_SOURCES=fbx_pgdb1.hip).
+forest-benchmarking_amd/build.py --profile).
 usage: python scripts/pgdb1_phase_profile.py [log2 B] [basis]; the library prints one P1PROF line per call on stderr."""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["FBX_LIBRARY"] = os.path.join(ROOT, "forest-benchmarking_amd", "libfbx_p1prof.so")
+os.environ["FBX_LIBRARY"] = os.path.join(ROOT, "forest-benchmarking_amd", "libfbx_prof.so")
 sys.path.insert(0, os.path.join(ROOT, "forest-benchmarking_amd"))
 import numpy as np
 from fbx import synthetic, _lib
