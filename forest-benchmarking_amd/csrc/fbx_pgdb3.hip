@@ -813,22 +813,96 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
             }
             auto cost_at = [&](double a) -> double {
                 double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < MAXJ; ++j) {
+                auto slot = [&](int j) __attribute__((always_inline)) {
                     if (t * MAXJ + j < m) {
                         double pp = fma(a, pup[j], pep[j]), pm = fma(a, pum[j], pem[j]);
                         pp = pp < EPS ? EPS : pp; pm = pm < EPS ? EPS : pm;
                         acc -= npl[j] * fast_log_pos(pp) + nmi[j] * fast_log_pos(pm);
                     }
+                };
+                // (beyond four slots the six slot arrays do not fit the 128 registers of a thread: they live in scratch and the passes
+                //  over them are loops -- same terms in the same order)
+                if constexpr (MAXJ <= 4) {
+#pragma unroll
+                    for (int j = 0; j < MAXJ; ++j) slot(j);
+                } else {
+#pragma unroll 1
+                    for (int j = 0; j < MAXJ; ++j) slot(j);
                 }
                 return bsum(acc, L);
             };
+            // Round 6: once two halvings have failed -- the long runs of a stalled iteration, ~50 halvings each -- the NEXT KL halvings
+            // are evaluated in ONE pass over the thread's outcomes (one read of the six per-slot arrays, which live in scratch for the
+            // Pauli in-basis: 1.4 KB per thread = 0.7 MB per workgroup through L2 / HBM per evaluation, what bounded this phase) and the
+            // loop below walks them in order.  Every cost is the same sum in the same order as cost_at's (per-thread terms by slot, the
+            // wavefront reduction, the sixteen partials added in wavefront order): the accepted step and every count are
+            // BIT-IDENTICAL to the one-at-a-time loop; what changes is that up to KL - 1 evaluations behind the accepted one are wasted.
+#ifndef FBX3_LADDER
+#define FBX3_LADDER 4
+#endif
+            constexpr int KL = FBX3_LADDER;
+            auto cost_ladder = [&](double a0, double (&out)[KL]) __attribute__((always_inline)) {
+                double acc[KL];
+#pragma unroll
+                for (int k = 0; k < KL; ++k) acc[k] = 0.0;
+                auto slot = [&](int j) __attribute__((always_inline)) {
+                    if (t * MAXJ + j < m) {
+                        const double ep_ = pep[j], em_ = pem[j], up_ = pup[j], um_ = pum[j], np_ = npl[j], nm_ = nmi[j];
+                        double a = a0;
+#pragma unroll
+                        for (int k = 0; k < KL; ++k) {
+                            double pp = fma(a, up_, ep_), pm = fma(a, um_, em_);
+                            pp = pp < EPS ? EPS : pp; pm = pm < EPS ? EPS : pm;
+                            acc[k] -= np_ * fast_log_pos(pp) + nm_ * fast_log_pos(pm);
+                            a *= 0.5;
+                            __builtin_amdgcn_sched_barrier(0);      // one step's two logarithms at a time: interleaved chains spill
+                        }
+                    }
+                };
+                if constexpr (MAXJ <= 4) {                      // register-resident slot arrays: static indices
+#pragma unroll
+                    for (int j = 0; j < MAXJ; ++j) slot(j);
+                } else {                                        // slot arrays in scratch anyway: a loop
+#pragma unroll 1
+                    for (int j = 0; j < MAXJ; ++j) slot(j);
+                }
+#pragma unroll
+                for (int k = 0; k < KL; ++k) acc[k] = wave_sum(acc[k]);
+                FBX_BLOCK_SYNC();                               // earlier readers of `red` are done
+                if ((t & 63) == 0) {
+#pragma unroll
+                    for (int k = 0; k < KL; ++k) L.red[k * (NT / 64) + (t >> 6)] = acc[k];
+                }
+                FBX_BLOCK_SYNC();
+#pragma unroll
+                for (int k = 0; k < KL; ++k) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NT / 64; ++w) sum += L.red[k * (NT / 64) + w];
+                    out[k] = sum;
+                }
+            };
             new_cost = cost_at(alpha); ++cost_evals;
             double change = GAMMA * alpha * ipr;
+            int fails = 0;
             while (new_cost > old_cost + change) {
+                if (fails >= 2) {
+                    double lad[KL];
+                    cost_ladder(0.5 * alpha, lad); cost_evals += KL;
+                    bool stop = false;
+#pragma unroll
+                    for (int k = 0; k < KL; ++k) {
+                        if (!stop) {
+                            alpha *= 0.5; change *= 0.5; new_cost = lad[k]; ++backtracks;
+                            stop = alpha < ALPHA_MIN || !(new_cost > old_cost + change);
+                        }
+                    }
+                    if (stop) break;
+                    continue;
+                }
                 alpha *= 0.5; change *= 0.5;
                 new_cost = cost_at(alpha); ++cost_evals;
-                ++backtracks;
+                ++backtracks; ++fails;
                 if (alpha < ALPHA_MIN) break;
             }
         }
