@@ -54,26 +54,35 @@ def _proj_general(kind, x, d, return_iters):
         out = _cp_general(x)
     elif kind in (_lib.PROJ_TP, _lib.PROJ_TNI):
         out = _tp_general(x, d, kind == _lib.PROJ_TNI)
-    else:                                                       # Dykstra, :87-144, one item at a time
+    else:
+        # Dykstra, :87-144, the WHOLE batch in lockstep: every iteration is one batched eigendecomposition + product (CP) and one
+        # batched partial trace (TP / TNI) over the items that are still running -- 3 device calls per iteration instead of 3 per
+        # iteration and item.  An item's numbers do not depend on its neighbours (one workgroup per matrix), and its scalar
+        # stopping rule is evaluated with the very expressions of the one-at-a-time form: same result, bit for bit.
         out = np.empty_like(x)
         tni = kind == _lib.PROJ_PHYSICAL_TNI
-        for b in range(x.shape[0]):
-            old_cp = np.zeros_like(x[b]); old_tp = np.zeros_like(x[b]); last_cp = np.zeros_like(x[b])
-            last_state = x[b]
-            while True:
-                iters[b] += 1
-                pre_cp = last_state - old_cp
-                cp = _cp_general(pre_cp[None])[0]
-                new_cp = cp - pre_cp
-                pre_tp = cp - old_tp
-                new_state = _tp_general(pre_tp[None], d, tni)[0]
-                new_tp = new_state - pre_tp
-                crit = (np.linalg.norm(new_cp - old_cp) ** 2 + np.linalg.norm(new_tp - old_tp) ** 2
-                        + 2 * abs(np.vdot(old_tp, new_state - last_state)) + 2 * abs(np.vdot(old_cp, cp - last_cp)))
-                if not crit >= 1e-4:
-                    break
-                old_cp, old_tp, last_cp, last_state = new_cp, new_tp, cp, new_state
-            out[b] = new_state
+        B = x.shape[0]
+        old_cp = np.zeros_like(x); old_tp = np.zeros_like(x); last_cp = np.zeros_like(x)
+        last_state = x.copy()
+        active = np.arange(B)
+        while active.size:
+            iters[active] += 1
+            pre_cp = last_state[active] - old_cp[active]
+            cp = _cp_general(pre_cp)
+            new_cp = cp - pre_cp
+            pre_tp = cp - old_tp[active]
+            new_state = _tp_general(pre_tp, d, tni)
+            new_tp = new_state - pre_tp
+            running = np.zeros(active.size, dtype=bool)
+            for k, b in enumerate(active):
+                crit = (np.linalg.norm(new_cp[k] - old_cp[b]) ** 2 + np.linalg.norm(new_tp[k] - old_tp[b]) ** 2
+                        + 2 * abs(np.vdot(old_tp[b], new_state[k] - last_state[b])) + 2 * abs(np.vdot(old_cp[b], cp[k] - last_cp[b])))
+                running[k] = crit >= 1e-4                        # (a NaN ends the item, as `not crit >= 1e-4` does)
+            done = active[~running]
+            out[done] = new_state[~running]
+            keep = active[running]
+            old_cp[keep], old_tp[keep], last_cp[keep], last_state[keep] = new_cp[running], new_tp[running], cp[running], new_state[running]
+            active = keep
     return (out, iters) if return_iters else out
 
 

@@ -294,3 +294,29 @@ def test_choi_projections_beyond_three_qubits_and_for_a_qutrit(gpu):
             got, its = ps.proj_choi_batch(kind, x[None], return_iters=True)
             assert its[0] == it and np.abs(got[0] - want).max() < 1e-10
             assert d == 3 or it < 40
+
+
+def test_generic_dykstra_runs_the_batch_in_lockstep(gpu):
+    """Choi projections outside the fused kernels (qutrits, 4-5 qubits) advance the whole batch per Dykstra iteration -- three device
+    calls per iteration, not per iteration and item.  Items leave when their own stopping rule fires: every item must equal its
+    one-at-a-time result bit for bit, with its own iteration count (the oracle's)."""
+    from fbx.operator_tools import project_superoperators as ps
+    from fbx import _lib
+    from fbx_oracle import superops as so
+    rs = np.random.RandomState(77)
+    d, D = 3, 9
+    xs = []
+    for noise in (0.02, 0.3, 0.08, 1.0, 0.0, 0.15):
+        k = rs.randn(2, d, d) + 1j * rs.randn(2, d, d)
+        w, v = np.linalg.eigh(sum(q.conj().T @ q for q in k))
+        k = k @ (v @ np.diag(w ** -0.5) @ v.conj().T)
+        xs.append(so.kraus2choi(list(k)) + noise * (rs.randn(D, D) + 1j * rs.randn(D, D)))
+    xs = np.array(xs)
+    for kind, tp in ((_lib.PROJ_PHYSICAL_TP, True), (_lib.PROJ_PHYSICAL_TNI, False)):
+        got, its = ps.proj_choi_batch(kind, xs, return_iters=True)
+        assert len(set(its.tolist())) >= 3                                         # the items really leave at different iterations
+        for b in range(len(xs)):
+            one, it1 = ps.proj_choi_batch(kind, xs[b][None], return_iters=True)
+            assert np.array_equal(one[0], got[b]) and it1[0] == its[b]
+            want, it = so.proj_choi_to_physical(xs[b], tp, return_iters=True)
+            assert its[b] == it and np.abs(got[b] - want).max() < 1e-10
