@@ -298,49 +298,125 @@ bool pgdb1_eligible(const fbx_design* des) { return des->dev.n == 1 && des->dev.
 
 static long long env_ll(const char* name, long long dflt) { const char* v = getenv(name); return v && *v ? atoll(v) : dflt; }
 
-// Binned relaunch of one chunk of the batch (items [first, first + n) of the caller's arrays).
-static int pgdb1_binned_chunk(const fbx_design* des, long long first, long long n, const double* e, const double* c, int tp, int mode,
-                              int max_iters, double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw,
-                              const PgdbExtras& ex, long long tail_items, int check_every) {
-    const int m = des->dev.m;
-    const size_t lds = sizeof(double) * 2 * (size_t)m * 64;
-    FBX_HIP(hipFuncSetAttribute((const void*)pgdb1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    P1Bins bins;
-    bins.cap_slots = (n + 63) / 64 * 64;
-    const size_t region_doubles = (size_t)(P1_NB / 2) * bins.cap_slots * P1_NF;          // one set of bin regions
-    const size_t tab_doubles = (size_t)n * 2 * m;
-    void* w = nullptr;
-    // (no room for the bins: the caller falls back to the persistent kernel, which needs none)
-    if (workspace(WS_PGDB1_BINS, 256 + (tab_doubles + 2 * region_doubles) * sizeof(double), &w) != FBX_OK) { (void)hipGetLastError(); return FBX_ERR_NOMEM; }
-    int* cnt = (int*)w;                                   // three count arrays of 16 ints
-    bins.tab = (double*)((char*)w + 256);
-    double* region[2] = {bins.tab + tab_doubles, bins.tab + tab_doubles + region_doubles};
-    hipStream_t st = stream();
-    FBX_HIP(hipMemsetAsync(cnt, 0, 256, st));
-    DesignDev d = des->dev;
-    long long active_bound = n;                           // no more than this many reconstructions are still running
-    int host_cnt[P1_NB];
-    for (int step = 0;; ++step) {
+// Binned relaunch of one chunk of the batch (items [first, first + n) of the caller's arrays), advanced ONE LAUNCH AT A TIME so that
+// the chunks of a call can be interleaved on two streams (round 6, pgdb1_binned_run below).
+struct P1Run {
+    const fbx_design* des = nullptr; long long first = 0, n = 0; const double* e = nullptr; const double* c = nullptr;
+    int tp = 0, mode = 0, max_iters = 0; double* choi = nullptr; int32_t *it = nullptr, *dy = nullptr, *bt = nullptr; double* cost = nullptr;
+    int32_t* sw = nullptr; PgdbExtras ex; long long tail_items = 0; int check_every = 8;
+    hipStream_t st = nullptr; size_t lds = 0;
+    P1Bins bins; int* cnt = nullptr; double* region[2] = {nullptr, nullptr};
+    long long active_bound = 0; int step = 0; bool done = false, reading = false;
+    int* host_cnt = nullptr;              // [P1_NB], page-locked or plain: the destination of the asynchronous read-back
+
+    static size_t workspace_bytes(long long n, int m) {
+        const long long cap = (n + 63) / 64 * 64;
+        const size_t region_doubles = (size_t)(P1_NB / 2) * cap * P1_NF;
+        return (256 + ((size_t)n * 2 * m + 2 * region_doubles) * sizeof(double) + 255) & ~(size_t)255;
+    }
+    int start(void* w) {
+        const int m = des->dev.m;
+        lds = sizeof(double) * 2 * (size_t)m * 64;
+        bins.cap_slots = (n + 63) / 64 * 64;
+        const size_t region_doubles = (size_t)(P1_NB / 2) * bins.cap_slots * P1_NF, tab_doubles = (size_t)n * 2 * m;
+        cnt = (int*)w;                                    // three count arrays of 16 ints
+        bins.tab = (double*)((char*)w + 256);
+        region[0] = bins.tab + tab_doubles; region[1] = region[0] + region_doubles;
+        FBX_HIP(hipMemsetAsync(cnt, 0, 256, st));
+        active_bound = n; step = 0; done = n <= 0; reading = false;
+        return FBX_OK;
+    }
+    // enqueue the next launch (and, when due, the read-back of how many reconstructions are left)
+    int advance() {
+        if (done || reading) return FBX_OK;
         bins.cur = region[step & 1]; bins.next = region[(step + 1) & 1];
         bins.cur_count = cnt + 16 * (step % 3); bins.next_count = cnt + 16 * ((step + 1) % 3); bins.clear_count = cnt + 16 * ((step + 2) % 3);
         const bool tail = step > 0 && active_bound <= tail_items;
         const long long grid = (active_bound + 63) / 64 + (step == 0 ? 0 : P1_NB);
-        hipLaunchKernelGGL(pgdb1_step_kernel, dim3((unsigned)grid), dim3(64), lds, st, d, first, n, e, c, tp, mode, max_iters,
+        hipLaunchKernelGGL(pgdb1_step_kernel, dim3((unsigned)grid), dim3(64), lds, st, des->dev, first, n, e, c, tp, mode, max_iters,
                            choi, it, dy, bt, cost, sw, ex.trace, ex.trace_iters, bins, step == 0 ? 1 : 0, tail ? 1 : 0, step);
         FBX_HIP(hipGetLastError());
-        if (tail) break;
-        if (mode == FBX_MODE_FIXED && step + 1 >= max_iters) break;        // every reconstruction runs exactly max_iters iterations
+        ++step;
+        if (tail) { done = true; return FBX_OK; }
+        if (mode == FBX_MODE_FIXED && step >= max_iters) { done = true; return FBX_OK; }        // every reconstruction runs exactly max_iters iterations
         // how many are left: read back every few launches (the grid shrinks with it), at every launch near the end
-        if ((step + 1) % check_every == 0 || active_bound <= 4 * tail_items) {
-            FBX_HIP(hipMemcpyAsync(host_cnt, bins.next_count, sizeof(host_cnt), hipMemcpyDeviceToHost, st));
-            FBX_HIP(hipStreamSynchronize(st));
-            long long a = 0;
-            for (int k = 0; k < P1_NB; ++k) a += host_cnt[k];
-            active_bound = a;
-            if (a == 0) break;
+        if (step % check_every == 0 || active_bound <= 4 * tail_items) {
+            FBX_HIP(hipMemcpyAsync(host_cnt, bins.next_count, sizeof(int) * P1_NB, hipMemcpyDeviceToHost, st));
+            reading = true;
         }
+        return FBX_OK;
     }
-    return FBX_OK;
+    // wait for a pending read-back (the launches of the OTHER stream keep the device busy meanwhile)
+    int settle() {
+        if (!reading) return FBX_OK;
+        FBX_HIP(hipStreamSynchronize(st));
+        long long a = 0;
+        for (int k = 0; k < P1_NB; ++k) a += host_cnt[k];
+        active_bound = a; reading = false;
+        if (a == 0) done = true;
+        return FBX_OK;
+    }
+};
+
+// The binned relaunch of a whole call.  One launch per outer iteration leaves the chip half empty (round 5's counters: a wavefront
+// resident on 57 % of the SIMD-cycles of the call -- every launch ends with its slowest wavefront, the last one with the serial
+// floor of one lane): the batch is therefore cut into chunks that run as INDEPENDENT binned pipelines, two at a time on two
+// streams (the calling thread's and its second compute stream), so that one pipeline's launches fill the other's tails.  Bins are
+// per chunk; an item's arithmetic does not know which chunk or stream it ran in (bit-identical outputs, tests/test_pgdb1_gpu.py).
+static int pgdb1_binned_run(const fbx_design* des, long long B, const double* e, const double* c, int tp, int mode, int max_iters,
+                            double* choi, int32_t* it, int32_t* dy, int32_t* bt, double* cost, int32_t* sw, const PgdbExtras& ex,
+                            long long chunk, long long tail_items, int check_every, int n_streams) {
+    FBX_HIP(hipFuncSetAttribute((const void*)pgdb1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * 2 * (size_t)des->dev.m * 64)));
+    const int m = des->dev.m;
+    const int lanes = n_streams > 1 && B > chunk ? 2 : 1;         // pipelines in flight
+    hipStream_t sts[2] = {stream(), stream()};
+    hipEvent_t* ev = nullptr;
+    if (lanes == 2) {
+        hipStream_t s_in, s_out;
+        { const int rc = copy_streams(&s_in, &s_out, &sts[1]); if (rc) return rc; }
+        { const int rc = ordering_events(2, &ev); if (rc) return rc; }
+    }
+    void* w = nullptr;
+    const size_t per = P1Run::workspace_bytes(chunk < B ? chunk : B, m);
+    // (no room for the bins: the caller falls back to the persistent kernel, which needs none)
+    if (workspace(WS_PGDB1_BINS, per * lanes, &w) != FBX_OK) { (void)hipGetLastError(); return FBX_ERR_NOMEM; }
+    // (page-locked: a read-back into pageable memory would hold the host until its stream has drained -- and with it the other pipeline's launches)
+    static thread_local int* host_cnt_mem = nullptr;
+    if (!host_cnt_mem) FBX_HIP(hipHostMalloc((void**)&host_cnt_mem, sizeof(int) * 2 * P1_NB, hipHostMallocDefault));
+    int* host_cnt[2] = {host_cnt_mem, host_cnt_mem + P1_NB};
+    if (lanes == 2) {                                              // the second stream starts behind whatever the caller queued on the first
+        FBX_HIP(hipEventRecord(ev[0], sts[0]));
+        FBX_HIP(hipStreamWaitEvent(sts[1], ev[0], 0));
+    }
+    P1Run run[2];
+    long long next = 0;
+    int rc = FBX_OK;
+    auto feed = [&](int k) -> int {                                // the next chunk of the batch into pipeline k
+        P1Run& r = run[k];
+        r = P1Run();
+        r.des = des; r.first = next; r.n = B - next < chunk ? B - next : chunk; r.e = e; r.c = c; r.tp = tp; r.mode = mode; r.max_iters = max_iters;
+        r.choi = choi; r.it = it; r.dy = dy; r.bt = bt; r.cost = cost; r.sw = sw; r.ex = ex; r.tail_items = tail_items; r.check_every = check_every;
+        r.st = sts[k]; r.host_cnt = host_cnt[k];
+        next += r.n;
+        return r.start((char*)w + per * k);
+    };
+    for (int k = 0; k < lanes && rc == FBX_OK; ++k) { run[k].done = true; if (next < B) rc = feed(k); }
+    while (rc == FBX_OK) {
+        bool any = false;
+        for (int k = 0; k < lanes && rc == FBX_OK; ++k) {
+            if (run[k].done && next < B) rc = feed(k);             // (stream order: the new chunk's first launch follows the old one's last)
+            if (!run[k].done) { any = true; rc = run[k].advance(); }
+        }
+        for (int k = 0; k < lanes && rc == FBX_OK; ++k) rc = run[k].settle();
+        if (!any) break;
+    }
+    if (lanes == 2) {                                              // the caller's stream continues behind the second one's last launch
+        if (rc != FBX_OK) { (void)hipStreamSynchronize(sts[1]); return rc; }
+        FBX_HIP(hipEventRecord(ev[1], sts[1]));
+        FBX_HIP(hipStreamWaitEvent(sts[0], ev[1], 0));
+    }
+    return rc;
 }
 
 #ifdef FBX_PHASE_TIMERS
@@ -373,18 +449,23 @@ int pgdb1_dispatch(const fbx_design* des, int64_t B, const double* e, const doub
         // settings), a fixed iteration count -- where nothing ever leaves the batch -- 2^17.  fbx_set_option("pgdb1_binned") = 0 never /
         // 1 by these rules / 2 always; environment, for experiments: FBX_P1_BINNED overrides it per call; FBX_P1_TAIL the number of reconstructions left at which the
         // last launch takes over; FBX_P1_CHUNK the largest number binned at once (its workspace is 3.5 KB + 16 m bytes per reconstruction).
-        const long long binned = env_ll("FBX_P1_BINNED", option_pgdb1_binned()), chunk = env_ll("FBX_P1_CHUNK", 1 << 20), tail = env_ll("FBX_P1_TAIL", 8192),
+        const long long binned = env_ll("FBX_P1_BINNED", option_pgdb1_binned()), chunk = env_ll("FBX_P1_CHUNK", 0), tail = env_ll("FBX_P1_TAIL", 8192),
                         every = env_ll("FBX_P1_CHECK", 8);
         const long long from = mode == FBX_MODE_FIXED ? (1 << 17) : (des->dev.m <= 12 ? (1 << 19) : (1 << 20));
         // (a stage of the pipelined host entry point shares the calling thread's workspaces with the stage on the other stream:
         // those stay with the persistent kernel)
         if (!ex.launch_stream && !(mode == FBX_MODE_FIXED && max_iters == 0) && (binned == 2 || (binned == 1 && B >= from))) {
-            const long long chunk_ = chunk < 4096 ? 4096 : (chunk > (1 << 22) ? (1 << 22) : chunk);
-            int rc = FBX_OK;
-            for (long long f = 0; f < B && rc == FBX_OK; f += chunk_) {
-                const long long n = B - f < chunk_ ? B - f : chunk_;
-                rc = pgdb1_binned_chunk(des, f, n, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex, tail, every < 1 ? 1 : (int)every);
-            }
+            // chunks: FBX_P1_CHUNK, else HALF the batch (at least 2^18 items, at most 2^20): one pipeline per stream.  Measured at 2^20
+            // experiments (scripts/pgdb1_streams_time.py, same box, every output bit-identical): a pipeline costs ~22 ms whatever its
+            // size -- the launches of the long tail of iteration counts, the serial floor of the slowest lanes -- plus ~7.7 ms per 2^18
+            // items, so MORE chunks than streams lose (4 chunks on one stream 121 ms, on two 74 ms against 53 ms for one), and two
+            // pipelines that run side by side reach their latency-bound phases together: 53.1 -> 51.9 ms to convergence, 234 -> 212 ms
+            // for 30 fixed iterations (Pauli), 34.5 -> 34.7 / 46.7 -> 47.2 ms (SIC).
+            long long chunk_ = chunk > 0 ? chunk : (B + 1) / 2;
+            if (chunk <= 0) chunk_ = chunk_ < (1 << 18) ? (1 << 18) : (chunk_ > (1 << 20) ? (1 << 20) : chunk_);
+            chunk_ = chunk_ < 4096 ? 4096 : (chunk_ > (1 << 22) ? (1 << 22) : chunk_);
+            const int rc = pgdb1_binned_run(des, B, e, c, tp, mode, max_iters, choi, it, dy, bt, cost, sw, ex, chunk_, tail, every < 1 ? 1 : (int)every,
+                                            (int)env_ll("FBX_P1_STREAMS", 2));
             // out of device memory for the bins (before anything of the chunk was launched: results are per item, the chunks
             // already done stay valid and are simply recomputed): the persistent kernel below takes the whole batch
             if (rc != FBX_ERR_NOMEM) return rc;
