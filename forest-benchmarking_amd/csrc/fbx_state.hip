@@ -86,6 +86,54 @@ __device__ __forceinline__ cplx pauli_synthesis(const double* w, double w0, int 
     cplx o; o.re = re; o.im = im; return o;
 }
 
+// Round 6: the two Pauli passes of the iterative-MLE loop with their per-lane index and sign logic evaluated ONCE per reconstruction.
+// The state kernels are bound by vector-instruction issue (profiles/r06: 46-48 % of their vector instructions are fp64 arithmetic,
+// the rest phase selects, index arithmetic and reductions), and what a lane selects in pauli_expectations / pauli_synthesis depends on
+// nothing but the lane: lane p reads the SAME component (real or imaginary, by the number of Y factors of its Pauli) of d fixed
+// entries with fixed signs; entry (row, col) adds d fixed weights with fixed signs to its real or imaginary part.  As tables: one
+// 8-byte LDS read + one FMA with a +-1 constant per term (expectations), one read + two FMAs with constants in {0, +-1} (synthesis).
+// A product with +-1 is exact and a term with coefficient 0 leaves a non-negative-zero accumulator untouched: BIT-IDENTICAL to the
+// select forms above (tests/test_state_gpu.py holds both against the reference fixtures; scripts/compare_libs.py the hashes).
+template <int NQ>
+struct PauliTables {
+    static constexpr int d = 1 << NQ;
+    int eoff[d]; double esg[d];             // r[p] = sum_row esg[row] * ((double*)rho)[eoff[row]]
+    int sp[d]; double sa[d], sb[d];         // entry: re += sa[z] * w[sp[z]], im += sb[z] * w[sp[z]]
+    // lane `p` of the expectation pass, entry (row, col) of the synthesis pass
+    __device__ __forceinline__ void init(int p, int row, int col) {
+        int x, z, ny; pauli_masks<NQ>(p, x, z, ny);
+#pragma unroll
+        for (int r = 0; r < d; ++r) {
+            int c, ph, neg; pauli_entry<NQ>(x, z, ny, r, c, ph, neg);
+            const double s = neg ? -1.0 : 1.0;
+            eoff[r] = 2 * (c * d + r) + (ph & 1);                               // ph 0 / 2: real part, 1 / 3: imaginary part
+            esg[r] = (ph == 0 || ph == 3) ? s : -s;
+        }
+        const int xs = row ^ col;
+#pragma unroll
+        for (int zz = 0; zz < d; ++zz) {
+            sp[zz] = pauli_index<NQ>(xs, zz);
+            const int ph = __popc(xs & zz) & 3, neg = __popc(col & zz) & 1;
+            const double s = neg ? -1.0 : 1.0;
+            sa[zz] = ph == 0 ? s : ph == 2 ? -s : 0.0;
+            sb[zz] = ph == 1 ? s : ph == 3 ? -s : 0.0;
+        }
+    }
+    __device__ __forceinline__ double expectation(const cplx* rho) const {
+        const double* f = reinterpret_cast<const double*>(rho);
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < d; ++r) acc = fma(esg[r], f[eoff[r]], acc);
+        return acc;
+    }
+    __device__ __forceinline__ cplx synthesis(const double* w, double w0, bool on_diagonal) const {
+        double re = on_diagonal ? w0 : 0.0, im = 0.0;
+#pragma unroll
+        for (int zz = 0; zz < d; ++zz) { const double v = w[sp[zz]]; re = fma(sa[zz], v, re); im = fma(sb[zz], v, im); }
+        cplx o; o.re = re; o.im = im; return o;
+    }
+};
+
 // One setting of the design held by a lane for the whole reconstruction (designs of at most 64
 // settings -- every state-tomography design of the reference has 4^n - 1 <= 63): Pauli index,
 // coefficient and measured expectation are fetched from HBM once instead of once per iteration.
@@ -98,6 +146,32 @@ __device__ __forceinline__ LaneSetting load_lane_setting(const DesignDev& des, c
 }
 
 // R operator of tomography.py:273-338 for the state in L.rho; result element of this lane.
+// the register-resident-settings form of r_operator_elem below (designs of at most 64 settings) with the Pauli passes as tables: what
+// the iterative-MLE loop runs.  Same operations in the same order.
+template <int NQ>
+__device__ __forceinline__ cplx r_operator_tab(const DesignDev& des, StateLds<NQ>& L, int lane, const LaneSetting& mine,
+                                               const PauliTables<NQ>& tab) {
+    constexpr int d = 1 << NQ, D = d * d;
+    const int m = des.m;
+    if (lane < D) { L.r[lane] = tab.expectation(L.rho); L.w[lane] = 0.0; }
+    FBX_WAVE_SYNC();
+    double s0 = 0.0;
+    if (mine.valid) {
+        const double pe = mine.cf * L.r[mine.p];
+        const double gp = ((1.0 + mine.e) * 0.5) / ((1.0 + pe) * 0.5 + DBL_MIN);
+        const double gm = ((1.0 - mine.e) * 0.5) / ((1.0 - pe) * 0.5 + DBL_MIN);
+        s0 = 0.5 * (gp + gm);
+        atomicAdd(&L.w[mine.p], mine.cf * 0.5 * (gp - gm));
+    }
+    s0 = wave_sum(s0);
+    FBX_WAVE_SYNC();
+    if (lane < D) L.w[lane] = L.w[lane] / m;
+    FBX_WAVE_SYNC();
+    cplx out; out.re = 0.0; out.im = 0.0;
+    if (lane < D) out = tab.synthesis(L.w, s0 / m + 0.0, lane / d == lane % d);
+    return out;
+}
+
 template <int NQ>
 __device__ cplx r_operator_elem(const DesignDev& des, const double* __restrict__ e, StateLds<NQ>& L, int lane,
                                 const LaneSetting* mine = nullptr) {
@@ -253,10 +327,11 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
     if (act) L.rho[lane] = rho;
     FBX_WAVE_SYNC();
     const LaneSetting mine = load_lane_setting<NQ>(des, e, lane);
+    PauliTables<NQ> tab; tab.init(act ? lane : 0, row, col);
     int iteration = 1, hit = 0;
     while (true) {
         if (iteration >= maxiter) { hit = 1; break; }            // tomography.py:244-246
-        cplx T = r_operator_elem<NQ>(des, e, L, lane, &mine);      // R(rho)
+        cplx T = des.m <= 64 ? r_operator_tab<NQ>(des, L, lane, mine, tab) : r_operator_elem<NQ>(des, e, L, lane, &mine);      // R(rho)
         if (act && row == col) T.re -= 1.0;                        // Tk = R - I
         if (entropy_penalty > 0.0) {                               // tomography.py:252-254
             herm_function<NQ>(L.rho, L.aux, 0, L, lane, false);    // logm(rho)
@@ -339,13 +414,14 @@ mle_state_packed_kernel(DesignDev des, long long B, const double* __restrict__ e
     cplx rho; rho.re = (row == col) ? 1.0 / d : 0.0; rho.im = 0.0;
     rho_l[t] = rho;
     FBX_WAVE_SYNC();
+    PauliTables<NQ> tab; tab.init(t, row, col);
     int iteration = 1, hit = 0;
     bool running = valid;
     while (__ballot(running)) {
         if (running && iteration >= maxiter) { hit = 1; running = false; }     // tomography.py:244-246
         if (!__ballot(running)) break;
         // ---- R(rho)  (tomography.py:273-338)
-        pauli_expectations<NQ>(rho_l, r_l, t);
+        r_l[t] = tab.expectation(rho_l);
         w_l[t] = 0.0;
         FBX_WAVE_SYNC();
         double s0 = 0.0;
@@ -360,7 +436,7 @@ mle_state_packed_kernel(DesignDev des, long long B, const double* __restrict__ e
         FBX_WAVE_SYNC();
         w_l[t] = w_l[t] / m;
         FBX_WAVE_SYNC();
-        cplx T = pauli_synthesis<NQ>(w_l, s0 / m + 0.0, row, col);
+        cplx T = tab.synthesis(w_l, s0 / m + 0.0, row == col);
         if (row == col) T.re -= 1.0;                                           // Tk = R - I
         cplx Um; Um.re = epsilon * T.re + ((row == col) ? 1.0 : 0.0); Um.im = epsilon * T.im;
         FBX_WAVE_SYNC();

@@ -64,6 +64,13 @@ for wl in wls:
         js = [l for l in open(p) if l.startswith("{")]
         if js:
             open(os.path.join(dst, f"bench_{wl}_line_under_rocprof.json"), "w").write(js[-1])
+            if wl in PER_CALL:
+                # a call of many launches that may OVERLAP (two pipelines on two streams since round 6): the sum of the launches'
+                # durations is not the call's duration -- the HIP-event time of the call, from the bench line of the traced run
+                try:
+                    kernel_s[wl] = json.loads(js[-1])["roofline"]["kernel_ms"] / 1e3
+                except Exception:
+                    pass
     pmc = {}
     for d in sorted(glob.glob(os.path.join(out, f"pmc*_{wl}"))):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

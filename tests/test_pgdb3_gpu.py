@@ -67,7 +67,10 @@ def test_batch_of_256_properties(gpu):
     got, st = tomography.pgdb_process_estimate_batch(design, e, c, mode="fixed", max_iters=100, return_stats=True)
     assert (st["iterations"] == 100).all()
     assert (st["jacobi_sweeps"] >= st["dykstra"]).all() and (st["eig_terms"] <= 64 * st["dykstra"]).all()
-    assert (st["cost_evals"] == 1 + 100 + st["backtracks"]).all()
+    # one evaluation at the start, one per iteration, one per halving -- plus what the four-at-a-time pass of a long halving run
+    # evaluates beyond the accepted step (at most three per outer iteration: only the run's last pass can be cut short)
+    extra = st["cost_evals"] - (1 + 100 + st["backtracks"])
+    assert (extra >= 0).all() and (extra <= 3 * 100).all() and extra.max() > 0
     assert np.abs(got - got.conj().transpose(0, 2, 1)).max() < 1e-12
     pt = np.einsum("biojo->bij", got.reshape(-1, 8, 8, 8, 8))
     assert np.abs(pt - np.eye(8)).max() < 1e-12
