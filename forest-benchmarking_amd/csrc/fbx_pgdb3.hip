@@ -34,7 +34,6 @@ extern long long* g_phase_out;      // fbx_pgdb.hip (diagnostics builds only)
 #define FBX3_BASIS_WRITE_STEP 3e-1     // outer step below which every basis is written back (10 x the threshold above, as in the 2-qubit kernel)
 #define FBX3_BASIS_CHAIN_SWEEPS 216   // as FBX_BASIS_CHAIN_SWEEPS of the 2-qubit kernel (fbx_pgdb.hip)
 
-#define FBX3_PARK_DYKSTRA 0      // (measured: 271.7 against 272.8 ms per 256 reconstructions -- not worth 64 GB of traffic per launch)
 namespace p3 {
 constexpr int NQ = 3, d = 8, D = 64, NB = 32, NT = 1024, LD = 64, LDs = d + 1;
 constexpr double EPS = 1e-6, GAMMA = 0.3, STOP = 1e-10, ALPHA_MIN = 1e-15;
@@ -193,12 +192,9 @@ __device__ void rotate_into_basis_mfma(Lds& L, int t) {
     FBX_BLOCK_SYNC();
 }
 
-// The 64 x 64 eigensolver as a REAL function call: inlined into the 1024-thread kernels, its per-thread address
-// constants and those of every other phase are hoisted out of the Dykstra loop together and spilled -- with scratch
-// reloads inside the Jacobi round loop.  Behind a call boundary the solver is allocated on its own (80 registers, no
-// scratch, as in eigh_kernel<64, 1024>) and the caller's live values are saved around the call, once per decomposition.
-#define FBX3_JACOBI_CALL 0      // 1: behind a call boundary (noinline), 0: inlined into the kernels (round 4: 296 -> 274 ms per 256 reconstructions;
-                                // the role-split solver needs more than the 80 caller-saved registers and saved 49 more to scratch per call)
+// The 64 x 64 eigensolver is INLINED into the kernels (behind a call boundary -- tried in round 4, when its per-thread address constants
+// were hoisted out of the Dykstra loop and spilled -- the role-split solver needs more than the 80 caller-saved registers and saved 49
+// more to scratch per call: 296 against 274 ms per 256 reconstructions).
 __device__ __forceinline__
 int jacobi64(cplx* Ms, cplx* Vs, int t, bool init_identity, double* red, double tol2) {
     t = opaque(t);
@@ -837,10 +833,7 @@ pgdb3_kernel(DesignDev des, long long B, const double* __restrict__ expect, cons
             // loop below walks them in order.  Every cost is the same sum in the same order as cost_at's (per-thread terms by slot, the
             // wavefront reduction, the sixteen partials added in wavefront order): the accepted step and every count are
             // BIT-IDENTICAL to the one-at-a-time loop; what changes is that up to KL - 1 evaluations behind the accepted one are wasted.
-#ifndef FBX3_LADDER
-#define FBX3_LADDER 4
-#endif
-            constexpr int KL = FBX3_LADDER;
+            constexpr int KL = 4;       // (eight: 168.2 against 162.4 ms for the Pauli in-basis -- sixteen logarithm chains in flight spill; two: 163.8)
             auto cost_ladder = [&](double a0, double (&out)[KL]) __attribute__((always_inline)) {
                 double acc[KL];
 #pragma unroll
