@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=16,
                     help="items run through the oracle for cpu_baseline, its reference-faithful and multi-core variants and "
                          "the parity self-check (0 = skip every CPU leg; ~25 s of one core at the default)")
-    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "sweep3", "pgdb3", "pgdb1", "mle_state", "mle_state3"],
+    ap.add_argument("--workload", default="all", choices=["all", "pgdb", "sweep", "sweep3", "pgdb3", "pgdb1", "mle_state", "mle_state3", "shots"],
                     help="all (N = 1 default) = headline pgdb + every secondary leg; pgdb = headline only; "
                          "sweep / pgdb3 / pgdb1 = that workload as the primary line")
     ap.add_argument("--sweep-items", type=int, default=1_000_000)
@@ -638,6 +638,59 @@ def run_mle_state(args, comm, _lib, synthetic, with_cpu, n=2):
     return line
 
 
+def run_shots(args, comm, _lib, synthetic, with_cpu):
+    """SURVEY 8 row f2, the caller side of the path: shots_to_obs_moments (observable_estimation.py:804-853) for the shots of one
+    configs[1]-sized acquisition -- 1024 two-qubit process tomographies x 540 settings x 1000 shots, [n_shots][n_qubits] 0/1 bytes per
+    setting as qc.run returns them -- reduced on the device to the expectations and variances the estimators take.  Bit patterns come
+    from a fixed 64 Ki-setting block (generated once, tiled): the kernel's work does not depend on the values."""
+    n, shots = 2, 1000
+    S = 1024 * 540
+    block = 1 << 16
+    rs = np.random.RandomState(11 + comm.rank)
+    bits0 = rs.randint(0, 2, size=(block, shots, n)).astype(np.uint8)
+    mask0 = rs.randint(0, 2, size=(block, n)).astype(np.uint8); mask0[:, 0] |= (mask0.sum(1) == 0)
+    reps = -(-S // block)
+    bits = np.tile(bits0, (reps, 1, 1))[:S]; mask = np.tile(mask0, (reps, 1))[:S]
+    lib = _lib.lib()
+    d_bits, d_mask = _lib.DeviceBuffer.from_array(bits), _lib.DeviceBuffer.from_array(mask)
+    d_mean, d_var = _lib.DeviceBuffer(S * 8), _lib.DeviceBuffer(S * 8)
+
+    def step():
+        _lib.check(lib.fbx_shots_to_moments_dev(n, S, shots, d_bits.ptr, d_mask.ptr, None, 0, d_mean.ptr, d_var.ptr))
+
+    elapsed, kms = timed_steps(step, args.steps, args.warmup, comm, _lib)
+    ksec = kms / 1e3 / args.steps
+    mean = d_mean.to_array(np.float64, (S,)); var = d_var.to_array(np.float64, (S,))
+    bytes_setting = shots * n + n + 16
+    gbs = S * bytes_setting / ksec / 1e9
+    line = {"tag": "shots_2q", "metric": "shots -> observable moments, settings/sec (2-qubit, 1000 shots per setting)",
+            "value": comm.world * S * args.steps / elapsed, "unit": "settings/s", "n_gpus": comm.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{S} settings (1024 two-qubit process tomographies x 540) x {shots} shots x {n} qubits of 0/1 bytes per GPU, "
+                                   "resident in HBM: +-1 products under the observable's mask, mean and variance of the mean per setting",
+                       "items_per_gpu": S, "parallelism": f"shard{comm.world}"},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": _profiled("shots_kernel_hbm_bytes_per_launch"), "kernel": "shots_pipe_packed_kernel<2,*>",
+                         "kernel_ms": 1e3 * ksec,
+                         "note": f"achieved = {bytes_setting} algorithmic bytes per setting ({shots} x {n} shot bytes + mask in, mean + variance out) / HIP-event kernel time"}}
+    if with_cpu and comm.rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from fbx_oracle import acquisition as oa
+        k, t0, exact = 0, time.perf_counter(), True
+        while k < 4096 and time.perf_counter() - t0 < 3.0:
+            m_, v_ = oa.shots_to_obs_moments(bits[k], mask[k])
+            exact = exact and m_ == mean[k] and abs(v_ - var[k]) <= 1e-18 + 1e-15 * abs(v_)
+            k += 1
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": k / dt, "unit": "settings/s", "cores": 1, "kind": "port",
+                                "sample": f"first {k} settings, numpy oracle (observable_estimation.py:804-853), {dt:.1f} s"}
+        line["config"]["matches_oracle_on_sample"] = bool(exact)
+    for buf in (d_bits, d_mask, d_mean, d_var):
+        buf.free()
+    return line
+
+
 class PgdbBatch:
     """A resident batch of 2-qubit process tomographies and its output buffers."""
 
@@ -1109,6 +1162,8 @@ def main():
         line = run_pgdb3(args, comm, _lib, synthetic, with_cpu)
     elif args.workload == "pgdb1":
         line = run_pgdb1(args, comm, _lib, synthetic, with_cpu)
+    elif args.workload == "shots":
+        line = run_shots(args, comm, _lib, synthetic, with_cpu)
     elif args.workload in ("mle_state", "mle_state3"):
         line = run_mle_state(args, comm, _lib, synthetic, with_cpu, n=2 if args.workload == "mle_state" else 3)
     else:
@@ -1124,6 +1179,7 @@ def main():
             secondary.append(run_pgdb1(args, comm, _lib, synthetic, with_cpu))
             secondary.append(run_mle_state(args, comm, _lib, synthetic, with_cpu, n=2))
             secondary.append(run_mle_state(args, comm, _lib, synthetic, with_cpu, n=3))
+            secondary.append(run_shots(args, comm, _lib, synthetic, with_cpu))
             args.in_basis = basis
             _lib.release_workspace()
         line, batch = run_pgdb(args, comm, _lib, synthetic, rank_info)

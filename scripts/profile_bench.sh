@@ -7,7 +7,7 @@
 # bench.py reads: pmc_traffic.json (HBM bytes per launch) and pmc_flops.json (fp64 operations per launch, counted by the hardware).
 set -u
 TAG=${1:-r06}; shift || true
-WLS=${*:-"pgdb lean8192 lean65536 sweep sweep3 pgdb3 pgdb3pauli pgdb1 mle_state mle_state3"}
+WLS=${*:-"pgdb lean8192 lean65536 sweep sweep3 pgdb3 pgdb3pauli pgdb1 mle_state mle_state3 shots"}
 cd "$(dirname "$0")/.."
 REPO=$PWD
 export TMPDIR=/tmp
@@ -26,6 +26,7 @@ bench_args() {
         pgdb1)      echo "--workload pgdb1" ;;
         mle_state)  echo "--workload mle_state" ;;
         mle_state3) echo "--workload mle_state3" ;;
+        shots)      echo "--workload shots" ;;
     esac
 }
 cd /tmp
