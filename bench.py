@@ -671,7 +671,7 @@ def run_shots(args, comm, _lib, synthetic, with_cpu):
                                    "resident in HBM: +-1 products under the observable's mask, mean and variance of the mean per setting",
                        "items_per_gpu": S, "parallelism": f"shard{comm.world}"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": _profiled("shots_kernel_hbm_bytes_per_launch"), "kernel": "shots_pipe_packed_kernel<2,*>",
+                         "traffic": _profiled("shots_kernel_hbm_bytes_per_launch"), "kernel": "shots_pipe_kernel<2,2>",
                          "kernel_ms": 1e3 * ksec,
                          "note": f"achieved = {bytes_setting} algorithmic bytes per setting ({shots} x {n} shot bytes + mask in, mean + variance out) / HIP-event kernel time"}}
     if with_cpu and comm.rank == 0:
