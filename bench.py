@@ -9,17 +9,24 @@
 A "step" is one pass of the hot path (fbx_pgdb_process_dev, FBX_MODE_FIXED, 100 outer iterations
 of projected gradient descent with backtracking, fp64) over one batch that is already resident in HBM.
 
+OUTPUT: one short JSON line per secondary workload / parity leg first, and -- LAST -- the compact headline object the driver
+parses (< 4 KB: the contract's keys, `config`, `roofline`, `cpu_baseline`); the full record goes to gpurun_out/bench_detail.json
+(--detail-out).  See DESIGN.md section 5 and tests/test_bench_line.py.
+
 N = 1 (BASELINE.json configs[1], the configuration the metric is quoted on): 1024 independent 2-qubit
 process tomographies (Pauli in-basis, 540 settings, 1000 shots).  The same run also times, outside
-the headline's timed region and reported under "secondary": the conversion sweep of configs[2]
-(10^6 Kraus sets), the 3-qubit PGDB of configs[3] (batch 256), the converge-mode (reference
-semantics) throughput, the host-pointer (H2D + D2H inclusive) rate, the latency of one experiment
-through the reference-signature call, a parity self-check of the timed items against the oracle and
-the CPU baselines (oracle = numpy restatement of the reference, timed on this box's host cores).
+the headline's timed region and reported as secondary lines: the conversion sweeps of configs[2]
+(10^6 two-qubit / 65 536 three-qubit Kraus sets), the 3-qubit PGDB of configs[3] (batch 256, both in-bases), the
+single-qubit PGDB (2^20 experiments to convergence), the state-estimator half of the path (iterative MLE, 2 and 3 qubits,
+maxiter 100), the caller-side shot reduction (shots -> moments), configs[4]'s whole batch on one GPU, the converge-mode
+(reference semantics) throughput, the host-pointer (H2D + D2H inclusive) rate, the latency of one experiment
+through the reference-signature call, the parity of the timed items against the committed reference fixtures and the oracle,
+and the CPU baselines (oracle = numpy restatement of the reference, timed on this box's host cores).
+`--workload pgdb | sweep | sweep3 | pgdb3 | pgdb1 | mle_state | mle_state3 | shots` runs one of them as the primary line.
 
 N > 1 (BASELINE.json configs[4]): 65 536 two-qubit tomographies with distinct seeds, block-partitioned
 over the ranks (strong scaling: the total is fixed for N = 2, 4, 8), no data-path collective.  The
-line also carries the weak-scaling figure with configs[1]'s 1024 items on every rank
+headline's config also carries the weak-scaling figure with configs[1]'s 1024 items on every rank
 ("per_gpu_1024"), which is the number comparable with the N = 1 headline.
 
 No torch: ranks meet through fbx.parallel (RCCL communicator inside libfbx.so; rank 0's unique id
