@@ -104,6 +104,14 @@ def test_bench_state_mle_workload(gpu):
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
 
 
+def test_bench_shots_workload(gpu):
+    """The caller-side reduction as a bench line: HBM roofline on algorithmic bytes, exact against the oracle."""
+    line, full = _bench("--workload", "shots", "--steps", "3", "--warmup", "1", "--cpu-sample", "4")
+    assert line["unit"] == "settings/s" and line["dtype"] == "u8" and line["roofline"]["bound"] == "hbm"
+    assert 0.05 < line["roofline"]["frac"] < 1.0 and line["roofline"]["unit"] == "GB/s"
+    assert full["config"]["matches_oracle_on_sample"] is True and line["cpu_baseline"]["value"] > 0
+
+
 def test_bench_refuses_to_share_a_gpu_without_oversubscribe(gpu):
     """One GPU per rank or no number: two ranks on a one-GPU box must exit non-zero (no host-files fallback)."""
     import fbx
