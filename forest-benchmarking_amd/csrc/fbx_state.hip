@@ -13,6 +13,7 @@
 #include "fbx_eigh64.hpp"
 #include <hip/hip_cooperative_groups.h>
 #include <cfloat>
+#include <type_traits>
 #include <cstdlib>
 #include <algorithm>
 #include <vector>
@@ -134,6 +135,76 @@ struct PauliTables {
     }
 };
 
+// The same tables with the signs as BIT MASKS (one 32-bit word per pass instead of d doubles) and the synthesis terms ordered by the part
+// they feed: what the 3-qubit kernel uses -- with the double-valued coefficients above it holds 236 registers (two wavefronts per SIMD),
+// with these ~110 (four).  Entry (row, col), x = row ^ col: the weights with even popc(x & z) feed the real part, those with odd parity the
+// imaginary part -- for x != 0 half of the z each, in ascending z inside each half; on the diagonal (x = 0) all d feed the real part.  The
+// list holds the real-part terms first, in ascending z, then the others: the first d / 2 terms always go to the real accumulator, the
+// second half continues the SAME accumulator on the diagonal and starts the imaginary one elsewhere, so every sum keeps the order of the
+// select form (bit-identical).  A sign flip is one v_xor on the high word.
+template <int NQ, bool FMA_SIGNS = false>
+struct PauliTablesLean {
+    static constexpr int d = 1 << NQ;
+    int eoff[d]; unsigned esign;            // bit r: the expectation term of row r enters negated
+    int sp[d]; unsigned ssign;              // bit k: synthesis term k enters negated
+    double esg[FMA_SIGNS ? d : 1], ssg[FMA_SIGNS ? d : 1];      // FMA_SIGNS: the same signs as +-1.0 (one FMA per term instead of xor + add)
+    __device__ __forceinline__ void init(int p, int row, int col) {
+        int x, z, ny; pauli_masks<NQ>(p, x, z, ny);
+        esign = 0u;
+#pragma unroll
+        for (int r = 0; r < d; ++r) {
+            int c, ph, neg; pauli_entry<NQ>(x, z, ny, r, c, ph, neg);
+            eoff[r] = 2 * (c * d + r) + (ph & 1);
+            const bool minus = (ph == 0 || ph == 3) ? neg != 0 : neg == 0;
+            esign |= (minus ? 1u : 0u) << r;
+        }
+        const int xs = row ^ col;
+        ssign = 0u;
+#pragma unroll
+        for (int q = 0; q < d; ++q) sp[q] = 0;
+        int k = 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int zz = 0; zz < d; ++zz) {
+                const int ph = __popc(xs & zz) & 3, neg = __popc(col & zz) & 1;
+                if ((ph & 1) == pass) {
+                    const bool minus = (ph >= 2) != (neg != 0);
+                    // (k is a compile-time-unknown position: the writes below are selects over the d slots, once per reconstruction)
+                    const int pidx = pauli_index<NQ>(xs, zz);
+#pragma unroll
+                    for (int q = 0; q < d; ++q) sp[q] = (q == k) ? pidx : sp[q];
+                    ssign |= (minus ? 1u : 0u) << k;
+                    ++k;
+                }
+            }
+        }
+        if constexpr (FMA_SIGNS) {
+#pragma unroll
+            for (int q = 0; q < d; ++q) { esg[q] = ((esign >> q) & 1u) ? -1.0 : 1.0; ssg[q] = ((ssign >> q) & 1u) ? -1.0 : 1.0; }
+        }
+    }
+    static __device__ __forceinline__ double signed_(double v, unsigned bits, int k) {
+        return __hiloint2double(__double2hiint(v) ^ (int)(((bits >> k) & 1u) << 31), __double2loint(v));
+    }
+    __device__ __forceinline__ double expectation(const cplx* rho) const {
+        const double* f = reinterpret_cast<const double*>(rho);
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < d; ++r) { if constexpr (FMA_SIGNS) acc = fma(esg[r], f[eoff[r]], acc); else acc += signed_(f[eoff[r]], esign, r); }
+        return acc;
+    }
+    __device__ __forceinline__ cplx synthesis(const double* w, double w0, bool on_diagonal) const {
+        double re = on_diagonal ? w0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < d / 2; ++k) { if constexpr (FMA_SIGNS) re = fma(ssg[k], w[sp[k]], re); else re += signed_(w[sp[k]], ssign, k); }
+        double acc = on_diagonal ? re : 0.0;                  // the diagonal continues its real sum, every other entry starts the imaginary one
+#pragma unroll
+        for (int k = d / 2; k < d; ++k) { if constexpr (FMA_SIGNS) acc = fma(ssg[k], w[sp[k]], acc); else acc += signed_(w[sp[k]], ssign, k); }
+        cplx o; o.re = on_diagonal ? acc : re; o.im = on_diagonal ? 0.0 : acc; return o;
+    }
+};
+
 // One setting of the design held by a lane for the whole reconstruction (designs of at most 64
 // settings -- every state-tomography design of the reference has 4^n - 1 <= 63): Pauli index,
 // coefficient and measured expectation are fetched from HBM once instead of once per iteration.
@@ -148,9 +219,9 @@ __device__ __forceinline__ LaneSetting load_lane_setting(const DesignDev& des, c
 // R operator of tomography.py:273-338 for the state in L.rho; result element of this lane.
 // the register-resident-settings form of r_operator_elem below (designs of at most 64 settings) with the Pauli passes as tables: what
 // the iterative-MLE loop runs.  Same operations in the same order.
-template <int NQ>
+template <int NQ, class Tables>
 __device__ __forceinline__ cplx r_operator_tab(const DesignDev& des, StateLds<NQ>& L, int lane, const LaneSetting& mine,
-                                               const PauliTables<NQ>& tab) {
+                                               const Tables& tab) {
     constexpr int d = 1 << NQ, D = d * d;
     const int m = des.m;
     if (lane < D) { L.r[lane] = tab.expectation(L.rho); L.w[lane] = 0.0; }
@@ -307,13 +378,14 @@ __device__ __forceinline__ cplx matmul_elem(const cplx* A, const cplx* Bm, int l
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NQ>
-__global__ void __launch_bounds__(64)
-mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
-                 double epsilon, double entropy_penalty, double beta, double tol, int maxiter,
-                 double* __restrict__ rho_out, int* __restrict__ iters_out, int* __restrict__ hit_out) {
+// PLAIN: no entropy penalty, no hedging, a design of at most 64 settings (every state design of the reference) -- the variants'
+// code (two Hermitian matrix functions through the Jacobi) is compiled out
+template <int NQ, bool PLAIN, class Tables>
+__device__ __forceinline__ void
+mle_state_body(char* smem, const DesignDev& des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
+               double epsilon, double entropy_penalty, double beta, double tol, int maxiter,
+               double* __restrict__ rho_out, int* __restrict__ iters_out, int* __restrict__ hit_out) {
     constexpr int d = 1 << NQ, D = d * d;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     StateLds<NQ> L; L.carve(smem, StateLds<NQ>::staged(des.m) ? des.m : 0);
     const int lane = threadIdx.x;
     const long long item = blockIdx.x;
@@ -327,13 +399,15 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
     if (act) L.rho[lane] = rho;
     FBX_WAVE_SYNC();
     const LaneSetting mine = load_lane_setting<NQ>(des, e, lane);
-    PauliTables<NQ> tab; tab.init(act ? lane : 0, row, col);
+    Tables tab; tab.init(act ? lane : 0, row, col);
     int iteration = 1, hit = 0;
     while (true) {
         if (iteration >= maxiter) { hit = 1; break; }            // tomography.py:244-246
-        cplx T = des.m <= 64 ? r_operator_tab<NQ>(des, L, lane, mine, tab) : r_operator_elem<NQ>(des, e, L, lane, &mine);      // R(rho)
+        cplx T;                                                    // R(rho)
+        if constexpr (PLAIN) T = r_operator_tab<NQ>(des, L, lane, mine, tab);
+        else T = des.m <= 64 ? r_operator_tab<NQ>(des, L, lane, mine, tab) : r_operator_elem<NQ>(des, e, L, lane, &mine);
         if (act && row == col) T.re -= 1.0;                        // Tk = R - I
-        if (entropy_penalty > 0.0) {                               // tomography.py:252-254
+        if (!PLAIN && entropy_penalty > 0.0) {                     // tomography.py:252-254
             herm_function<NQ>(L.rho, L.aux, 0, L, lane, false);    // logm(rho)
             cplx lg; lg.re = 0.0; lg.im = 0.0;
             if (act) lg = L.aux[lane];
@@ -343,7 +417,7 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
             if (act && row == col) { lg.re -= tr_re; lg.im -= tr_im; }
             T.re -= entropy_penalty * lg.re; T.im -= entropy_penalty * lg.im;
         }
-        if (beta > 0.0) {                                          // tomography.py:257-260
+        if (!PLAIN && beta > 0.0) {                                // tomography.py:257-260
             T.re *= num_meas / 2; T.im *= num_meas / 2;
             herm_function<NQ>(L.rho, L.aux, 1, L, lane, false);    // pinv(rho)
             cplx pi; pi.re = 0.0; pi.im = 0.0;
@@ -377,6 +451,28 @@ mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, 
     }
     if (act) { rho_out[(item * D + lane) * 2] = rho.re; rho_out[(item * D + lane) * 2 + 1] = rho.im; }
     if (lane == 0) { if (iters_out) iters_out[item] = iteration; if (hit_out) hit_out[item] = hit; }
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(64)
+mle_state_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
+                 double epsilon, double entropy_penalty, double beta, double tol, int maxiter,
+                 double* __restrict__ rho_out, int* __restrict__ iters_out, int* __restrict__ hit_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    mle_state_body<NQ, false, PauliTables<NQ>>(smem, des, B, expect, counts, epsilon, entropy_penalty, beta, tol, maxiter, rho_out, iters_out, hit_out);
+}
+
+// The plain 3-qubit reconstruction (what bench.py --workload mle_state3 times): the body without the variants and with the ordered
+// tables (PauliTablesLean: d indices + d signs per pass instead of d + 2 d coefficients), held to 128 registers = FOUR wavefronts per
+// SIMD -- with the tables of PauliTables it needs 236 registers (two wavefronts), and two wavefronts do not fill the vector pipe
+// (VALU active 0.40 per wave).  Same box, bit-identical: 22.7 -> 17.4 ms per 2^18 reconstructions with the signs as bit masks
+// (94 registers), 17.0 ms with the signs as +-1.0 constants of an FMA (110 registers) -- the latter is what runs.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+mle_state_plain3_kernel(DesignDev des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
+                        double epsilon, double tol, int maxiter, double* __restrict__ rho_out, int* __restrict__ iters_out,
+                        int* __restrict__ hit_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    mle_state_body<3, true, PauliTablesLean<3, true>>(smem, des, B, expect, counts, epsilon, 0.0, 0.0, tol, maxiter, rho_out, iters_out, hit_out);
 }
 
 // ---- plain diluted MLE (no entropy penalty, no hedging) for 1 and 2 qubits with SEVERAL items per
@@ -1373,7 +1469,11 @@ int fbx_mle_state_dev(const fbx_design* design, int64_t B, const double* d_expec
     else if (packed)
         hipLaunchKernelGGL(mle_state_packed_kernel<2>, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, stream(), design->dev,
                            (long long)B, d_expect, epsilon, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
-    else
+    else if (n == 3 && entropy_penalty == 0.0 && beta == 0.0 && m <= 64) {
+        FBX_HIP(hipFuncSetAttribute((const void*)mle_state_plain3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mle_state_plain3_kernel, dim3((unsigned)B), dim3(64), lds, stream(), design->dev, (long long)B, d_expect, d_counts,
+                           epsilon, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
+    } else
         FBX_DISPATCH_NQ(n, mle_state_kernel, lds, B, design->dev, (long long)B, d_expect, d_counts, epsilon, entropy_penalty,
                         beta, tol, maxiter, d_rho_out, d_iters_out, d_hit_max_out);
     FBX_HIP(hipGetLastError());
