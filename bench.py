@@ -600,7 +600,7 @@ def run_mle_state(args, comm, _lib, synthetic, with_cpu, n=2):
     m = design.m
     # the iteration counter starts at 1 and the cap check precedes the update (tomography.py:241-246): min(its, maxiter - 1) updates
     ex = mle_state_executed_flop(n, m, float(np.mean(np.minimum(its, maxiter - 1))))
-    kernel = {1: "mle_state_packed_kernel<1>", 2: "mle_state_packed_kernel<2>", 3: "mle_state_kernel<3>"}[n]
+    kernel = {1: "mle_state_packed_kernel<1>", 2: "mle_state_packed_kernel<2>", 3: "mle_state_plain3_kernel"}[n]
     meas = _measured_flop(kernel, B)
     algo_bytes = 2 * m * 8 + d * d * 16 + 8
     line = {"tag": f"mle_state_{n}q",

@@ -25,7 +25,7 @@ WL = {"pgdb": ("pgdb_kernel<2, 9>", "pgdb_kernel_hbm_bytes_per_launch", 1024, "p
       "pgdb3pauli": ("pgdb3_kernel<14>", "pgdb3pauli_kernel_hbm_bytes_per_launch", 256, "pgdb3_kernel<14>"),
       "pgdb1": ("pgdb1_step_kernel", "pgdb1_kernel_hbm_bytes_per_launch", 1 << 20, "pgdb1_step_kernel"),
       "mle_state": ("mle_state_packed_kernel<2>", "mle_state2_kernel_hbm_bytes_per_launch", 1 << 20, "mle_state_packed_kernel<2>"),
-      "mle_state3": ("mle_state_kernel<3>", "mle_state3_kernel_hbm_bytes_per_launch", 1 << 18, "mle_state_kernel<3>"),
+      "mle_state3": ("mle_state_plain3_kernel", "mle_state3_kernel_hbm_bytes_per_launch", 1 << 18, "mle_state_plain3_kernel"),
       "shots": ("shots_pipe", "shots_kernel_hbm_bytes_per_launch", 1024 * 540, "shots_pipe_kernel<2,2>")}
 # workloads whose bench step is MANY launches of the kernel (one per outer iteration): counters are summed over a step's launches.
 # The --pmc passes run bench.py with --steps 2 --warmup 1 = 3 calls.
