@@ -112,7 +112,13 @@ __device__ void predict_table(const double* Rb, const double* Ct, double* T, int
 // record of a paused reconstruction (pieces, below): the estimate's blocks [8][64], then 13 scalars
 constexpr int PGDB_REC_EST = 8 * 64, PGDB_REC = PGDB_REC_EST + 16;
 
-template <int NQ, int MAXJ, bool LEAN, bool PIECES = false>
+// TPC: the kind of projection as a COMPILE-TIME constant (1 = trace preserving, 0 = trace non-increasing) or -1 = the run-time
+// argument.  With both kinds compiled in, the trace-non-increasing branch (a d x d eigendecomposition of the partial trace inside every
+// Dykstra iteration) costs the register-capped two-waves kernel 35 spilled registers it never uses in a trace-preserving run: its
+// instantiations take the kind as a template argument (fbx_pgdb_lean.hip; 8192 items 50.9 -> 49.0 ms, 65 536 items 402 -> 387 ms, same box,
+// bit-identical).  The one-wave kernels (no spills either way, same time) keep the run-time form.  (With the registers that freed, the
+// two-workers form of the 16 x 16 Jacobi was tried in this kernel again: 48.9 against 49.0 ms -- not adopted.)
+template <int NQ, int MAXJ, bool LEAN, bool PIECES = false, int TPC = -1>
 __device__ __forceinline__ void
 pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const double* __restrict__ expect,
           const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
@@ -448,7 +454,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
         // distance the estimate still moves per iteration (-10 % time, parity survey unchanged).
         { const double tr_ = des.eig_rel_tol * outer_step; L.choi.jtol2 = fmax(FBX_JACOBI_TOL2, tr_ * tr_); }
         basis.write_all = outer_step < FBX_BASIS_WRITE_STEP;
-        const Blk proj = proj_physical_blk<NQ>(x, trace_preserving != 0, L.choi, lane, dyk, sweeps, 100000,
+        const Blk proj = proj_physical_blk<NQ>(x, TPC < 0 ? trace_preserving != 0 : TPC != 0, L.choi, lane, dyk, sweeps, 100000,
                                                &basis);
         const Blk upd = blk_sub(proj, est);
         Blk grad = blk_zero();
@@ -698,7 +704,7 @@ pgdb_body(char* smem, long long item_, const DesignDev& des, long long B, const 
 
 // The ticket loop of the pieces kernels (pgdb_lean_pieces_kernel, fbx_pgdb_lean.hip: the protocol is described there;
 // pgdb_pieces_kernel, fbx_pgdb.hip): persistent workgroups draw (item, piece) tickets from `queue` until none is left.
-template <int NQ, int MAXJ, bool LEAN>
+template <int NQ, int MAXJ, bool LEAN, int TPC = -1>
 __device__ __forceinline__ void
 pgdb_pieces_run(char* smem, const DesignDev& des, long long B, const double* __restrict__ expect, const double* __restrict__ counts,
                 int trace_preserving, int mode, int max_iters, double* __restrict__ choi_out, int* __restrict__ iters_out,
@@ -729,7 +735,7 @@ pgdb_pieces_run(char* smem, const DesignDev& des, long long B, const double* __r
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const int stop = piece + 1 < pieces ? (piece + 1) * piece_iters : 0x7fffffff;
-        pgdb_body<NQ, MAXJ, LEAN, true>(smem, item, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
+        pgdb_body<NQ, MAXJ, LEAN, true, TPC>(smem, item, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out,
                                   dykstra_out, backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap,
                                   LEAN ? ncounts + (size_t)blockIdx.x * 2 * MAXJ * 64 : nullptr, trace_out, trace_iters,
                                   recs + (size_t)item * PGDB_REC, stop, piece > 0);

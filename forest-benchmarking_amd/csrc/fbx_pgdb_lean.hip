@@ -37,7 +37,8 @@ pgdb_lean_kernel(DesignDev des, long long B, const double* __restrict__ expect,
 // write-back) and publishes `piece + 1` in the item's progress flag; the consumer polls the flag (relaxed, s_sleep), issues an
 // agent-scope acquire fence and reads.  A ticket's predecessor was drawn nb tickets earlier by a workgroup that is running, so the
 // wait is almost never entered and cannot deadlock.  Results are bit-identical to the one-launch-per-reconstruction form.
-template <int NQ, int MAXJ>
+// (TPC: the kind of projection at compile time -- fbx_pgdb_body.hpp)
+template <int NQ, int MAXJ, int TPC>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 pgdb_lean_pieces_kernel(DesignDev des, long long B, const double* __restrict__ expect,
                         const double* __restrict__ counts, int trace_preserving, int mode, int max_iters,
@@ -48,23 +49,26 @@ pgdb_lean_pieces_kernel(DesignDev des, long long B, const double* __restrict__ e
                         double* __restrict__ ncounts, int* __restrict__ trace_out, int trace_iters,
                         int pieces, int piece_iters, int* __restrict__ queue, int* __restrict__ flags, double* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    pgdb_pieces_run<NQ, MAXJ, true>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out, dykstra_out,
+    pgdb_pieces_run<NQ, MAXJ, true, TPC>(smem, des, B, expect, counts, trace_preserving, mode, max_iters, choi_out, iters_out, dykstra_out,
                                     backtracks_out, cost_out, work_out, phase_out, basis_scratch, basis_cap, ncounts, trace_out,
                                     trace_iters, pieces, piece_iters, queue, flags, recs);
 }
 
+template <int MAXJ, int TPC>
+static int lean_pieces_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {
+    FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_pieces_kernel<2, MAXJ, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FBX_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), st));
+    FBX_HIP(hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)a.nb, st));
+    const unsigned grid = (unsigned)(a.nb < 2048 ? a.nb : 2048);
+    hipLaunchKernelGGL((pgdb_lean_pieces_kernel<2, MAXJ, TPC>), dim3(grid), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
+                       a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters,
+                       a.pieces, a.piece_iters, a.queue, a.flags, a.recs);
+    return FBX_OK;
+}
+
 template <int MAXJ>
 static int lean_launch(size_t lds, hipStream_t st, const PgdbLaunch& a) {
-    if (a.pieces > 1) {
-        FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_pieces_kernel<2, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FBX_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), st));
-        FBX_HIP(hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)a.nb, st));
-        const unsigned grid = (unsigned)(a.nb < 2048 ? a.nb : 2048);
-        hipLaunchKernelGGL((pgdb_lean_pieces_kernel<2, MAXJ>), dim3(grid), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
-                           a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters,
-                           a.pieces, a.piece_iters, a.queue, a.flags, a.recs);
-        return FBX_OK;
-    }
+    if (a.pieces > 1) return a.tp ? lean_pieces_launch<MAXJ, 1>(lds, st, a) : lean_pieces_launch<MAXJ, 0>(lds, st, a);
     FBX_HIP(hipFuncSetAttribute((const void*)pgdb_lean_kernel<2, MAXJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((pgdb_lean_kernel<2, MAXJ>), dim3((unsigned)a.nb), dim3(64), lds, st, a.dev, a.nb, a.e, a.c, a.tp, a.mode, a.max_iters,
                        a.choi, a.it, a.dy, a.bt, a.cost, a.sw, a.phase, a.basis, a.basis_cap, a.ncounts, a.trace, a.trace_iters);
