@@ -17,8 +17,8 @@ wls = sys.argv[4:]
 os.makedirs(dst, exist_ok=True)
 # workload -> (substring of the dominant kernel's name, key in pmc_traffic.json, items per launch)
 WL = {"pgdb": ("pgdb_kernel<2, 9>", "pgdb_kernel_hbm_bytes_per_launch", 1024, "pgdb_kernel<2,9>"),
-      "lean8192": ("pgdb_lean_pieces_kernel<2, 9>", "pgdb_lean8192_hbm_bytes_per_launch", 8192, "pgdb_lean_pieces_kernel<2,9>"),
-      "lean65536": ("pgdb_lean_pieces_kernel<2, 9>", "pgdb_lean65536_hbm_bytes_per_launch", 65536, "pgdb_lean_pieces_kernel<2,9>"),
+      "lean8192": ("pgdb_lean_pieces_kernel<2, 9,", "pgdb_lean8192_hbm_bytes_per_launch", 8192, "pgdb_lean_pieces_kernel<2,9>"),
+      "lean65536": ("pgdb_lean_pieces_kernel<2, 9,", "pgdb_lean65536_hbm_bytes_per_launch", 65536, "pgdb_lean_pieces_kernel<2,9>"),
       "sweep": ("sweep2q_pair_kernel", "sweep_kernel_hbm_bytes_per_launch", 1000000, "sweep2q_pair_kernel"),
       "sweep3": ("sweep3_regs_kernel", "sweep3_kernel_hbm_bytes_per_launch", 65536, "sweep3_regs_kernel"),
       "pgdb3": ("pgdb3_kernel<4>", "pgdb3_kernel_hbm_bytes_per_launch", 256, "pgdb3_kernel<4>"),
